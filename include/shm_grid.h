@@ -1,0 +1,149 @@
+/* shm_grid.h -- C ABI of the MI355X (gfx950) regular-grid Signed Heat Method solver.
+ *
+ * Drop-in boundary for the hot path of nzfeng/signed-heat-3d:
+ *     SignedHeatGridSolver::computeDistance()      src/signed_heat_grid_solver.cpp:5-114  (mesh source)
+ *                                                  src/signed_heat_grid_solver.cpp:116-222 (point source)
+ * The reference has no FFI; the C++ adapter (signed-heat-3d_amd/host/signed_heat_grid_solver.h, same
+ * class surface as include/signed_heat_grid_solver.h:11-22 of the reference) computes the cheap
+ * geometry-dependent pre-processing on the host (centroid/radius/meanEdgeLength/setFaceVectorAreas/
+ * barycenter, signed_heat_3d.cpp:3-89, signed_heat_grid_solver.cpp:498-503) and hands flat arrays to
+ * this library.  Everything from the Step-1 summation to the final shift runs on the GPU.
+ *
+ * Conventions: plain pointers and sizes only; the caller owns every host buffer; the library owns
+ * all device memory; no exception crosses this boundary; every function returns an shm_status and
+ * shm_grid_last_error() gives the message; one solve at a time per handle; a handle pins one HIP
+ * device and its own streams.  Node flattening: idx = i + j*n + k*n*n (x fastest),
+ * signed_heat_grid_solver.cpp:505-508.  There is NO CPU fallback: without a HIP device
+ * shm_grid_create fails with SHM_ERR_HIP.
+ */
+#ifndef SHM_GRID_H
+#define SHM_GRID_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHM_GRID_ABI_VERSION 1
+
+typedef struct shm_solver shm_solver; /* opaque */
+
+typedef enum {
+    SHM_OK = 0,
+    SHM_ERR_INVALID = 1,   /* bad argument / inconsistent sizes */
+    SHM_ERR_HIP = 2,       /* HIP runtime error (incl. "no device") */
+    SHM_ERR_NOMEM = 3,     /* allocation failed */
+    SHM_ERR_BREAKDOWN = 4, /* CG breakdown (p.Kp <= 0 or non-finite residual) */
+    SHM_ERR_NOCONV = 5,    /* max_iters reached before tol (phi is still returned) */
+    SHM_ERR_RCCL = 6,      /* RCCL error */
+    SHM_ERR_STATE = 7,     /* call order violated (e.g. solve before set_problem) */
+    SHM_ERR_SINGULAR = 8   /* A A^T not positive definite */
+} shm_status;
+
+enum { SHM_F64 = 64, SHM_F32 = 32 };
+
+/* Construction-time configuration (replaces `new SignedHeatGridSolver()`, src/main.cpp:290). */
+typedef struct {
+    int32_t device;      /* HIP device ordinal */
+    int32_t precision;   /* SHM_F64 (reference arithmetic) or SHM_F32 */
+    int32_t local_slabs; /* z-slabs owned by THIS process (>=1).  1 in production; >1 runs the same
+                            slab/halo/partial-reduction code path on one GPU (loop-back transport). */
+    int32_t rank;        /* rank of this process among `world` processes (0 when world==1) */
+    int32_t world;       /* number of processes = GPUs; z-slabs are split rank-major */
+    int32_t verbose;     /* mirrors SignedHeatGridSolver::VERBOSE (signed_heat_grid_solver.h:22) */
+    const void* rccl_unique_id; /* 128-byte ncclUniqueId from shm_comm_unique_id() of rank 0; NULL iff world==1 */
+} shm_config;
+
+/* Source geometry, already reduced to what the hot loops read
+ * (signed_heat_grid_solver.cpp:53-57 mesh / :162-166 points). */
+typedef struct {
+    int64_t S;             /* number of sources: faces (mesh) or points (cloud) */
+    const double* pos;     /* [3S] face barycenters (:498-503) or point positions */
+    const double* wnormal; /* [3S] N_f*A_f (:57) or n_p*A_p (:166) */
+    const double* area;    /* [S]  A_f (shoelace, signed_heat_3d.cpp:74-88) or tufted dual area */
+    double lambda;         /* 1/sqrt(tCoef*h^2) (:42-44 / :151-153) */
+} shm_sources;
+
+/* Grid block of signed_heat_grid_solver.cpp:13-26. */
+typedef struct {
+    int32_t n;          /* nodes per side: nx=ny=nz = (size_t)(2*2^(hCoef+3)) */
+    double bbox_min[3]; /* centroid - radius*scale */
+    double cell;        /* 2*s/(n-1) */
+} shm_grid;
+
+typedef struct {
+    int32_t fast_integration; /* SignedHeat3DOptions::fastIntegration (signed_heat_3d.h:27) */
+    int32_t scrub_nonfinite;  /* 1 = mesh overload's divYt scrub (:72-74); 0 = point overload (:180) */
+    double tol;               /* stop when ||P r|| <= tol * ||P b||;  <=0 -> default 1e-8 (fp64) / 1e-5 (fp32) */
+    int32_t max_iters;        /* <=0 -> default 20*n */
+    int32_t check_every;      /* residual is inspected on the host every this many iterations; <=0 -> 32 */
+} shm_opts;
+
+typedef struct {
+    int32_t n, m;             /* grid side; constraint rows (distinct source cells) */
+    int64_t S;
+    int32_t iters;            /* projected-CG iterations executed */
+    double rel_residual;      /* ||P r|| / ||P b|| at exit */
+    double shift;             /* area-weighted mean of phi over the sources that was subtracted */
+    /* device-side timings (hipEvent, ms) */
+    double ms_conv;           /* Steps 1+2 */
+    double ms_div;            /* D^T Y (+ scrub) */
+    double ms_setup;          /* constraint rows, A A^T, Cholesky + triangular inverse */
+    double ms_pcg;            /* projected CG loop */
+    double ms_shift;          /* shift + phi write-out */
+    double ms_total;          /* whole shm_grid_solve */
+    double ms_stencil_avg;    /* average duration of one stencil (q=Kp, p.q) launch inside the loop */
+    double bytes_per_iter;    /* algorithmic HBM bytes per CG iteration of the decomposition launched */
+} shm_stats;
+
+/* --- life cycle -------------------------------------------------------------------------------- */
+shm_status shm_grid_create(const shm_config* cfg, shm_solver** out);
+void shm_grid_destroy(shm_solver* s);
+const char* shm_grid_last_error(const shm_solver* s); /* s may be NULL: error of the failed create */
+int32_t shm_grid_abi_version(void);
+
+/* --- the hot path ------------------------------------------------------------------------------ */
+/* Upload sources + (re)build the grid state.  Equivalent of the `options.rebuild` block
+ * (signed_heat_grid_solver.cpp:8-36) plus making the inputs resident in HBM. */
+shm_status shm_grid_set_problem(shm_solver* s, const shm_sources* src, const shm_grid* grid);
+/* Steps 1-3 + shift on the device; phi stays resident.  (signed_heat_grid_solver.cpp:38-113) */
+shm_status shm_grid_solve(shm_solver* s, const shm_opts* opts, shm_stats* stats);
+/* Copy phi of the z-planes owned by this process to the host: k in [*k_begin,*k_end), x fastest,
+ * (k_end-k_begin)*n*n doubles.  With world==1 that is the whole grid (N = n^3 values). */
+shm_status shm_grid_get_phi(shm_solver* s, double* phi_out, int32_t* k_begin, int32_t* k_end);
+/* One-shot convenience = set_problem + solve + get_phi (world==1 only): the call a C++ adapter's
+ * computeDistance() makes. */
+shm_status shm_grid_compute_distance(shm_solver* s, const shm_sources* src, const shm_grid* grid,
+                                     const shm_opts* opts, double* phi_out, shm_stats* stats);
+
+/* --- stage access (parity tests call these; same kernels as shm_grid_solve) --------------------- */
+typedef enum {
+    SHM_FIELD_Y0 = 0, /* normalised X, x component  (Y[3*idx+0], :60-62) */
+    SHM_FIELD_Y1 = 1,
+    SHM_FIELD_Y2 = 2,
+    SHM_FIELD_DIV = 3, /* divYt (:71-74) */
+    SHM_FIELD_PHI = 4
+} shm_field;
+shm_status shm_grid_run_conv(shm_solver* s);                       /* Steps 1+2 only */
+shm_status shm_grid_run_divergence(shm_solver* s, int32_t scrub);  /* needs run_conv */
+shm_status shm_grid_get_field(shm_solver* s, shm_field f, double* out /* owned planes */);
+/* out = L*u with the reference's Laplacian (signed_heat_grid_solver.cpp:278-334); u,out: n^3 doubles
+ * on the host (world==1). */
+shm_status shm_grid_apply_laplacian(shm_solver* s, const double* u, double* out);
+/* Constraint rows (signed_heat_grid_solver.cpp:80-98): nodes/coeffs hold 8*S entries; *m rows written. */
+shm_status shm_grid_get_constraints(shm_solver* s, int64_t* nodes, double* coeffs, int32_t* m);
+/* v <- v - A^T (A A^T)^-1 A v on the device (the projector inside the CG); v: n^3 doubles, world==1. */
+shm_status shm_grid_apply_projector(shm_solver* s, double* v);
+
+/* --- multi-GPU bootstrap ------------------------------------------------------------------------ */
+/* Fill 128 bytes with a fresh ncclUniqueId (rank 0 calls this, the launcher broadcasts the bytes). */
+shm_status shm_comm_unique_id(void* out128);
+/* z-plane range [k0,k1) owned by slab `slab` of `nslabs` for a grid of n planes (pure host logic). */
+void shm_plan_slab(int32_t n, int32_t nslabs, int32_t slab, int32_t* k0, int32_t* k1);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHM_GRID_H */

@@ -1,0 +1,1029 @@
+// libshm_grid.so -- C ABI (include/shm_grid.h) + host orchestration of the gfx950 kernels.
+//
+// Replaces, for the regular-grid solver of nzfeng/signed-heat-3d:
+//   * the serial source-integration loops        signed_heat_grid_solver.cpp:48-65 / :157-174
+//   * Eigen assembly of D and the product D^T Y   :70-74 / :179-180
+//   * Eigen assembly of L, A, the KKT matrix and its sparse LU (solveSquare)  :80-108 / :186-214
+//     -> matrix-free projected CG on null(A) with a dense (A A^T)^-1
+//   * the shift                                   :110-111 / :216-217
+// One process drives one GPU; the grid is cut into z-slabs (rank-major).  A process may own several
+// slabs (loop-back transport, used to exercise the slab logic on one GPU); across processes the halo
+// planes and the reduction vectors travel over RCCL (xGMI) on the solver's own stream.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/shm_grid.h"
+#include "shm_kernels.hip.h"
+
+namespace shm {
+
+struct Error : std::runtime_error {
+    shm_status code;
+    Error(shm_status c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+static std::string fmt(const char* f, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, f);
+    vsnprintf(buf, sizeof buf, f, ap);
+    va_end(ap);
+    return buf;
+}
+
+#define HIPCHK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            throw shm::Error(e_ == hipErrorOutOfMemory ? SHM_ERR_NOMEM : SHM_ERR_HIP,                        \
+                             shm::fmt("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__)); \
+    } while (0)
+
+// ---- RCCL, resolved lazily (only multi-process runs touch it) -----------------------------------
+struct Rccl {
+    typedef struct ncclComm* comm_t;
+    struct unique_id { char internal[128]; };
+    int (*GetUniqueId)(unique_id*) = nullptr;
+    int (*CommInitRank)(comm_t*, int, unique_id, int) = nullptr;
+    int (*CommDestroy)(comm_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    int (*Send)(const void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    void* h = nullptr;
+    enum { kFloat32 = 7, kFloat64 = 8, kSum = 0 };  // ncclDataType_t / ncclRedOp_t values (rccl.h)
+
+    static Rccl& get() {
+        static Rccl r;
+        if (!r.h) r.load();
+        return r;
+    }
+    void load() {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* nm : names) {
+            h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        if (!h) throw Error(SHM_ERR_RCCL, std::string("cannot load librccl: ") + dlerror());
+#define SYM(field, name)                                                                    \
+    *(void**)(&field) = dlsym(h, name);                                                     \
+    if (!field) throw Error(SHM_ERR_RCCL, std::string("librccl lacks symbol ") + name)
+        SYM(GetUniqueId, "ncclGetUniqueId");
+        SYM(CommInitRank, "ncclCommInitRank");
+        SYM(CommDestroy, "ncclCommDestroy");
+        SYM(AllReduce, "ncclAllReduce");
+        SYM(Send, "ncclSend");
+        SYM(Recv, "ncclRecv");
+        SYM(GroupStart, "ncclGroupStart");
+        SYM(GroupEnd, "ncclGroupEnd");
+        SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    }
+    void chk(int rc, const char* what) {
+        if (rc != 0) throw Error(SHM_ERR_RCCL, fmt("%s failed: %s", what, GetErrorString ? GetErrorString(rc) : "?"));
+    }
+};
+
+template <typename T> struct DevArray {
+    T* p = nullptr;
+    size_t count = 0;
+    DevArray() = default;
+    DevArray(const DevArray&) = delete;
+    DevArray& operator=(const DevArray&) = delete;
+    DevArray(DevArray&& o) noexcept : p(o.p), count(o.count) {
+        o.p = nullptr;
+        o.count = 0;
+    }
+    ~DevArray() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        count = 0;
+    }
+    void alloc(size_t c) {
+        if (c <= count && p) return;
+        release();
+        if (c == 0) c = 1;
+        HIPCHK(hipMalloc((void**)&p, c * sizeof(T)));
+        count = c;
+    }
+    void upload(const std::vector<T>& v, hipStream_t st) {
+        alloc(v.size());
+        if (!v.empty()) HIPCHK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    }
+};
+
+struct Event {
+    hipEvent_t e = nullptr;
+    Event() { HIPCHK(hipEventCreate(&e)); }
+    ~Event() { if (e) (void)hipEventDestroy(e); }
+    Event(const Event&) = delete;
+    void record(hipStream_t s) { HIPCHK(hipEventRecord(e, s)); }
+};
+static float elapsed(Event& a, Event& b) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, a.e, b.e));
+    return ms;
+}
+
+// One constraint row (trilinearCoefficients, signed_heat_grid_solver.cpp:433-464).
+struct Row {
+    int64_t nodes[8];
+    double coeffs[8];
+};
+
+struct SolverBase {
+    virtual ~SolverBase() = default;
+    virtual void set_problem(const shm_sources&, const shm_grid&) = 0;
+    virtual void solve(const shm_opts&, shm_stats*) = 0;
+    virtual void get_phi(double*, int32_t*, int32_t*) = 0;
+    virtual void run_conv() = 0;
+    virtual void run_divergence(int scrub) = 0;
+    virtual void get_field(shm_field, double*) = 0;
+    virtual void apply_laplacian(const double*, double*) = 0;
+    virtual void get_constraints(int64_t*, double*, int32_t*) = 0;
+    virtual void apply_projector(double*) = 0;
+};
+
+template <typename T> constexpr int vec_width() { return sizeof(T) == 8 ? 2 : 4; }
+
+template <typename T>
+struct Slab {
+    int k0 = 0, k1 = 0, nzl = 0;  // owned global planes [k0,k1)
+    size_t plane = 0, nown = 0, ntot = 0;
+    DevArray<T> Y0, Y1, Y2, r /* also divYt */, x, p, q /* also phi */;
+    DevArray<double> partials, red /* [1+m] */, pq /* [1] */, u /* [m] */, sc;
+    // constraint pieces restricted to owned nodes
+    DevArray<int> row_ptr, ent_row, node_ptr;
+    DevArray<uint32_t> ent_node, node_id;
+    DevArray<double> ent_coef, nent_coef;
+    DevArray<ShiftItem> shift_items;
+    int n_touched = 0, n_shift = 0;
+    GridParams gp{};
+};
+
+template <typename T>
+struct Solver final : SolverBase {
+    shm_config cfg;
+    hipStream_t stream = nullptr;
+    int n = 0;
+    size_t N = 0;
+    double cell = 0., lambda = 0.;
+    double bbox_min[3] = {0, 0, 0};
+    int64_t S = 0;
+    std::vector<double> h_pos, h_wn, h_area;
+    double src_center[3] = {0, 0, 0}, src_radius = 0., area_sum = 0.;
+    DevArray<T> d_src;  // [S][6]
+    std::vector<Slab<T>> slabs;
+    int total_slabs = 1, first_slab = 0;
+    bool have_problem = false, have_conv = false, have_div = false, have_phi = false, have_constraints = false;
+    // constraints (replicated)
+    std::vector<Row> rows;
+    int m = 0, mp = 0;
+    DevArray<double> Ginv, gjP, gjR, gjC;
+    DevArray<int> gjFlag;
+    DevArray<double*> d_redptrs;
+    double* h_pinned = nullptr;
+    Rccl::comm_t comm = nullptr;
+    int vec = 1;  // vector width usable for this n
+
+    explicit Solver(const shm_config& c) : cfg(c) {
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev <= 0)
+            throw Error(SHM_ERR_HIP, fmt("no HIP device available (%s); this library has no CPU fallback",
+                                          e == hipSuccess ? "device count 0" : hipGetErrorString(e)));
+        if (cfg.device < 0 || cfg.device >= ndev) throw Error(SHM_ERR_INVALID, fmt("device %d out of range [0,%d)", cfg.device, ndev));
+        HIPCHK(hipSetDevice(cfg.device));
+        HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIPCHK(hipHostMalloc((void**)&h_pinned, 64 * sizeof(double)));
+        if (cfg.world > 1) {
+            if (!cfg.rccl_unique_id) throw Error(SHM_ERR_INVALID, "world>1 needs rccl_unique_id");
+            Rccl& R = Rccl::get();
+            Rccl::unique_id id;
+            memcpy(&id, cfg.rccl_unique_id, sizeof id);
+            R.chk(R.CommInitRank(&comm, cfg.world, id, cfg.rank), "ncclCommInitRank");
+        }
+    }
+    ~Solver() override {
+        (void)hipSetDevice(cfg.device);
+        if (comm) (void)Rccl::get().CommDestroy(comm);
+        if (h_pinned) (void)hipHostFree(h_pinned);
+        slabs.clear();
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    void log(const char* f, ...) {
+        if (!cfg.verbose) return;
+        va_list ap;
+        va_start(ap, f);
+        vfprintf(stderr, f, ap);
+        va_end(ap);
+        fputc('\n', stderr);
+    }
+
+    static int grid_for(size_t work_items, int cap = 2048) {
+        size_t b = (work_items + kBlock - 1) / kBlock;
+        if (b < 1) b = 1;
+        if (b > (size_t)cap) b = cap;
+        return (int)b;
+    }
+
+    // ------------------------------------------------------------------------------------------
+    void set_problem(const shm_sources& src, const shm_grid& g) override {
+        HIPCHK(hipSetDevice(cfg.device));
+        if (g.n < 2) throw Error(SHM_ERR_INVALID, "grid.n must be >= 2");
+        if (!(g.cell > 0.) || !std::isfinite(g.cell)) throw Error(SHM_ERR_INVALID, "grid.cell must be positive and finite");
+        if (src.S <= 0 || !src.pos || !src.wnormal || !src.area) throw Error(SHM_ERR_INVALID, "sources: S>0 and non-null arrays required");
+        if (!(src.lambda > 0.) || !std::isfinite(src.lambda)) throw Error(SHM_ERR_INVALID, "sources.lambda must be positive and finite");
+        if (src.S > (int64_t)1 << 28) throw Error(SHM_ERR_INVALID, "too many sources");
+        total_slabs = cfg.world * cfg.local_slabs;
+        first_slab = cfg.rank * cfg.local_slabs;
+        if (g.n < total_slabs) throw Error(SHM_ERR_INVALID, fmt("grid.n=%d smaller than the number of z-slabs %d", g.n, total_slabs));
+        n = g.n;
+        N = (size_t)n * n * n;
+        cell = g.cell;
+        lambda = src.lambda;
+        for (int a = 0; a < 3; a++) bbox_min[a] = g.bbox_min[a];
+        S = src.S;
+        h_pos.assign(src.pos, src.pos + 3 * S);
+        h_wn.assign(src.wnormal, src.wnormal + 3 * S);
+        h_area.assign(src.area, src.area + S);
+        // every source must lie strictly inside the grid (the reference indexes cell+1 unchecked, :443-449)
+        for (int64_t s = 0; s < S; s++)
+            for (int a = 0; a < 3; a++) {
+                const double d = (h_pos[3 * s + a] - bbox_min[a]) / cell;
+                if (!(d >= 0.) || !(std::floor(d) + 1. <= (double)(n - 1)))
+                    throw Error(SHM_ERR_INVALID, fmt("source %lld lies outside the grid cells", (long long)s));
+            }
+        // bounding sphere of the sources (fp32 exponent offset) and total area
+        double c[3] = {0, 0, 0};
+        for (int64_t s = 0; s < S; s++)
+            for (int a = 0; a < 3; a++) c[a] += h_pos[3 * s + a];
+        for (int a = 0; a < 3; a++) src_center[a] = c[a] / (double)S;
+        src_radius = 0.;
+        area_sum = 0.;
+        for (int64_t s = 0; s < S; s++) {
+            double d2 = 0.;
+            for (int a = 0; a < 3; a++) d2 += (h_pos[3 * s + a] - src_center[a]) * (h_pos[3 * s + a] - src_center[a]);
+            src_radius = std::max(src_radius, std::sqrt(d2));
+            area_sum += h_area[s];  // sequential like `normalization += A` (:477)
+        }
+        std::vector<T> packed((size_t)S * 6);
+        for (int64_t s = 0; s < S; s++)
+            for (int a = 0; a < 3; a++) {
+                packed[6 * s + a] = (T)h_pos[3 * s + a];
+                packed[6 * s + 3 + a] = (T)h_wn[3 * s + a];
+            }
+        d_src.upload(packed, stream);
+
+        vec = (n % vec_width<T>() == 0) ? vec_width<T>() : 1;
+        slabs.clear();
+        slabs.resize(cfg.local_slabs);
+        for (int ls = 0; ls < cfg.local_slabs; ls++) {
+            Slab<T>& sl = slabs[ls];
+            int32_t k0, k1;
+            shm_plan_slab(n, total_slabs, first_slab + ls, &k0, &k1);
+            sl.k0 = k0;
+            sl.k1 = k1;
+            sl.nzl = k1 - k0;
+            sl.plane = (size_t)n * n;
+            sl.nown = sl.plane * sl.nzl;
+            sl.ntot = sl.plane * (sl.nzl + 2);
+            if (sl.ntot >= ((size_t)1 << 32)) throw Error(SHM_ERR_INVALID, "slab too large for 32-bit local node indices; use more slabs");
+            for (DevArray<T>* a : {&sl.Y0, &sl.Y1, &sl.Y2, &sl.r, &sl.x, &sl.p, &sl.q}) a->alloc(sl.ntot);
+            // ghosts of p are read only where a neighbour exists, but zero everything once for hygiene
+            HIPCHK(hipMemsetAsync(sl.p.p, 0, sl.ntot * sizeof(T), stream));
+            HIPCHK(hipMemsetAsync(sl.Y2.p, 0, sl.ntot * sizeof(T), stream));
+            sl.partials.alloc(kMaxPartials);
+            sl.pq.alloc(1);
+            sl.sc.alloc(SC_COUNT);
+            HIPCHK(hipMemsetAsync(sl.sc.p, 0, SC_COUNT * sizeof(double), stream));
+            sl.gp.n = n;
+            sl.gp.nzl = sl.nzl;
+            sl.gp.k0 = sl.k0;
+            sl.gp.inv_h = 1. / cell;
+            sl.gp.inv_h2 = 1. / (cell * cell);
+        }
+        HIPCHK(hipStreamSynchronize(stream));
+        have_problem = true;
+        have_conv = have_div = have_phi = have_constraints = false;
+        log("[shm] problem set: n=%d N=%zu S=%lld slabs=%d(local %d) vec=%d", n, N, (long long)S, total_slabs, cfg.local_slabs, vec);
+    }
+
+    void need_problem() const {
+        if (!have_problem) throw Error(SHM_ERR_STATE, "shm_grid_set_problem has not been called");
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // Steps 1+2
+    void launch_conv() {
+        for (Slab<T>& sl : slabs) {
+            ConvParams P;
+            P.n = n;
+            P.kk_begin = (sl.k0 > 0) ? 0 : 1;                  // low ghost plane exists globally?
+            P.kk_end = (sl.k1 < n) ? sl.nzl + 2 : sl.nzl + 1;  // high ghost plane exists globally?
+            P.k0 = sl.k0;
+            for (int a = 0; a < 3; a++) {
+                P.bbox_min[a] = bbox_min[a];
+                P.center[a] = src_center[a];
+            }
+            P.cell = cell;
+            P.lambda = lambda;
+            P.radius = src_radius;
+            P.S = (int)S;
+            const size_t total = (size_t)(P.kk_end - P.kk_begin) * sl.plane;
+            constexpr int NPT = 2;
+            const unsigned grid = (unsigned)((total + (size_t)kBlock * NPT - 1) / ((size_t)kBlock * NPT));
+            hipLaunchKernelGGL((conv_normalize_kernel<T, NPT>), dim3(grid), dim3(kBlock), 0, stream, P, d_src.p, sl.Y0.p, sl.Y1.p, sl.Y2.p);
+        }
+        HIPCHK(hipGetLastError());
+        have_conv = true;
+    }
+
+    void launch_div(int scrub) {
+        for (Slab<T>& sl : slabs)
+            hipLaunchKernelGGL((divergence_kernel<T>), dim3(grid_for(sl.nown, 4096)), dim3(kBlock), 0, stream, sl.gp, sl.Y0.p, sl.Y1.p, sl.Y2.p,
+                               sl.r.p, scrub);
+        HIPCHK(hipGetLastError());
+        have_div = true;
+    }
+
+    void run_conv() override {
+        need_problem();
+        HIPCHK(hipSetDevice(cfg.device));
+        launch_conv();
+        HIPCHK(hipStreamSynchronize(stream));
+    }
+    void run_divergence(int scrub) override {
+        need_problem();
+        if (!have_conv) throw Error(SHM_ERR_STATE, "run_conv must precede run_divergence");
+        HIPCHK(hipSetDevice(cfg.device));
+        launch_div(scrub);
+        HIPCHK(hipStreamSynchronize(stream));
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // Constraint rows (:80-98 / :186-204), sequential over the sources like the reference.
+    void build_rows() {
+        rows.clear();
+        std::unordered_set<uint64_t> used;
+        used.reserve((size_t)S * 2);
+        const double h = cell;
+        for (int64_t s = 0; s < S; s++) {
+            const double* b = &h_pos[3 * s];
+            const size_t i = (size_t)std::floor((b[0] - bbox_min[0]) / h);
+            const size_t j = (size_t)std::floor((b[1] - bbox_min[1]) / h);
+            const size_t k = (size_t)std::floor((b[2] - bbox_min[2]) / h);
+            const uint64_t cid = i + j * (uint64_t)n + k * (uint64_t)n * n;
+            if (!used.insert(cid).second) continue;
+            Row r;
+            const double tx = (b[0] - (i * h + bbox_min[0])) / h;
+            const double ty = (b[1] - (j * h + bbox_min[1])) / h;
+            const double tz = (b[2] - (k * h + bbox_min[2])) / h;
+            auto ix = [&](size_t a, size_t bb, size_t c) { return (int64_t)(a + bb * (size_t)n + c * (size_t)n * n); };
+            r.nodes[0] = ix(i, j, k);
+            r.nodes[1] = ix(i + 1, j, k);
+            r.nodes[2] = ix(i, j + 1, k);
+            r.nodes[3] = ix(i, j, k + 1);
+            r.nodes[4] = ix(i + 1, j + 1, k);
+            r.nodes[5] = ix(i + 1, j, k + 1);
+            r.nodes[6] = ix(i, j + 1, k + 1);
+            r.nodes[7] = ix(i + 1, j + 1, k + 1);
+            r.coeffs[0] = (1. - tx) * (1. - ty) * (1. - tz);
+            r.coeffs[1] = tx * (1. - ty) * (1. - tz);
+            r.coeffs[2] = (1. - tx) * ty * (1. - tz);
+            r.coeffs[3] = (1. - tx) * (1. - ty) * tz;
+            r.coeffs[4] = tx * ty * (1. - tz);
+            r.coeffs[5] = tx * (1. - ty) * tz;
+            r.coeffs[6] = (1. - tx) * ty * tz;
+            r.coeffs[7] = tx * ty * tz;
+            rows.push_back(r);
+        }
+        m = (int)rows.size();
+        mp = ((m + kGJ - 1) / kGJ) * kGJ;
+    }
+
+    // Per-slab CSR pieces, shift items, and G = A A^T (sparse triplets -> dense on device -> inverted).
+    void build_constraints() {
+        build_rows();
+        const size_t plane = (size_t)n * n;
+        for (Slab<T>& sl : slabs) {
+            const int64_t lo = (int64_t)sl.k0 * (int64_t)plane, hi = (int64_t)sl.k1 * (int64_t)plane;
+            const int64_t shiftoff = (int64_t)plane - lo;  // global node -> local ghost-layout index
+            std::vector<int> row_ptr(m + 1, 0);
+            std::vector<uint32_t> ent_node;
+            std::vector<double> ent_coef;
+            std::vector<std::pair<uint32_t, std::pair<int, double>>> by_node;
+            for (int r = 0; r < m; r++) {
+                for (int e = 0; e < 8; e++) {
+                    const int64_t g = rows[r].nodes[e];
+                    if (g < lo || g >= hi) continue;
+                    const uint32_t l = (uint32_t)(g + shiftoff);
+                    ent_node.push_back(l);
+                    ent_coef.push_back(rows[r].coeffs[e]);
+                    by_node.push_back({l, {r, rows[r].coeffs[e]}});
+                }
+                row_ptr[r + 1] = (int)ent_node.size();
+            }
+            std::stable_sort(by_node.begin(), by_node.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+            std::vector<uint32_t> node_id;
+            std::vector<int> node_ptr, ent_row;
+            std::vector<double> nent_coef;
+            for (size_t a = 0; a < by_node.size(); a++) {
+                if (a == 0 || by_node[a].first != by_node[a - 1].first) {
+                    node_id.push_back(by_node[a].first);
+                    node_ptr.push_back((int)a);
+                }
+                ent_row.push_back(by_node[a].second.first);
+                nent_coef.push_back(by_node[a].second.second);
+            }
+            node_ptr.push_back((int)by_node.size());
+            sl.n_touched = (int)node_id.size();
+            sl.row_ptr.upload(row_ptr, stream);
+            sl.ent_node.upload(ent_node, stream);
+            sl.ent_coef.upload(ent_coef, stream);
+            sl.node_id.upload(node_id, stream);
+            sl.node_ptr.upload(node_ptr, stream);
+            sl.ent_row.upload(ent_row, stream);
+            sl.nent_coef.upload(nent_coef, stream);
+            sl.red.alloc((size_t)m + 1);
+            sl.u.alloc((size_t)std::max(m, 1));
+            // shift items: every source contributes one bilinear evaluation per z-plane of its cell (:405-431)
+            std::vector<ShiftItem> items;
+            for (int64_t s = 0; s < S; s++) {
+                const double* b = &h_pos[3 * s];
+                const int i = (int)std::floor((b[0] - bbox_min[0]) / cell);
+                const int j = (int)std::floor((b[1] - bbox_min[1]) / cell);
+                const int k = (int)std::floor((b[2] - bbox_min[2]) / cell);
+                const double tx = (b[0] - (i * cell + bbox_min[0])) / cell;
+                const double ty = (b[1] - (j * cell + bbox_min[1])) / cell;
+                const double tz = (b[2] - (k * cell + bbox_min[2])) / cell;
+                for (int dz = 0; dz < 2; dz++) {
+                    const int kz = k + dz;
+                    if (kz < sl.k0 || kz >= sl.k1) continue;
+                    ShiftItem it;
+                    it.node = (uint32_t)((size_t)i + (size_t)j * n + (size_t)(kz - sl.k0 + 1) * plane);
+                    it.pad = 0.f;
+                    it.tx = tx;
+                    it.ty = ty;
+                    it.weight = h_area[s] * (dz == 0 ? (1. - tz) : tz);
+                    items.push_back(it);
+                }
+            }
+            sl.n_shift = (int)items.size();
+            sl.shift_items.upload(items, stream);
+        }
+        // ---- G = A A^T as triplets via a node -> entries map
+        std::unordered_map<int64_t, std::vector<std::pair<int, double>>> node_map;
+        node_map.reserve((size_t)m * 4);
+        for (int r = 0; r < m; r++)
+            for (int e = 0; e < 8; e++) node_map[rows[r].nodes[e]].push_back({r, rows[r].coeffs[e]});
+        std::unordered_map<uint64_t, double> gmap;
+        gmap.reserve((size_t)m * 32);
+        for (int r = 0; r < m; r++)
+            for (int e = 0; e < 8; e++)
+                for (const auto& oc : node_map[rows[r].nodes[e]]) gmap[(uint64_t)r * (uint64_t)mp + (uint64_t)oc.first] += rows[r].coeffs[e] * oc.second;
+        Ginv.alloc((size_t)mp * mp);
+        HIPCHK(hipMemsetAsync(Ginv.p, 0, (size_t)mp * mp * sizeof(double), stream));
+        // scatter the (few) non-zeros with 2D copies row by row would be slow; upload triplets and scatter
+        std::vector<uint64_t> tidx;
+        std::vector<double> tval;
+        tidx.reserve(gmap.size() + (mp - m));
+        tval.reserve(gmap.size() + (mp - m));
+        for (const auto& kv : gmap) {
+            tidx.push_back(kv.first);
+            tval.push_back(kv.second);
+        }
+        for (int a = m; a < mp; a++) {  // identity tail keeps the padded matrix SPD
+            tidx.push_back((uint64_t)a * mp + a);
+            tval.push_back(1.0);
+        }
+        DevArray<uint64_t> d_tidx;
+        DevArray<double> d_tval;
+        d_tidx.upload(tidx, stream);
+        d_tval.upload(tval, stream);
+        hipLaunchKernelGGL(scatter_triplets_kernel, dim3(grid_for(tidx.size(), 4096)), dim3(kBlock), 0, stream, (size_t)tidx.size(), d_tidx.p,
+                           d_tval.p, Ginv.p);
+        HIPCHK(hipGetLastError());
+        invert_G();
+        {   // device tables of the per-slab reduction buffers for the loop-back sum
+            std::vector<double*> ptrs;
+            for (Slab<T>& sl : slabs) ptrs.push_back(sl.red.p);
+            for (Slab<T>& sl : slabs) ptrs.push_back(sl.pq.p);
+            d_redptrs.upload(ptrs, stream);
+        }
+        HIPCHK(hipStreamSynchronize(stream));  // d_tidx/d_tval and ptrs go out of scope
+        have_constraints = true;
+    }
+
+    void invert_G() {
+        const int nb = mp / kGJ;
+        gjP.alloc(kGJ * kGJ);
+        gjR.alloc((size_t)kGJ * mp);
+        gjC.alloc((size_t)mp * kGJ);
+        gjFlag.alloc(1);
+        HIPCHK(hipMemsetAsync(gjFlag.p, 0, sizeof(int), stream));
+        for (int kb = 0; kb < nb; kb++) {
+            hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjP.p, gjFlag.p);
+            hipLaunchKernelGGL(gj_panels_kernel, dim3(nb), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjP.p, gjR.p, gjC.p);
+            hipLaunchKernelGGL(gj_update_kernel, dim3(nb, nb), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjP.p, gjR.p, gjC.p);
+        }
+        HIPCHK(hipGetLastError());
+        int flag = 0;
+        HIPCHK(hipMemcpyAsync(&flag, gjFlag.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (flag) throw Error(SHM_ERR_SINGULAR, "A A^T is not positive definite (duplicate or degenerate constraint rows)");
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // transport: sum a per-slab reduction vector over all slabs of all processes
+    void allreduce(int which /*0: red, 1: pq*/, int count) {
+        auto buf = [&](Slab<T>& sl) { return which == 0 ? sl.red.p : sl.pq.p; };
+        if (slabs.size() > 1) {
+            double** slot = d_redptrs.p + (which ? slabs.size() : 0);  // table built in build_constraints()
+            hipLaunchKernelGGL(sum_slabs_kernel, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, (int)slabs.size(), slot, count);
+        }
+        if (comm) {
+            Rccl& R = Rccl::get();
+            R.chk(R.AllReduce(buf(slabs[0]), buf(slabs[0]), (size_t)count, Rccl::kFloat64, Rccl::kSum, comm, stream), "ncclAllReduce");
+            for (size_t s = 1; s < slabs.size(); s++)
+                HIPCHK(hipMemcpyAsync(buf(slabs[s]), buf(slabs[0]), (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        }
+    }
+
+    // transport: fill the ghost planes of `field` (p) from the neighbouring slabs
+    void halo_exchange_p() {
+        const size_t pb = slabs[0].plane * sizeof(T);
+        for (size_t s = 0; s + 1 < slabs.size(); s++) {
+            Slab<T>&a = slabs[s], &b = slabs[s + 1];
+            HIPCHK(hipMemcpyAsync(b.p.p, a.p.p + (size_t)a.nzl * a.plane, pb, hipMemcpyDeviceToDevice, stream));                // a top -> b low ghost
+            HIPCHK(hipMemcpyAsync(a.p.p + (size_t)(a.nzl + 1) * a.plane, b.p.p + b.plane, pb, hipMemcpyDeviceToDevice, stream));  // b bottom -> a high ghost
+        }
+        if (comm) {
+            Rccl& R = Rccl::get();
+            const int dt = sizeof(T) == 8 ? Rccl::kFloat64 : Rccl::kFloat32;
+            Slab<T>&lo = slabs.front(), &hi = slabs.back();
+            const size_t cnt = lo.plane;
+            R.chk(R.GroupStart(), "ncclGroupStart");
+            if (cfg.rank > 0) {
+                R.chk(R.Send(lo.p.p + lo.plane, cnt, dt, cfg.rank - 1, comm, stream), "ncclSend(lo)");
+                R.chk(R.Recv(lo.p.p, cnt, dt, cfg.rank - 1, comm, stream), "ncclRecv(lo)");
+            }
+            if (cfg.rank < cfg.world - 1) {
+                R.chk(R.Send(hi.p.p + (size_t)hi.nzl * hi.plane, cnt, dt, cfg.rank + 1, comm, stream), "ncclSend(hi)");
+                R.chk(R.Recv(hi.p.p + (size_t)(hi.nzl + 1) * hi.plane, cnt, dt, cfg.rank + 1, comm, stream), "ncclRecv(hi)");
+            }
+            R.chk(R.GroupEnd(), "ncclGroupEnd");
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------
+    struct StencilLaunch {
+        dim3 grid, block;
+        int rpb;  // rows per logical block
+    };
+    StencilLaunch stencil_dims(const Slab<T>& sl) const {
+        const int per_row = (n + vec - 1) / vec;
+        int tx = 1;
+        while (tx < per_row && tx < kBlock) tx <<= 1;
+        const int ry = kBlock / tx;
+        const int rows = n * sl.nzl;
+        int rpb = (rows + 4095) / 4096;            // aim at <= 4096 blocks (<= kMaxPartials partial sums)
+        rpb = ((rpb + ry - 1) / ry) * ry;
+        const int nblk = (rows + rpb - 1) / rpb;
+        return {dim3((unsigned)nblk), dim3((unsigned)tx, (unsigned)ry), rpb};
+    }
+
+    void launch_stencil(Slab<T>& sl) {
+        const StencilLaunch L = stencil_dims(sl);
+        if (vec == 1)
+            hipLaunchKernelGGL((stencil_dot_kernel<T, 1>), L.grid, L.block, 0, stream, sl.gp, L.rpb, sl.p.p, sl.q.p, sl.partials.p);
+        else
+            hipLaunchKernelGGL((stencil_dot_kernel<T, vec_width<T>()>), L.grid, L.block, 0, stream, sl.gp, L.rpb, sl.p.p, sl.q.p, sl.partials.p);
+    }
+
+    template <int VEC> void launch_update_xr(Slab<T>& sl, int rho_slot, int grid) {
+        hipLaunchKernelGGL((update_xr_kernel<T, VEC>), dim3(grid), dim3(kBlock), 0, stream, sl.nown / VEC, sl.plane, sl.sc.p, rho_slot, sl.pq.p,
+                           sl.x.p, sl.p.p, sl.r.p, sl.q.p, sl.partials.p);
+    }
+    template <int VEC> void launch_update_p(Slab<T>& sl, int rho_old, int rho_new, int init, int grid) {
+        hipLaunchKernelGGL((update_p_kernel<T, VEC>), dim3(grid), dim3(kBlock), 0, stream, sl.nown / VEC, sl.plane, sl.sc.p, rho_old, rho_new,
+                           sl.red.p, init, sl.r.p, sl.p.p, 1);
+    }
+    template <int VEC> void launch_norm2(Slab<T>& sl, const T* v, int grid) {
+        hipLaunchKernelGGL((norm2_kernel<T, VEC>), dim3(grid), dim3(kBlock), 0, stream, sl.nown / VEC, sl.plane, v, sl.partials.p);
+    }
+
+    int stream_grid(const Slab<T>& sl) const { return grid_for(sl.nown / vec, 2048); }
+
+    // r <- P r on all slabs; leaves red[0] = sum of the first nparts[s] `partials` and sc[SC_UW] = u.w
+    void launch_projection(const std::vector<int>& nparts) {
+        for (size_t s = 0; s < slabs.size(); s++) {
+            Slab<T>& sl = slabs[s];
+            hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(1 + (m + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, m, sl.row_ptr.p, sl.ent_node.p,
+                               sl.ent_coef.p, sl.r.p, sl.partials.p, nparts[s], sl.red.p);
+        }
+        allreduce(0, 1 + m);
+        for (Slab<T>& sl : slabs) {
+            if (m > 0)
+                hipLaunchKernelGGL(ginv_matvec_kernel, dim3((m + 3) / 4), dim3(kBlock), 0, stream, m, mp, Ginv.p, sl.red.p + 1, sl.u.p);
+            hipLaunchKernelGGL((scatter_nodes_kernel<T>), dim3(1 + (sl.n_touched + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sl.n_touched,
+                               sl.node_id.p, sl.node_ptr.p, sl.ent_row.p, sl.nent_coef.p, sl.u.p, sl.red.p + 1, m, sl.sc.p, sl.r.p);
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------
+    void solve(const shm_opts& o_in, shm_stats* st) override {
+        need_problem();
+        HIPCHK(hipSetDevice(cfg.device));
+        shm_opts o = o_in;
+        if (o.fast_integration) throw Error(SHM_ERR_INVALID, "fast_integration (BFS, signed_heat_grid_solver.cpp:224-275) is not implemented on the device yet");
+        if (!(o.tol > 0.)) o.tol = sizeof(T) == 8 ? 1e-8 : 1e-5;
+        if (o.max_iters <= 0) o.max_iters = 20 * n;
+        if (o.check_every <= 0) o.check_every = 32;
+
+        Event e_start, e_conv, e_div, e_setup, e_pcg, e_end;
+        const auto wall0 = std::chrono::steady_clock::now();
+        e_start.record(stream);
+        launch_conv();
+        e_conv.record(stream);
+        launch_div(o.scrub_nonfinite);
+        e_div.record(stream);
+        build_constraints();  // host work overlaps the conv kernel; G^-1 on the device
+        e_setup.record(stream);
+
+        // ---- projected CG: x=0; r=P b; p=-r; loop { q=Kp; a=rho/p.q; x+=a p; r=P(r+a q); p=-r+b p }
+        std::vector<int> nparts(slabs.size());
+        for (size_t s = 0; s < slabs.size(); s++) {
+            Slab<T>& sl = slabs[s];
+            HIPCHK(hipMemsetAsync(sl.x.p, 0, sl.ntot * sizeof(T), stream));
+            nparts[s] = stream_grid(sl);
+            if (vec == 1) launch_norm2<1>(sl, sl.r.p, nparts[s]);
+            else launch_norm2<vec_width<T>()>(sl, sl.r.p, nparts[s]);
+        }
+        launch_projection(nparts);
+        for (size_t s = 0; s < slabs.size(); s++) {
+            if (vec == 1) launch_update_p<1>(slabs[s], SC_RHO_A, SC_RHO_A, 1, nparts[s]);
+            else launch_update_p<vec_width<T>()>(slabs[s], SC_RHO_A, SC_RHO_A, 1, nparts[s]);
+        }
+        HIPCHK(hipGetLastError());
+
+        // sampled per-kernel timing (events on the solver's stream)
+        const int kMaxSamples = 64;
+        std::vector<std::unique_ptr<Event>> ev;
+        if (st) for (int a = 0; a < 2 * kMaxSamples; a++) ev.emplace_back(new Event());
+        int nsamples = 0;
+
+        int it = 0;
+        double rho0 = 0., rho = 0.;
+        bool converged = false, breakdown = false;
+        while (it < o.max_iters && !converged && !breakdown) {
+            const int batch_end = std::min(o.max_iters, it + o.check_every);
+            for (; it < batch_end; it++) {
+                const int slot_old = (it & 1) ? SC_RHO_B : SC_RHO_A, slot_new = (it & 1) ? SC_RHO_A : SC_RHO_B;
+                halo_exchange_p();
+                const bool sample = st && nsamples < kMaxSamples && (it % 8 == 3);
+                if (sample) ev[2 * nsamples]->record(stream);
+                for (Slab<T>& sl : slabs) launch_stencil(sl);
+                if (sample) {
+                    ev[2 * nsamples + 1]->record(stream);
+                    nsamples++;
+                }
+                for (Slab<T>& sl : slabs) {
+                    const StencilLaunch L = stencil_dims(sl);
+                    hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, stream, sl.partials.p, (int)L.grid.x, sl.pq.p);
+                }
+                allreduce(1, 1);
+                for (size_t s = 0; s < slabs.size(); s++) {
+                    if (vec == 1) launch_update_xr<1>(slabs[s], slot_old, nparts[s]);
+                    else launch_update_xr<vec_width<T>()>(slabs[s], slot_old, nparts[s]);
+                }
+                launch_projection(nparts);
+                for (size_t s = 0; s < slabs.size(); s++) {
+                    if (vec == 1) launch_update_p<1>(slabs[s], slot_old, slot_new, 0, nparts[s]);
+                    else launch_update_p<vec_width<T>()>(slabs[s], slot_old, slot_new, 0, nparts[s]);
+                }
+            }
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(h_pinned, slabs[0].sc.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            rho0 = h_pinned[SC_RHO0];
+            rho = h_pinned[(it & 1) ? SC_RHO_B : SC_RHO_A];
+            if (!std::isfinite(rho) || !std::isfinite(rho0)) breakdown = true;
+            else if (rho <= o.tol * o.tol * rho0) converged = true;  // rho = rr - u.w may round slightly below 0 at convergence
+            log("[shm] it=%d rel_res=%.3e", it, std::sqrt(std::fabs(rho / rho0)));
+        }
+        e_pcg.record(stream);
+
+        // ---- shift + phi (:110-111)
+        for (Slab<T>& sl : slabs) {
+            const int g = std::max(1, std::min(256, (sl.n_shift + kBlock - 1) / kBlock));
+            hipLaunchKernelGGL((shift_partial_kernel<T>), dim3(g), dim3(kBlock), 0, stream, sl.n_shift, sl.shift_items.p, n, sl.x.p, sl.partials.p);
+            hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, stream, sl.partials.p, g, sl.pq.p);
+        }
+        allreduce(1, 1);
+        for (Slab<T>& sl : slabs)
+            hipLaunchKernelGGL((write_phi_kernel<T>), dim3(grid_for(sl.nown, 4096)), dim3(kBlock), 0, stream, sl.nown, sl.plane, sl.x.p, sl.pq.p, area_sum,
+                               sl.sc.p, sl.q.p);
+        HIPCHK(hipGetLastError());
+        e_end.record(stream);
+        HIPCHK(hipMemcpyAsync(h_pinned, slabs[0].sc.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        have_phi = true;
+        const auto wall1 = std::chrono::steady_clock::now();
+
+        if (st) {
+            memset(st, 0, sizeof *st);
+            st->n = n;
+            st->m = m;
+            st->S = S;
+            st->iters = it;
+            st->rel_residual = std::sqrt(std::fabs(rho / rho0));
+            st->shift = h_pinned[SC_SHIFT];
+            st->ms_conv = elapsed(e_start, e_conv);
+            st->ms_div = elapsed(e_conv, e_div);
+            st->ms_setup = elapsed(e_div, e_setup);
+            st->ms_pcg = elapsed(e_setup, e_pcg);
+            st->ms_shift = elapsed(e_pcg, e_end);
+            st->ms_total = std::chrono::duration<double, std::milli>(wall1 - wall0).count();
+            double acc = 0.;
+            for (int a = 0; a < nsamples; a++) acc += elapsed(*ev[2 * a], *ev[2 * a + 1]);
+            st->ms_stencil_avg = nsamples ? acc / nsamples : 0.;
+            st->bytes_per_iter = 11.0 * (double)N * sizeof(T);
+        }
+        if (breakdown) throw Error(SHM_ERR_BREAKDOWN, fmt("projected CG broke down at iteration %d (rho=%g, rho0=%g)", it, rho, rho0));
+        if (!converged) throw Error(SHM_ERR_NOCONV, fmt("projected CG: max_iters=%d reached, rel. residual %.3e > tol %.1e", o.max_iters,
+                                                          std::sqrt(std::fabs(rho / rho0)), o.tol));
+    }
+
+    // ------------------------------------------------------------------------------------------
+    void copy_owned_to_host(int which, double* out) {
+        size_t off = 0;
+        for (Slab<T>& sl : slabs) {
+            const T* srcp = nullptr;
+            switch (which) {
+                case SHM_FIELD_Y0: srcp = sl.Y0.p; break;
+                case SHM_FIELD_Y1: srcp = sl.Y1.p; break;
+                case SHM_FIELD_Y2: srcp = sl.Y2.p; break;
+                case SHM_FIELD_DIV: srcp = sl.r.p; break;
+                default: srcp = sl.q.p; break;
+            }
+            srcp += sl.plane;
+            if (sizeof(T) == 8) {
+                HIPCHK(hipMemcpyAsync(out + off, srcp, sl.nown * sizeof(double), hipMemcpyDeviceToHost, stream));
+            } else {
+                DevArray<double> tmp;
+                tmp.alloc(sl.nown);
+                hipLaunchKernelGGL((convert_kernel<T, double>), dim3(grid_for(sl.nown, 4096)), dim3(kBlock), 0, stream, sl.nown, srcp, tmp.p);
+                HIPCHK(hipMemcpyAsync(out + off, tmp.p, sl.nown * sizeof(double), hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+            }
+            off += sl.nown;
+        }
+        HIPCHK(hipStreamSynchronize(stream));
+    }
+
+    void get_phi(double* out, int32_t* kb, int32_t* ke) override {
+        need_problem();
+        if (!have_phi) throw Error(SHM_ERR_STATE, "no phi: shm_grid_solve has not completed");
+        HIPCHK(hipSetDevice(cfg.device));
+        copy_owned_to_host(SHM_FIELD_PHI, out);
+        if (kb) *kb = slabs.front().k0;
+        if (ke) *ke = slabs.back().k1;
+    }
+
+    void get_field(shm_field f, double* out) override {
+        need_problem();
+        HIPCHK(hipSetDevice(cfg.device));
+        if ((f == SHM_FIELD_Y0 || f == SHM_FIELD_Y1 || f == SHM_FIELD_Y2) && !have_conv) throw Error(SHM_ERR_STATE, "Y not computed");
+        if (f == SHM_FIELD_DIV && !have_div) throw Error(SHM_ERR_STATE, "divergence not computed");
+        if (f == SHM_FIELD_PHI && !have_phi) throw Error(SHM_ERR_STATE, "phi not computed");
+        copy_owned_to_host((int)f, out);
+    }
+
+    void upload_owned(const double* in, int which) {
+        // host N-vector -> slab array `which` (0: p with ghosts filled from the host copy, 1: r)
+        std::vector<T> tmp;
+        for (Slab<T>& sl : slabs) {
+            tmp.assign(sl.ntot, (T)0);
+            const int klo = std::max(0, sl.k0 - 1), khi = std::min(n, sl.k1 + 1);
+            for (int k = klo; k < khi; k++)
+                for (size_t a = 0; a < sl.plane; a++) tmp[(size_t)(k - sl.k0 + 1) * sl.plane + a] = (T)in[(size_t)k * sl.plane + a];
+            T* dst = which == 0 ? sl.p.p : sl.r.p;
+            HIPCHK(hipMemcpyAsync(dst, tmp.data(), sl.ntot * sizeof(T), hipMemcpyHostToDevice, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+        }
+    }
+
+    void apply_laplacian(const double* u, double* out) override {
+        need_problem();
+        if (cfg.world != 1) throw Error(SHM_ERR_INVALID, "apply_laplacian is a single-process test entry point");
+        HIPCHK(hipSetDevice(cfg.device));
+        upload_owned(u, 0);
+        for (Slab<T>& sl : slabs)
+            hipLaunchKernelGGL((laplacian_kernel<T>), dim3(grid_for(sl.nown, 4096)), dim3(kBlock), 0, stream, sl.gp, sl.p.p, sl.q.p);
+        HIPCHK(hipGetLastError());
+        copy_owned_to_host(SHM_FIELD_PHI, out);
+    }
+
+    void get_constraints(int64_t* nodes, double* coeffs, int32_t* m_out) override {
+        need_problem();
+        build_rows();
+        for (int r = 0; r < m; r++)
+            for (int e = 0; e < 8; e++) {
+                nodes[8 * (size_t)r + e] = rows[r].nodes[e];
+                coeffs[8 * (size_t)r + e] = rows[r].coeffs[e];
+            }
+        *m_out = m;
+    }
+
+    void apply_projector(double* v) override {
+        need_problem();
+        if (cfg.world != 1) throw Error(SHM_ERR_INVALID, "apply_projector is a single-process test entry point");
+        HIPCHK(hipSetDevice(cfg.device));
+        build_constraints();
+        upload_owned(v, 1);
+        std::vector<int> nparts(slabs.size(), 0);
+        launch_projection(nparts);
+        HIPCHK(hipGetLastError());
+        have_div = true;
+        copy_owned_to_host(SHM_FIELD_DIV, v);
+        have_div = false;
+    }
+};
+
+}  // namespace shm
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+struct shm_solver {
+    std::unique_ptr<shm::SolverBase> impl;
+    std::string err;
+    shm_config cfg;
+};
+
+static thread_local std::string g_create_error;
+
+template <typename F> static shm_status guard(shm_solver* s, F&& f) {
+    if (!s) return SHM_ERR_INVALID;
+    try {
+        f();
+        s->err.clear();
+        return SHM_OK;
+    } catch (const shm::Error& e) {
+        s->err = e.what();
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        s->err = "host allocation failed";
+        return SHM_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        s->err = e.what();
+        return SHM_ERR_INVALID;
+    }
+}
+
+extern "C" {
+
+int32_t shm_grid_abi_version(void) { return SHM_GRID_ABI_VERSION; }
+
+void shm_plan_slab(int32_t n, int32_t nslabs, int32_t slab, int32_t* k0, int32_t* k1) {
+    // balanced contiguous split: the first (n % nslabs) slabs get one extra plane
+    const int32_t q = n / nslabs, r = n % nslabs;
+    const int32_t b = slab * q + (slab < r ? slab : r);
+    if (k0) *k0 = b;
+    if (k1) *k1 = b + q + (slab < r ? 1 : 0);
+}
+
+shm_status shm_grid_create(const shm_config* cfg, shm_solver** out) {
+    if (!cfg || !out) {
+        g_create_error = "null argument";
+        return SHM_ERR_INVALID;
+    }
+    *out = nullptr;
+    try {
+        shm_config c = *cfg;
+        if (c.local_slabs <= 0) c.local_slabs = 1;
+        if (c.world <= 0) c.world = 1;
+        if (c.rank < 0 || c.rank >= c.world) throw shm::Error(SHM_ERR_INVALID, "rank out of range");
+        if (c.precision != SHM_F64 && c.precision != SHM_F32) throw shm::Error(SHM_ERR_INVALID, "precision must be SHM_F64 or SHM_F32");
+        std::unique_ptr<shm_solver> s(new shm_solver());
+        s->cfg = c;
+        if (c.precision == SHM_F64) s->impl.reset(new shm::Solver<double>(c));
+        else s->impl.reset(new shm::Solver<float>(c));
+        *out = s.release();
+        g_create_error.clear();
+        return SHM_OK;
+    } catch (const shm::Error& e) {
+        g_create_error = e.what();
+        return e.code;
+    } catch (const std::exception& e) {
+        g_create_error = e.what();
+        return SHM_ERR_INVALID;
+    }
+}
+
+void shm_grid_destroy(shm_solver* s) { delete s; }
+
+const char* shm_grid_last_error(const shm_solver* s) { return s ? s->err.c_str() : g_create_error.c_str(); }
+
+shm_status shm_grid_set_problem(shm_solver* s, const shm_sources* src, const shm_grid* grid) {
+    return guard(s, [&] {
+        if (!src || !grid) throw shm::Error(SHM_ERR_INVALID, "null argument");
+        s->impl->set_problem(*src, *grid);
+    });
+}
+
+shm_status shm_grid_solve(shm_solver* s, const shm_opts* opts, shm_stats* stats) {
+    return guard(s, [&] {
+        shm_opts o;
+        memset(&o, 0, sizeof o);
+        o.scrub_nonfinite = 1;
+        if (opts) o = *opts;
+        s->impl->solve(o, stats);
+    });
+}
+
+shm_status shm_grid_get_phi(shm_solver* s, double* phi_out, int32_t* k_begin, int32_t* k_end) {
+    return guard(s, [&] {
+        if (!phi_out) throw shm::Error(SHM_ERR_INVALID, "null phi_out");
+        s->impl->get_phi(phi_out, k_begin, k_end);
+    });
+}
+
+shm_status shm_grid_compute_distance(shm_solver* s, const shm_sources* src, const shm_grid* grid, const shm_opts* opts, double* phi_out,
+                                     shm_stats* stats) {
+    shm_status rc = shm_grid_set_problem(s, src, grid);
+    if (rc != SHM_OK) return rc;
+    if (s->cfg.world != 1) {
+        s->err = "shm_grid_compute_distance is the single-process entry point; use set_problem/solve/get_phi per rank";
+        return SHM_ERR_INVALID;
+    }
+    rc = shm_grid_solve(s, opts, stats);
+    if (rc != SHM_OK && rc != SHM_ERR_NOCONV) return rc;
+    std::string keep = s->err;
+    shm_status rc2 = shm_grid_get_phi(s, phi_out, nullptr, nullptr);
+    if (rc2 != SHM_OK) return rc2;
+    s->err = keep;
+    return rc;
+}
+
+shm_status shm_grid_run_conv(shm_solver* s) { return guard(s, [&] { s->impl->run_conv(); }); }
+shm_status shm_grid_run_divergence(shm_solver* s, int32_t scrub) { return guard(s, [&] { s->impl->run_divergence(scrub); }); }
+shm_status shm_grid_get_field(shm_solver* s, shm_field f, double* out) {
+    return guard(s, [&] {
+        if (!out) throw shm::Error(SHM_ERR_INVALID, "null out");
+        s->impl->get_field(f, out);
+    });
+}
+shm_status shm_grid_apply_laplacian(shm_solver* s, const double* u, double* out) {
+    return guard(s, [&] {
+        if (!u || !out) throw shm::Error(SHM_ERR_INVALID, "null argument");
+        s->impl->apply_laplacian(u, out);
+    });
+}
+shm_status shm_grid_get_constraints(shm_solver* s, int64_t* nodes, double* coeffs, int32_t* m) {
+    return guard(s, [&] {
+        if (!nodes || !coeffs || !m) throw shm::Error(SHM_ERR_INVALID, "null argument");
+        s->impl->get_constraints(nodes, coeffs, m);
+    });
+}
+shm_status shm_grid_apply_projector(shm_solver* s, double* v) {
+    return guard(s, [&] {
+        if (!v) throw shm::Error(SHM_ERR_INVALID, "null argument");
+        s->impl->apply_projector(v);
+    });
+}
+
+shm_status shm_comm_unique_id(void* out128) {
+    if (!out128) return SHM_ERR_INVALID;
+    try {
+        shm::Rccl& R = shm::Rccl::get();
+        shm::Rccl::unique_id id;
+        R.chk(R.GetUniqueId(&id), "ncclGetUniqueId");
+        memcpy(out128, &id, sizeof id);
+        return SHM_OK;
+    } catch (const shm::Error& e) {
+        g_create_error = e.what();
+        return e.code;
+    }
+}
+
+}  // extern "C"

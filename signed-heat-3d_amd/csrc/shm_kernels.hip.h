@@ -1,0 +1,618 @@
+// Hand-written gfx950 (CDNA4, wave64) kernels of the grid Signed Heat Method hot path.
+// Every kernel cites the reference lines (into nzfeng/signed-heat-3d) whose arithmetic it reproduces.
+//
+// Data layout in HBM (per z-slab): every N-vector is stored as (nzl+2) planes of n*n values -- one
+// ghost plane below, nzl owned planes, one ghost plane above -- x fastest (idx = i + j*n + kk*n*n),
+// so that the 7-point stencil and the z-differences index ghosts uniformly.  The reference's AoS
+// Y[3*idx+p] (signed_heat_grid_solver.cpp:58) is stored as three planar arrays (3N > 2^31 at 1024^3).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace shm {
+
+constexpr int kWave = 64;       // CDNA wavefront
+constexpr int kBlock = 256;     // 4 waves = one per SIMD
+constexpr int kMaxPartials = 8192;
+
+// ---- wave / block reductions (double accumulators everywhere) -----------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;
+}
+
+// Sum over a 256-thread block; result valid in thread 0.
+__device__ __forceinline__ double block_sum(double v, double* lds /* >= 4 doubles */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) lds[w] = v;
+    __syncthreads();
+    double s = 0.;
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x * blockDim.y + 63) >> 6;
+        for (int a = 0; a < nw; a++) s += lds[a];
+    }
+    return s;
+}
+
+// XCD-aware block remap (8 XCDs, block b is dispatched to XCD b%8): give every XCD one contiguous
+// range of logical blocks so that the z-neighbour planes a block re-reads sit in its own L2.
+// Bijective for any grid size.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+    const unsigned xcd = bid & 7u, slot = bid >> 3;
+    const unsigned q = nblk >> 3, r = nblk & 7u;
+    const unsigned base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
+// =================================================================================================
+// Step 1 + 2: X(x) = sum_s (N_s A_s) exp(-lambda |x-b_s|)/|x-b_s| ;  Y = X/|X|
+//   reference: signed_heat_grid_solver.cpp:48-65 (mesh), :157-174 (points); yukawaPotential
+//   signed_heat_3d.cpp:45-49; node position :510-514.
+// Lanes = grid nodes (NPT per thread for ILP), sources staged through LDS in tiles of kSrcTile and
+// broadcast-read by every lane.  Compute-bound (sqrt+exp+div per pair); HBM traffic is 3 stores/node.
+// For T=float the exponent is offset per node by a lower bound d0 of every source distance so that
+// exp() cannot underflow to 0 for all sources (SURVEY trap #4); the factor cancels in X/|X|.
+// =================================================================================================
+constexpr int kSrcTile = 512;
+
+template <typename T> __device__ __forceinline__ T t_exp(T x);
+template <> __device__ __forceinline__ double t_exp<double>(double x) { return exp(x); }
+template <> __device__ __forceinline__ float t_exp<float>(float x) { return __expf(x); }
+template <typename T> __device__ __forceinline__ T t_sqrt(T x);
+template <> __device__ __forceinline__ double t_sqrt<double>(double x) { return sqrt(x); }
+template <> __device__ __forceinline__ float t_sqrt<float>(float x) { return sqrtf(x); }
+
+struct ConvParams {
+    int n;              // nodes per side
+    int kk_begin;       // first local plane (0 = low ghost) to evaluate
+    int kk_end;         // one past the last local plane
+    int k0;             // global k of local plane 1 (first owned plane)
+    double bbox_min[3];
+    double cell;
+    double lambda;
+    double center[3];   // bounding-sphere centre / radius of the sources (fp32 exponent offset only)
+    double radius;
+    int S;
+};
+
+template <typename T, int NPT>
+__global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, const T* __restrict__ src /* [S][6]: pos xyz, wn xyz */,
+                                                                T* __restrict__ Y0, T* __restrict__ Y1, T* __restrict__ Y2) {
+    __shared__ T tile[kSrcTile * 6];
+    const size_t plane = (size_t)P.n * P.n;
+    const size_t first = (size_t)P.kk_begin * plane;
+    const size_t total = (size_t)(P.kk_end - P.kk_begin) * plane;
+    const size_t base = (size_t)blockIdx.x * (kBlock * NPT) + threadIdx.x;
+
+    T px[NPT], py[NPT], pz[NPT], ax[NPT], ay[NPT], az[NPT], d0[NPT];
+    bool live[NPT];
+#pragma unroll
+    for (int e = 0; e < NPT; e++) {
+        size_t v = base + (size_t)e * kBlock;
+        live[e] = v < total;
+        if (!live[e]) v = total - 1;
+        v += first;
+        const int kk = (int)(v / plane);
+        const int rem = (int)(v - (size_t)kk * plane);
+        const int j = rem / P.n, i = rem - j * P.n;
+        const int k = P.k0 + kk - 1;
+        // indicesToNodePosition: (i,j,k)*cellSize + bboxMin, evaluated in double like the reference
+        const double x = i * P.cell + P.bbox_min[0], y = j * P.cell + P.bbox_min[1], z = k * P.cell + P.bbox_min[2];
+        px[e] = (T)x; py[e] = (T)y; pz[e] = (T)z;
+        ax[e] = ay[e] = az[e] = (T)0;
+        if (sizeof(T) == 4) {
+            const double dx = x - P.center[0], dy = y - P.center[1], dz = z - P.center[2];
+            const double dd = sqrt(dx * dx + dy * dy + dz * dz) - P.radius;
+            d0[e] = (T)(dd > 0. ? dd : 0.);
+        } else {
+            d0[e] = (T)0;
+        }
+    }
+    const T lam = (T)P.lambda;
+    for (int s0 = 0; s0 < P.S; s0 += kSrcTile) {
+        const int cnt = min(kSrcTile, P.S - s0);
+        __syncthreads();
+        for (int a = threadIdx.x; a < cnt * 6; a += kBlock) tile[a] = src[(size_t)s0 * 6 + a];
+        __syncthreads();
+#pragma unroll 2
+        for (int s = 0; s < cnt; s++) {
+            const T sx = tile[6 * s], sy = tile[6 * s + 1], sz = tile[6 * s + 2];
+            const T wx = tile[6 * s + 3], wy = tile[6 * s + 4], wz = tile[6 * s + 5];
+#pragma unroll
+            for (int e = 0; e < NPT; e++) {
+                const T dx = px[e] - sx, dy = py[e] - sy, dz = pz[e] - sz;
+                const T r = t_sqrt<T>(dx * dx + dy * dy + dz * dz);
+                const T g = t_exp<T>(-lam * (r - d0[e])) / r;
+                ax[e] += wx * g; ay[e] += wy * g; az[e] += wz * g;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < NPT; e++) {
+        if (!live[e]) continue;
+        const size_t v = first + base + (size_t)e * kBlock;
+        const T nrm = t_sqrt<T>(ax[e] * ax[e] + ay[e] * ay[e] + az[e] * az[e]);
+        Y0[v] = ax[e] / nrm;  // 0/0 -> NaN exactly like X /= X.norm() (:61)
+        Y1[v] = ay[e] / nrm;
+        Y2[v] = az[e] / nrm;
+    }
+}
+
+// =================================================================================================
+// divYt = D^T Y  (gradient(): signed_heat_grid_solver.cpp:336-402, product :71, scrub :72-74)
+// Closed form of the transpose of the forward-difference operator with its mirrored last row:
+//   b += ( [a>=1] Ya[a-1] + [a==n-1] Ya[a] - [a<n-1] Ya[a] - [a==n-2] Ya[a+1] ) / h   per axis a.
+// One streaming pass: reads Y0 (row), Y1 (rows j+-1), Y2 (planes k+-1, ghosts), writes b.  4NT bytes.
+// =================================================================================================
+struct GridParams {
+    int n;      // nodes per side
+    int nzl;    // owned planes of this slab
+    int k0;     // global k of the first owned plane
+    double inv_h;
+    double inv_h2;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void divergence_kernel(GridParams G, const T* __restrict__ Y0, const T* __restrict__ Y1,
+                                                            const T* __restrict__ Y2, T* __restrict__ b, int scrub) {
+    const int n = G.n;
+    const size_t plane = (size_t)n * n;
+    const size_t nown = (size_t)G.nzl * plane;
+    for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < nown; v += (size_t)gridDim.x * kBlock) {
+        const int kk = (int)(v / plane);
+        const int rem = (int)(v - (size_t)kk * plane);
+        const int j = rem / n, i = rem - j * n;
+        const int k = G.k0 + kk;
+        const size_t c = v + plane;  // skip low ghost plane
+        const T ih = (T)G.inv_h;
+        T acc = (T)0;
+        // x axis
+        if (i >= 1) acc += ih * Y0[c - 1];
+        if (i == n - 1) acc += ih * Y0[c];
+        if (i < n - 1) acc -= ih * Y0[c];
+        if (i == n - 2) acc -= ih * Y0[c + 1];
+        // y axis
+        if (j >= 1) acc += ih * Y1[c - n];
+        if (j == n - 1) acc += ih * Y1[c];
+        if (j < n - 1) acc -= ih * Y1[c];
+        if (j == n - 2) acc -= ih * Y1[c + n];
+        // z axis
+        if (k >= 1) acc += ih * Y2[c - plane];
+        if (k == n - 1) acc += ih * Y2[c];
+        if (k < n - 1) acc -= ih * Y2[c];
+        if (k == n - 2) acc -= ih * Y2[c + plane];
+        if (scrub && !isfinite(acc)) acc = (T)0;
+        b[c] = acc;
+    }
+}
+
+// =================================================================================================
+// q = K p with K = -L, L the reference's 7-point Laplacian (laplacian(): :278-334): an out-of-grid
+// neighbour is replaced by the node itself, everything divided by h^2.  Fused with the partial
+// p.q reduction (double accumulators, one partial per block -> deterministic two-stage sum).
+// Launch: blockDim = (TX, RY); logical block = RY consecutive (j,kk) rows; thread handles VEC
+// consecutive x nodes per step.  Blocks are XCD-remapped so each XCD sweeps a contiguous z-range.
+// Algorithmic HBM bytes: read p once, write q once = 2NT.
+// =================================================================================================
+template <typename T, int VEC> struct VecT;
+template <> struct VecT<double, 2> { using type = double2; };
+template <> struct VecT<float, 4> { using type = float4; };
+template <> struct VecT<double, 1> { using type = double; };
+template <> struct VecT<float, 1> { using type = float; };
+
+template <typename T, int VEC>
+__device__ __forceinline__ void load_vec(const T* p, T (&v)[VEC]) {
+    using V = typename VecT<T, VEC>::type;
+    const V t = *reinterpret_cast<const V*>(p);
+    const T* tp = reinterpret_cast<const T*>(&t);
+#pragma unroll
+    for (int e = 0; e < VEC; e++) v[e] = tp[e];
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void store_vec(T* p, const T (&v)[VEC]) {
+    using V = typename VecT<T, VEC>::type;
+    V t;
+    T* tp = reinterpret_cast<T*>(&t);
+#pragma unroll
+    for (int e = 0; e < VEC; e++) tp[e] = v[e];
+    *reinterpret_cast<V*>(p) = t;
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void stencil_dot_kernel(GridParams G, int rpb, const T* __restrict__ p, T* __restrict__ q,
+                                                             double* __restrict__ partials) {
+    __shared__ double red[8];
+    const int n = G.n;
+    const size_t plane = (size_t)n * n;
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int rows = n * G.nzl;
+    const int row_end = min(rows, (int)(lb + 1) * rpb);
+    const T ih2 = (T)G.inv_h2;
+    double acc = 0.;
+    for (int row = (int)lb * rpb + threadIdx.y; row < row_end; row += blockDim.y) {
+        const int kk = row / n, j = row - kk * n;
+        const int k = G.k0 + kk;
+        const size_t rbase = (size_t)(kk + 1) * plane + (size_t)j * n;
+        // neighbour row offsets; an out-of-grid neighbour is the node itself (:299-319)
+        const ptrdiff_t oym = (j > 0) ? -(ptrdiff_t)n : 0, oyp = (j < n - 1) ? (ptrdiff_t)n : 0;
+        const ptrdiff_t ozm = (k > 0) ? -(ptrdiff_t)plane : 0, ozp = (k < n - 1) ? (ptrdiff_t)plane : 0;
+        for (int i = threadIdx.x * VEC; i < n; i += blockDim.x * VEC) {
+            const T* c = p + rbase + i;
+            T pc[VEC], ym[VEC], yp[VEC], zm[VEC], zp[VEC], out[VEC];
+            load_vec<T, VEC>(c, pc);
+            load_vec<T, VEC>(c + oym, ym);
+            load_vec<T, VEC>(c + oyp, yp);
+            load_vec<T, VEC>(c + ozm, zm);
+            load_vec<T, VEC>(c + ozp, zp);
+            const T left = (i > 0) ? c[-1] : pc[0];
+            const T right = (i + VEC < n) ? c[VEC] : pc[VEC - 1];
+#pragma unroll
+            for (int e = 0; e < VEC; e++) {
+                const T xm = (e == 0) ? left : pc[e - 1];
+                const T xp = (e == VEC - 1) ? right : pc[e + 1];
+                const T s = (xp + yp[e] + zp[e] + xm + ym[e] + zm[e]) - (T)6 * pc[e];
+                out[e] = -s * ih2;
+                acc += (double)pc[e] * (double)out[e];
+            }
+            store_vec<T, VEC>(q + rbase + i, out);
+        }
+    }
+    // block reduction over blockDim.x*blockDim.y == kBlock threads
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) partials[lb] = red[0] + red[1] + red[2] + red[3];
+}
+
+// L*u (not -L) for the operator-identity tests: same stencil, no reduction.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void laplacian_kernel(GridParams G, const T* __restrict__ u, T* __restrict__ out) {
+    const int n = G.n;
+    const size_t plane = (size_t)n * n;
+    const size_t nown = (size_t)G.nzl * plane;
+    for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < nown; v += (size_t)gridDim.x * kBlock) {
+        const int kk = (int)(v / plane);
+        const int rem = (int)(v - (size_t)kk * plane);
+        const int j = rem / n, i = rem - j * n;
+        const int k = G.k0 + kk;
+        const size_t c = v + plane;
+        const T uc = u[c];
+        const T xp = (i < n - 1) ? u[c + 1] : uc, xm = (i > 0) ? u[c - 1] : uc;
+        const T yp = (j < n - 1) ? u[c + n] : uc, ym = (j > 0) ? u[c - n] : uc;
+        const T zp = (k < n - 1) ? u[c + plane] : uc, zm = (k > 0) ? u[c - plane] : uc;
+        out[c] = ((xp + yp + zp + xm + ym + zm) - (T)6 * uc) * (T)G.inv_h2;
+    }
+}
+
+// =================================================================================================
+// Device-resident CG scalars (no host round trip inside the loop)
+// =================================================================================================
+enum Scalar : int {
+    SC_RHO0 = 0,   // ||P b||^2
+    SC_RHO_A = 1,  // rho of even iterations
+    SC_RHO_B = 2,  // rho of odd iterations
+    SC_UW = 3,     // u.w of the current projection
+    SC_SHIFT = 4,  // area-weighted mean of phi along the sources
+    SC_AREA = 5,   // sum of source areas
+    SC_COUNT = 8
+};
+// red[] layout (the all-reduced vector): red[0] = scalar partial sum, red[1..m] = w = A r'
+
+// Sum `np` block partials into *dst (single block; fixed order -> deterministic).
+__global__ __launch_bounds__(kBlock) void finalize_sum_kernel(const double* __restrict__ partials, int np, double* __restrict__ dst) {
+    __shared__ double red[8];
+    double s = 0.;
+    for (int a = threadIdx.x; a < np; a += kBlock) s += partials[a];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) *dst = s;
+}
+
+// x += alpha p ; r += alpha q ; partial ||r||^2     (alpha = rho / (p.Kp))
+// 6NT bytes (read x,p,r,q; write x,r).
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void update_xr_kernel(size_t nvec /* owned/VEC */, size_t off /* ghost plane offset */,
+                                                           const double* __restrict__ sc, int rho_slot, const double* __restrict__ pq,
+                                                           T* __restrict__ x, const T* __restrict__ p, T* __restrict__ r,
+                                                           const T* __restrict__ q, double* __restrict__ partials) {
+    __shared__ double red[8];
+    const double alpha_d = sc[rho_slot] / *pq;
+    const T alpha = (T)alpha_d;
+    double acc = 0.;
+    for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += (size_t)gridDim.x * kBlock) {
+        const size_t c = off + v * VEC;
+        T xv[VEC], pv[VEC], rv[VEC], qv[VEC];
+        load_vec<T, VEC>(x + c, xv);
+        load_vec<T, VEC>(p + c, pv);
+        load_vec<T, VEC>(r + c, rv);
+        load_vec<T, VEC>(q + c, qv);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            xv[e] += alpha * pv[e];
+            rv[e] += alpha * qv[e];
+            acc += (double)rv[e] * (double)rv[e];
+        }
+        store_vec<T, VEC>(x + c, xv);
+        store_vec<T, VEC>(r + c, rv);
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+// partial ||v||^2 over the owned nodes (initial residual)
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void norm2_kernel(size_t nvec, size_t off, const T* __restrict__ v_, double* __restrict__ partials) {
+    __shared__ double red[8];
+    double acc = 0.;
+    for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += (size_t)gridDim.x * kBlock) {
+        T a[VEC];
+        load_vec<T, VEC>(v_ + off + v * VEC, a);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) acc += (double)a[e] * (double)a[e];
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+// p = -r + beta p  with  rho_new = red[0] - u.w  (||r' - A^T u||^2 = ||r'||^2 - u.w because A A^T u = w),
+// beta = rho_new / rho_old.  init!=0: p = -r, rho0 = rho_new.  Block 0 publishes rho_new.   3NT bytes.
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void update_p_kernel(size_t nvec, size_t off, double* __restrict__ sc, int rho_old_slot, int rho_new_slot,
+                                                          const double* __restrict__ red0, int init, const T* __restrict__ r, T* __restrict__ p,
+                                                          int publish) {
+    const double rho_new = *red0 - sc[SC_UW];
+    const double beta_d = init ? 0. : rho_new / sc[rho_old_slot];
+    const T beta = (T)beta_d;
+    for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += (size_t)gridDim.x * kBlock) {
+        const size_t c = off + v * VEC;
+        T rv[VEC], pv[VEC];
+        load_vec<T, VEC>(r + c, rv);
+        if (!init) load_vec<T, VEC>(p + c, pv);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) pv[e] = init ? -rv[e] : (-rv[e] + beta * pv[e]);
+        store_vec<T, VEC>(p + c, pv);
+    }
+    // every block has read sc[rho_old_slot] before any block of the NEXT kernel runs; the new value goes
+    // to the other slot, so there is no intra-kernel race.
+    if (publish && blockIdx.x == 0 && threadIdx.x == 0) {
+        sc[rho_new_slot] = rho_new;
+        if (init) sc[SC_RHO0] = rho_new;
+    }
+}
+
+// =================================================================================================
+// Constraint operator A (trilinearCoefficients :433-464; rows :80-98) restricted to the nodes a slab owns.
+// =================================================================================================
+// red[1+row] = sum_e coef * v[node]  over the slab-owned entries of every row (CSR over all m rows);
+// block 0 additionally folds the scalar partials into red[0].
+template <typename T>
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(int m, const int* __restrict__ row_ptr, const uint32_t* __restrict__ ent_node,
+                                                             const double* __restrict__ ent_coef, const T* __restrict__ v,
+                                                             const double* __restrict__ partials, int np, double* __restrict__ red) {
+    __shared__ double lds[8];
+    if (blockIdx.x == 0) {
+        double s = 0.;
+        for (int a = threadIdx.x; a < np; a += kBlock) s += partials[a];
+        s = block_sum(s, lds);
+        if (threadIdx.x == 0) red[0] = s;
+        return;
+    }
+    const int row = (blockIdx.x - 1) * kBlock + threadIdx.x;
+    if (row >= m) return;
+    double s = 0.;
+    for (int e = row_ptr[row]; e < row_ptr[row + 1]; e++) s += ent_coef[e] * (double)v[ent_node[e]];
+    red[1 + row] = s;
+}
+
+// u = Ginv * w  (Ginv = (A A^T)^-1, dense, row-major, leading dimension ld); one wave per row.
+__global__ __launch_bounds__(kBlock) void ginv_matvec_kernel(int m, int ld, const double* __restrict__ Ginv, const double* __restrict__ w,
+                                                             double* __restrict__ u) {
+    const int row = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= m) return;
+    const double* g = Ginv + (size_t)row * ld;
+    double s = 0.;
+    for (int c = lane; c < m; c += kWave) s += g[c] * w[c];
+    s = wave_sum(s);
+    if (lane == 0) u[row] = s;
+}
+
+// v[node] -= sum_e coef * u[row]  (node-major lists: no atomics, deterministic); block 0 also
+// computes u.w into sc[SC_UW].
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scatter_nodes_kernel(int nnodes, const uint32_t* __restrict__ node_id, const int* __restrict__ node_ptr,
+                                                               const int* __restrict__ ent_row, const double* __restrict__ ent_coef,
+                                                               const double* __restrict__ u, const double* __restrict__ w, int m,
+                                                               double* __restrict__ sc, T* __restrict__ v) {
+    __shared__ double lds[8];
+    if (blockIdx.x == 0) {
+        double s = 0.;
+        for (int a = threadIdx.x; a < m; a += kBlock) s += u[a] * w[a];
+        s = block_sum(s, lds);
+        if (threadIdx.x == 0) sc[SC_UW] = s;
+        return;
+    }
+    const int t = (blockIdx.x - 1) * kBlock + threadIdx.x;
+    if (t >= nnodes) return;
+    double s = 0.;
+    for (int e = node_ptr[t]; e < node_ptr[t + 1]; e++) s += ent_coef[e] * u[ent_row[e]];
+    v[node_id[t]] = (T)((double)v[node_id[t]] - s);
+}
+
+// =================================================================================================
+// Shift (evaluateAverageAlongSourceGeometry :466-496 -> evaluateFunction :405-431): per source and per
+// z-plane of its cell the bilinear value (x lerp then y lerp) times area*(1-tz | tz); the owner of the
+// plane evaluates it, so slabs sum to the reference's nested lerp.  phi = -x here.
+// =================================================================================================
+struct ShiftItem {
+    uint32_t node;  // local index (ghost layout) of the (i,j) corner in the plane
+    float pad;
+    double tx, ty, weight;  // weight = area * (1-tz) or area * tz
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void shift_partial_kernel(int nitems, const ShiftItem* __restrict__ items, int n, const T* __restrict__ x,
+                                                               double* __restrict__ partials) {
+    __shared__ double red[8];
+    double acc = 0.;
+    for (int a = blockIdx.x * kBlock + threadIdx.x; a < nitems; a += gridDim.x * kBlock) {
+        const ShiftItem it = items[a];
+        const double v00 = -(double)x[it.node], v10 = -(double)x[it.node + 1];
+        const double v01 = -(double)x[it.node + n], v11 = -(double)x[it.node + n + 1];
+        const double a0 = v00 * (1. - it.tx) + v10 * it.tx;
+        const double a1 = v01 * (1. - it.tx) + v11 * it.tx;
+        acc += it.weight * (a0 * (1. - it.ty) + a1 * it.ty);
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+// phi = -x - shift   (:108, :111), written as double for the caller regardless of T.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void write_phi_kernel(size_t nown, size_t off, const T* __restrict__ x, const double* __restrict__ red0,
+                                                           double area_sum, double* __restrict__ sc, T* __restrict__ phi) {
+    const double shift = *red0 / area_sum;
+    for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < nown; v += (size_t)gridDim.x * kBlock)
+        phi[off + v] = (T)(-(double)x[off + v] - shift);
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc[SC_SHIFT] = shift;
+}
+
+// sum the per-slab reduction vectors of the slabs this process owns and write the result back to all of them
+__global__ __launch_bounds__(kBlock) void sum_slabs_kernel(int nslabs, double* const* __restrict__ bufs, int count) {
+    const int a = blockIdx.x * kBlock + threadIdx.x;
+    if (a >= count) return;
+    double s = 0.;
+    for (int t = 0; t < nslabs; t++) s += bufs[t][a];
+    for (int t = 0; t < nslabs; t++) bufs[t][a] = s;
+}
+
+// dense[idx[a]] = val[a]  (non-zeros of G = A A^T, each index unique)
+__global__ __launch_bounds__(kBlock) void scatter_triplets_kernel(size_t cnt, const uint64_t* __restrict__ idx, const double* __restrict__ val,
+                                                                  double* __restrict__ dense) {
+    for (size_t a = (size_t)blockIdx.x * kBlock + threadIdx.x; a < cnt; a += (size_t)gridDim.x * kBlock) dense[idx[a]] = val[a];
+}
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(kBlock) void convert_kernel(size_t count, const TS* __restrict__ src, TD* __restrict__ dst) {
+    for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < count; v += (size_t)gridDim.x * kBlock) dst[v] = (TD)src[v];
+}
+
+// =================================================================================================
+// Dense in-place inversion of the SPD matrix G = A A^T (m x m, padded to a multiple of 64 with an
+// identity tail) by blocked Gauss-Jordan without pivoting (Schur complements of an SPD matrix stay
+// SPD).  Setup-time only; replaces the reference's sparse LU of the KKT matrix (:101-107) together
+// with the projected CG.  Per 64-wide pivot block kb:
+//   1. P = inv(G[kb,kb])                                   (one workgroup, LDS)
+//   2. R = P * G[kb,:]  (row panel),  C = G[:,kb] (saved column panel)
+//   3. G[i,j] -= C[i] * R[j]   for i,j outside kb           (rank-64 update, LDS-tiled)
+//   4. G[kb,:] = R ; G[:,kb] = -C * P ; G[kb,kb] = P
+// =================================================================================================
+constexpr int kGJ = 64;
+
+// step 1: invert the 64x64 pivot block in LDS (Gauss-Jordan, SPD -> no pivoting); 256 threads.
+__global__ __launch_bounds__(kBlock) void gj_pivot_kernel(double* __restrict__ G, int ld, int kb, double* __restrict__ Pout, int* __restrict__ flag) {
+    __shared__ double a[kGJ][kGJ + 1];
+    __shared__ double colk[kGJ];
+    __shared__ double rowk[kGJ];
+    const size_t o = (size_t)kb * kGJ;
+    for (int t = threadIdx.x; t < kGJ * kGJ; t += kBlock) a[t / kGJ][t % kGJ] = G[(o + t / kGJ) * ld + o + t % kGJ];
+    __syncthreads();
+    for (int k = 0; k < kGJ; k++) {
+        const double piv = a[k][k];
+        if (threadIdx.x == 0 && !(piv > 0.)) *flag = 1;
+        if (threadIdx.x < kGJ) {
+            colk[threadIdx.x] = a[threadIdx.x][k];
+            rowk[threadIdx.x] = a[k][threadIdx.x];
+        }
+        __syncthreads();
+        const double ip = 1. / piv;
+        for (int t = threadIdx.x; t < kGJ * kGJ; t += kBlock) {
+            const int i = t / kGJ, j = t % kGJ;
+            double v;
+            if (i == k && j == k) v = ip;
+            else if (i == k) v = rowk[j] * ip;
+            else if (j == k) v = -colk[i] * ip;
+            else v = a[i][j] - colk[i] * rowk[j] * ip;
+            a[i][j] = v;
+        }
+        __syncthreads();
+    }
+    for (int t = threadIdx.x; t < kGJ * kGJ; t += kBlock) Pout[t] = a[t / kGJ][t % kGJ];
+}
+
+// step 2: R[:, jb] = P * G[kb, jb] and C[ib, :] = G[ib, kb] for every block index != kb.
+// grid.x = number of 64-blocks; block b handles column block jb=b of the row panel and row block ib=b
+// of the column panel.
+__global__ __launch_bounds__(kBlock) void gj_panels_kernel(const double* __restrict__ G, int ld, int kb, const double* __restrict__ P,
+                                                           double* __restrict__ R /* [64][ld] */, double* __restrict__ C /* [ld][64] */) {
+    __shared__ double p[kGJ][kGJ + 1];
+    __shared__ double g[kGJ][kGJ + 1];
+    const int b = blockIdx.x;
+    const size_t o = (size_t)kb * kGJ, ob = (size_t)b * kGJ;
+    for (int t = threadIdx.x; t < kGJ * kGJ; t += kBlock) {
+        const int i = t / kGJ, j = t % kGJ;
+        p[i][j] = P[t];
+        g[i][j] = G[(o + i) * ld + ob + j];                 // row panel block
+        C[(ob + i) * kGJ + j] = G[(ob + i) * ld + o + j];   // column panel block (copy)
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < kGJ * kGJ; t += kBlock) {
+        const int i = t / kGJ, j = t % kGJ;
+        double s = 0.;
+#pragma unroll 8
+        for (int k = 0; k < kGJ; k++) s += p[i][k] * g[k][j];
+        R[(size_t)i * ld + ob + j] = s;
+    }
+}
+
+// step 3+4: 64x64 output tile per block, 4x4 outputs per thread, K = 64 through LDS.
+__global__ __launch_bounds__(kBlock) void gj_update_kernel(double* __restrict__ G, int ld, int kb, const double* __restrict__ P,
+                                                           const double* __restrict__ R, const double* __restrict__ C) {
+    __shared__ double cs[kGJ][kGJ + 1];  // C tile  [i][k]
+    __shared__ double rs[kGJ][kGJ + 1];  // R tile  [k][j]  (or P for the column-panel rewrite)
+    const int ib = blockIdx.y, jb = blockIdx.x;
+    const size_t oi = (size_t)ib * kGJ, oj = (size_t)jb * kGJ;
+    const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
+    if (ib == kb && jb == kb) {  // G[kb,kb] = P
+        for (int t = threadIdx.x; t < kGJ * kGJ; t += kBlock) G[(oi + t / kGJ) * ld + oj + t % kGJ] = P[t];
+        return;
+    }
+    if (ib == kb) {  // G[kb, jb] = R
+        for (int t = threadIdx.x; t < kGJ * kGJ; t += kBlock) G[(oi + t / kGJ) * ld + oj + t % kGJ] = R[(size_t)(t / kGJ) * ld + oj + t % kGJ];
+        return;
+    }
+    for (int t = threadIdx.x; t < kGJ * kGJ; t += kBlock) {
+        const int i = t / kGJ, j = t % kGJ;
+        cs[i][j] = C[(oi + i) * kGJ + j];
+        rs[i][j] = (jb == kb) ? P[t] : R[(size_t)i * ld + oj + j];
+    }
+    __syncthreads();
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = 0.;
+#pragma unroll 4
+    for (int k = 0; k < kGJ; k++) {
+        double cv[4], rv[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) cv[a] = cs[ty * 4 + a][k];
+#pragma unroll
+        for (int b = 0; b < 4; b++) rv[b] = rs[k][tx * 4 + b];
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) acc[a][b] += cv[a] * rv[b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            double* dst = &G[(oi + ty * 4 + a) * ld + oj + tx * 4 + b];
+            *dst = (jb == kb) ? -acc[a][b] : (*dst - acc[a][b]);
+        }
+}
+
+}  // namespace shm

@@ -1,0 +1,218 @@
+"""ctypes binding of include/shm_grid.h (libshm_grid.so).  Plumbing only: no arithmetic happens here.
+
+There is deliberately no CPU fallback: if the shared library is missing, or no HIP device is visible,
+construction raises (ShmError / OSError).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+SHM_F64, SHM_F32 = 64, 32
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+STATUS_NAMES = {0: "SHM_OK", 1: "SHM_ERR_INVALID", 2: "SHM_ERR_HIP", 3: "SHM_ERR_NOMEM", 4: "SHM_ERR_BREAKDOWN",
+                5: "SHM_ERR_NOCONV", 6: "SHM_ERR_RCCL", 7: "SHM_ERR_STATE", 8: "SHM_ERR_SINGULAR"}
+
+# every symbol include/shm_grid.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = ["shm_grid_create", "shm_grid_destroy", "shm_grid_last_error", "shm_grid_abi_version", "shm_grid_set_problem",
+               "shm_grid_solve", "shm_grid_get_phi", "shm_grid_compute_distance", "shm_grid_run_conv", "shm_grid_run_divergence",
+               "shm_grid_get_field", "shm_grid_apply_laplacian", "shm_grid_get_constraints", "shm_grid_apply_projector",
+               "shm_comm_unique_id", "shm_plan_slab"]
+
+
+class ShmError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("%s: %s" % (STATUS_NAMES.get(status, status), message))
+        self.status = status
+
+
+class _Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("precision", C.c_int32), ("local_slabs", C.c_int32), ("rank", C.c_int32),
+                ("world", C.c_int32), ("verbose", C.c_int32), ("rccl_unique_id", C.c_void_p)]
+
+
+class _Sources(C.Structure):
+    _fields_ = [("S", C.c_int64), ("pos", C.c_void_p), ("wnormal", C.c_void_p), ("area", C.c_void_p), ("lam", C.c_double)]
+
+
+class _Grid(C.Structure):
+    _fields_ = [("n", C.c_int32), ("bbox_min", C.c_double * 3), ("cell", C.c_double)]
+
+
+class _Opts(C.Structure):
+    _fields_ = [("fast_integration", C.c_int32), ("scrub_nonfinite", C.c_int32), ("tol", C.c_double), ("max_iters", C.c_int32),
+                ("check_every", C.c_int32)]
+
+
+class ShmStats(C.Structure):
+    _fields_ = [("n", C.c_int32), ("m", C.c_int32), ("S", C.c_int64), ("iters", C.c_int32), ("rel_residual", C.c_double),
+                ("shift", C.c_double), ("ms_conv", C.c_double), ("ms_div", C.c_double), ("ms_setup", C.c_double),
+                ("ms_pcg", C.c_double), ("ms_shift", C.c_double), ("ms_total", C.c_double), ("ms_stencil_avg", C.c_double),
+                ("bytes_per_iter", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libshm_grid.so")
+
+
+_LIB = None
+
+
+def load_library():
+    """Load libshm_grid.so (built in-tree by __graft_entry__.build() / make -C signed-heat-3d_amd/csrc)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise OSError("libshm_grid.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` (%s)" % path)
+    lib = C.CDLL(path)
+    lib.shm_grid_last_error.restype = C.c_char_p
+    lib.shm_grid_last_error.argtypes = [C.c_void_p]
+    lib.shm_grid_create.argtypes = [C.POINTER(_Config), C.POINTER(C.c_void_p)]
+    lib.shm_grid_destroy.argtypes = [C.c_void_p]
+    lib.shm_grid_destroy.restype = None
+    lib.shm_grid_set_problem.argtypes = [C.c_void_p, C.POINTER(_Sources), C.POINTER(_Grid)]
+    lib.shm_grid_solve.argtypes = [C.c_void_p, C.POINTER(_Opts), C.POINTER(ShmStats)]
+    lib.shm_grid_get_phi.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.shm_grid_compute_distance.argtypes = [C.c_void_p, C.POINTER(_Sources), C.POINTER(_Grid), C.POINTER(_Opts), C.c_void_p,
+                                              C.POINTER(ShmStats)]
+    lib.shm_grid_run_conv.argtypes = [C.c_void_p]
+    lib.shm_grid_run_divergence.argtypes = [C.c_void_p, C.c_int32]
+    lib.shm_grid_get_field.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.shm_grid_apply_laplacian.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.shm_grid_get_constraints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+    lib.shm_grid_apply_projector.argtypes = [C.c_void_p, C.c_void_p]
+    lib.shm_comm_unique_id.argtypes = [C.c_void_p]
+    lib.shm_plan_slab.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.shm_plan_slab.restype = None
+    _LIB = lib
+    return lib
+
+
+def plan_slab(n, nslabs, slab):
+    lib = load_library()
+    k0, k1 = C.c_int32(), C.c_int32()
+    lib.shm_plan_slab(n, nslabs, slab, C.byref(k0), C.byref(k1))
+    return k0.value, k1.value
+
+
+def comm_unique_id():
+    lib = load_library()
+    buf = C.create_string_buffer(128)
+    rc = lib.shm_comm_unique_id(buf)
+    if rc != 0:
+        raise ShmError(rc, lib.shm_grid_last_error(None).decode())
+    return buf.raw
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class GridSolver:
+    """Thin handle around shm_solver*.  Mirrors the C ABI one to one."""
+
+    FIELD_Y0, FIELD_Y1, FIELD_Y2, FIELD_DIV, FIELD_PHI = 0, 1, 2, 3, 4
+
+    def __init__(self, device=0, precision=SHM_F64, local_slabs=1, rank=0, world=1, verbose=False, rccl_unique_id=None):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self._uid = C.create_string_buffer(rccl_unique_id, 128) if rccl_unique_id is not None else None
+        cfg = _Config(device, precision, local_slabs, rank, world, int(verbose),
+                      C.cast(self._uid, C.c_void_p) if self._uid is not None else None)
+        rc = self._lib.shm_grid_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            raise ShmError(rc, self._lib.shm_grid_last_error(None).decode())
+        self.n = 0
+        self.world, self.rank, self.local_slabs = world, rank, local_slabs
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.shm_grid_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, allow=()):
+        if rc != 0 and rc not in allow:
+            raise ShmError(rc, self._lib.shm_grid_last_error(self._h).decode())
+        return rc
+
+    def set_problem(self, pos, wnormal, area, lam, n, bbox_min, cell):
+        pos, wnormal, area = _f64(pos).reshape(-1), _f64(wnormal).reshape(-1), _f64(area).reshape(-1)
+        S = area.shape[0]
+        assert pos.shape[0] == 3 * S and wnormal.shape[0] == 3 * S
+        src = _Sources(S, pos.ctypes.data, wnormal.ctypes.data, area.ctypes.data, float(lam))
+        g = _Grid(int(n), (C.c_double * 3)(*[float(v) for v in bbox_min]), float(cell))
+        self._keep = (pos, wnormal, area)
+        self._chk(self._lib.shm_grid_set_problem(self._h, C.byref(src), C.byref(g)))
+        self.n, self.S = int(n), S
+
+    def owned_planes(self):
+        first = self.rank * self.local_slabs
+        total = self.world * self.local_slabs
+        return plan_slab(self.n, total, first)[0], plan_slab(self.n, total, first + self.local_slabs - 1)[1]
+
+    def solve(self, tol=0.0, max_iters=0, check_every=0, scrub=True, fast=False, allow_noconv=False):
+        o = _Opts(int(fast), int(scrub), float(tol), int(max_iters), int(check_every))
+        st = ShmStats()
+        self._chk(self._lib.shm_grid_solve(self._h, C.byref(o), C.byref(st)), allow=(5,) if allow_noconv else ())
+        return st
+
+    def _owned_count(self):
+        k0, k1 = self.owned_planes()
+        return (k1 - k0) * self.n * self.n
+
+    def get_phi(self):
+        out = np.empty(self._owned_count(), dtype=np.float64)
+        k0, k1 = C.c_int32(), C.c_int32()
+        self._chk(self._lib.shm_grid_get_phi(self._h, out.ctypes.data, C.byref(k0), C.byref(k1)))
+        return out, (k0.value, k1.value)
+
+    def run_conv(self):
+        self._chk(self._lib.shm_grid_run_conv(self._h))
+
+    def run_divergence(self, scrub=True):
+        self._chk(self._lib.shm_grid_run_divergence(self._h, int(scrub)))
+
+    def get_field(self, which):
+        out = np.empty(self._owned_count(), dtype=np.float64)
+        self._chk(self._lib.shm_grid_get_field(self._h, int(which), out.ctypes.data))
+        return out
+
+    def apply_laplacian(self, u):
+        u = _f64(u).reshape(-1)
+        out = np.empty_like(u)
+        self._chk(self._lib.shm_grid_apply_laplacian(self._h, u.ctypes.data, out.ctypes.data))
+        return out
+
+    def get_constraints(self):
+        nodes = np.empty(8 * self.S, dtype=np.int64)
+        coeffs = np.empty(8 * self.S, dtype=np.float64)
+        m = C.c_int32()
+        self._chk(self._lib.shm_grid_get_constraints(self._h, nodes.ctypes.data, coeffs.ctypes.data, C.byref(m)))
+        return nodes[:8 * m.value].reshape(-1, 8).copy(), coeffs[:8 * m.value].reshape(-1, 8).copy()
+
+    def apply_projector(self, v):
+        v = _f64(v).reshape(-1).copy()
+        self._chk(self._lib.shm_grid_apply_projector(self._h, v.ctypes.data))
+        return v
+
+    def compute_distance(self, pos, wnormal, area, lam, n, bbox_min, cell, **kw):
+        """One-shot convenience mirroring shm_grid_compute_distance (set_problem + solve + get_phi)."""
+        self.set_problem(pos, wnormal, area, lam, n, bbox_min, cell)
+        st = self.solve(**kw)
+        phi, _ = self.get_phi()
+        return phi, st
