@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- end-to-end grid Signed Heat Method throughput on MI355X (BASELINE.json metric).
+
+One "step" = one full device-resident pass of the hot path (Step 1+2 direct summation, divergence,
+constraint set-up incl. (A A^T)^-1, projected CG to the stated tolerance, shift) over one synthetic-free
+input (the reference's own data files) whose sources and grid are already resident in HBM.
+
+    python bench.py                       # N=1, workload = BASELINE.json configs[1]: bunny_small.obj, 256^3, fp64
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W          # z-slab partition over N GPUs, RCCL halo + all-reduce
+
+Prints ONE JSON line on rank 0.  `value` = grid nodes / s of the whole job (strong scaling: the grid is fixed,
+its z-slabs are spread over the ranks).  `roofline` is for the dominant kernel of the CG loop, with the kernel's
+duration measured live by HIP events on the solver's stream.  `cpu_baseline` times the C oracle (a port of the
+reference's serial loops, oracle/shm_oracle.c) on this box's host cores over a bounded sample.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (file, hCoef, precision)    n = 2*2^(hCoef+3)
+    "bunny_small_256_f64": ("data/bunny_small.obj", 4.0, 64),   # BASELINE.json configs[1]
+    "bunny_small_64_f64": ("data/bunny_small.obj", 2.0, 64),    # configs[0] (the reference's CPU-runnable case)
+    "bunny_small_128_f64": ("data/bunny_small.obj", 3.0, 64),
+    "rocker_512_f32": ("data/rocker.obj", 5.0, 32),             # configs[2]
+    "bunny_pc_512_f64": ("data/bunny.pc", 5.0, 64),             # configs[3]
+    "spraybottle_pc_1024_f32": ("data/SprayBottle.pc", 6.0, 32),  # configs[4] (.obj missing upstream -> .pc)
+    "bunny_small_512_f64": ("data/bunny_small.obj", 5.0, 64),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured streaming ceiling
+
+
+def cpu_baseline(pre, iters_gpu, tol, seconds_budget=25.0):
+    """Time the C oracle (kind "port": the reference's serial loops restated in C, 1 thread like the reference)
+    on a bounded sample: `planes` z-planes of the Step-1 summation (linear in planes) and `cg_its` iterations of
+    the host projected CG incl. its set-up, both extrapolated to the full job the GPU ran."""
+    import subprocess
+    so = os.path.join(ROOT, "oracle", "_build", "libshm_oracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(so)
+    f64 = np.ctypeslib.ndpointer(np.float64, flags="C")
+    i64 = np.ctypeslib.ndpointer(np.int64, flags="C")
+    ci, cd = ctypes.c_int, ctypes.c_double
+    lib.shmo_conv_normalize.argtypes = [ci, f64, cd, ci, f64, f64, cd, ci, ci, f64]
+    lib.shmo_divergence.argtypes = [ci, cd, f64, ci, f64]
+    lib.shmo_constraint_rows.argtypes = [ci, f64, cd, ci, f64, i64, f64]
+    lib.shmo_constraint_rows.restype = ci
+    lib.shmo_constrained_solve.argtypes = [ci, cd, f64, ci, i64, f64, cd, ci, f64, f64]
+    lib.shmo_set_threads.argtypes = [ci]
+    lib.shmo_set_threads(1)
+    n, S = pre["n"], pre["S"]
+    N = n ** 3
+    bbox = np.ascontiguousarray(pre["bbox_min"])
+    pos = np.ascontiguousarray(pre["pos"]).reshape(-1)
+    wn = np.ascontiguousarray(pre["wnormal"]).reshape(-1)
+    # --- Step 1+2 on a few z-planes
+    pairs_per_plane = n * n * S
+    planes = int(max(1, min(n, round(0.4 * seconds_budget / (pairs_per_plane * 22e-9)))))
+    Y = np.zeros(3 * N)
+    k0 = n // 2
+    t = time.perf_counter()
+    lib.shmo_conv_normalize(n, bbox, pre["cell"], S, pos, wn, pre["lam"], k0, k0 + planes, Y)
+    t_conv_sample = time.perf_counter() - t
+    t_conv = t_conv_sample * n / planes
+    # --- divergence (full) on a synthetic unit field: cost does not depend on the values
+    Y[:] = 1.0 / np.sqrt(3.0)
+    b = np.zeros(N)
+    t = time.perf_counter()
+    lib.shmo_divergence(n, pre["cell"], Y, 1, b)
+    t_div = time.perf_counter() - t
+    del Y
+    # --- constrained solve: set-up + a few CG iterations on a smooth synthetic right-hand side
+    nodes = np.zeros(8 * S, dtype=np.int64)
+    coeffs = np.zeros(8 * S)
+    m = lib.shmo_constraint_rows(n, bbox, pre["cell"], S, pos, nodes, coeffs)
+    rng = np.random.default_rng(0)
+    b = rng.standard_normal(N)
+    phi = np.zeros(N)
+    st = np.zeros(3)
+    t = time.perf_counter()
+    lib.shmo_constrained_solve(n, pre["cell"], b, m, nodes, coeffs, 0.0, 0, phi, st)   # set-up only (0 iterations)
+    t_setup = time.perf_counter() - t
+    cg_its = int(max(2, min(40, round(0.4 * seconds_budget / (N * 9e-9)))))
+    t = time.perf_counter()
+    lib.shmo_constrained_solve(n, pre["cell"], b, m, nodes, coeffs, 0.0, cg_its, phi, st)
+    t_iter = max(1e-9, (time.perf_counter() - t - t_setup)) / cg_its
+    total = t_conv + t_div + t_setup + t_iter * iters_gpu
+    return {
+        "value": N / total, "unit": "grid-nodes/s", "cores": 1, "kind": "port",
+        "sample": "C port of the reference's serial loops (oracle/shm_oracle.c, gcc -O3 -march=native, 1 thread): Step 1+2 on %d of %d "
+                  "z-planes (%.2f s, extrapolated linearly to %.0f s), divergence in full (%.2f s), dense-Cholesky projector set-up "
+                  "(%.2f s), %d projected-CG iterations (%.3f s each) extrapolated to the %d iterations the GPU run needed at the same "
+                  "tolerance %.1e" % (planes, n, t_conv_sample, t_conv, t_div, t_setup, cg_its, t_iter, iters_gpu, tol),
+        "seconds_extrapolated": total,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="bunny_small_256_f64", choices=sorted(WORKLOADS))
+    ap.add_argument("--tol", type=float, default=0.0, help="projected-CG relative residual tolerance (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+
+    import shm_import
+    shm = shm_import.load()
+    from signed_heat_3d_amd.host_abi import HostSolver
+
+    uid = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        box = [shm.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+
+    path, hCoef, precision = WORKLOADS[args.workload]
+    host = HostSolver(os.path.join(ROOT, path))          # C++ host mirror: loaders + signed_heat_3d.cpp helpers
+    pre = host.preprocess(hCoef=hCoef)                    # centroid/radius/h/areas/barycenters on the host (cheap)
+    n, N = pre["n"], pre["n"] ** 3
+
+    solver = shm.GridSolver(device=local_rank, precision=precision, rank=rank, world=world, rccl_unique_id=uid)
+    solver.set_problem(pre["pos"], pre["wnormal"], pre["area"], pre["lam"], n, pre["bbox_min"], pre["cell"])  # inputs resident in HBM
+    scrub = not path.endswith(".pc")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    st = None
+    for _ in range(args.warmup):
+        st = solver.solve(tol=args.tol, scrub=scrub)
+    barrier()
+    t0 = time.perf_counter()
+    stats = []
+    for _ in range(args.steps):
+        st = solver.solve(tol=args.tol, scrub=scrub)
+        stats.append(st.as_dict())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        T = precision // 8
+        avg = {k: float(np.mean([s[k] for s in stats])) for k in stats[0]}
+        # per-kernel algorithmic bytes of the decomposition launched; per rank = per launch
+        n_local = N / world
+        kernels = {
+            "stencil_dot_kernel": (2 * n_local * T, avg["ms_stencil_avg"]),
+            "update_xr_kernel": (6 * n_local * T, avg["ms_update_xr_avg"]),
+            "update_p_kernel": (3 * n_local * T, avg["ms_update_p_avg"]),
+        }
+        kinfo = {k: {"algorithmic_bytes": b, "avg_ms": ms, "achieved_GBps": (b / (ms * 1e-3) / 1e9 if ms > 0 else None)}
+                 for k, (b, ms) in kernels.items()}
+        dominant = max(kernels, key=lambda k: kernels[k][1])
+        ach = kinfo[dominant]["achieved_GBps"] or 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(args.workload, {}).get(dominant)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "grid-nodes/sec end-to-end SHM (conv+PCG)", "value": N * args.steps / elapsed, "unit": "grid-nodes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64" if precision == 64 else "f32",
+            "data": "reference data file %s (no RNG; sources + grid resident in HBM before the timed region)" % path,
+            "config": {"workload": args.workload, "grid": "%d^3" % n, "sources": int(pre["S"]), "constraint_rows": int(avg["m"]),
+                       "tol": args.tol if args.tol > 0 else (1e-8 if precision == 64 else 1e-5), "cg_iters": int(avg["iters"]),
+                       "rel_residual": avg["rel_residual"], "partition": "z-slabs x%d" % world},
+            "phases_ms": {k: avg[k] for k in ("ms_conv", "ms_div", "ms_setup", "ms_pcg", "ms_shift", "ms_total")},
+            "pcg": {"ms_per_iter": avg["ms_pcg"] / max(1.0, avg["iters"]), "algorithmic_bytes_per_iter": 11 * n_local * T,
+                    "achieved_GBps": 11 * n_local * T / (avg["ms_pcg"] / max(1.0, avg["iters"]) * 1e-3) / 1e9,
+                    "frac_of_hbm_peak": 11 * n_local * T / (avg["ms_pcg"] / max(1.0, avg["iters"]) * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "kernels": kinfo,
+            "roofline": {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "note": "achieved = algorithmic bytes per launch / avg launch duration (HIP events on the solver stream, "
+                                 "%d sampled launches per solve)" % int(avg["kernel_samples"])},
+        }
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(pre, int(avg["iters"]), out["config"]["tol"])
+                out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+            except Exception as e:  # the baseline is informational; never lose the GPU line over it
+                out["cpu_baseline"] = {"value": None, "unit": "grid-nodes/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -94,8 +94,13 @@ typedef struct {
     double ms_pcg;            /* projected CG loop */
     double ms_shift;          /* shift + phi write-out */
     double ms_total;          /* whole shm_grid_solve */
-    double ms_stencil_avg;    /* average duration of one stencil (q=Kp, p.q) launch inside the loop */
-    double bytes_per_iter;    /* algorithmic HBM bytes per CG iteration of the decomposition launched */
+    /* per-kernel averages inside the CG loop, hipEvents on the solver's stream around sampled launches */
+    double ms_stencil_avg;    /* q = K p + partial p.q                       2NT algorithmic bytes */
+    double ms_update_xr_avg;  /* x += a p, r += a q + partial ||r||^2        6NT */
+    double ms_project_avg;    /* gather A r, (A A^T)^-1 matvec, scatter A^T u (m-sized, not N-sized) */
+    double ms_update_p_avg;   /* p = -r + b p                                3NT */
+    int32_t kernel_samples;   /* how many iterations were sampled for the four averages above */
+    double bytes_per_iter;    /* algorithmic HBM bytes per CG iteration of the decomposition launched (11NT) */
 } shm_stats;
 
 /* --- life cycle -------------------------------------------------------------------------------- */

@@ -685,10 +685,10 @@ struct Solver final : SolverBase {
         }
         HIPCHK(hipGetLastError());
 
-        // sampled per-kernel timing (events on the solver's stream)
-        const int kMaxSamples = 64;
+        // sampled per-kernel timing (events on the solver's stream; 6 events per sampled iteration)
+        const int kMaxSamples = 48, kEvPer = 6;
         std::vector<std::unique_ptr<Event>> ev;
-        if (st) for (int a = 0; a < 2 * kMaxSamples; a++) ev.emplace_back(new Event());
+        if (st) for (int a = 0; a < kEvPer * kMaxSamples; a++) ev.emplace_back(new Event());
         int nsamples = 0;
 
         int it = 0;
@@ -700,26 +700,31 @@ struct Solver final : SolverBase {
                 const int slot_old = (it & 1) ? SC_RHO_B : SC_RHO_A, slot_new = (it & 1) ? SC_RHO_A : SC_RHO_B;
                 halo_exchange_p();
                 const bool sample = st && nsamples < kMaxSamples && (it % 8 == 3);
-                if (sample) ev[2 * nsamples]->record(stream);
+                auto mark = [&](int k) {
+                    if (sample) ev[kEvPer * nsamples + k]->record(stream);
+                };
+                mark(0);
                 for (Slab<T>& sl : slabs) launch_stencil(sl);
-                if (sample) {
-                    ev[2 * nsamples + 1]->record(stream);
-                    nsamples++;
-                }
+                mark(1);
                 for (Slab<T>& sl : slabs) {
                     const StencilLaunch L = stencil_dims(sl);
                     hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, stream, sl.partials.p, (int)L.grid.x, sl.pq.p);
                 }
                 allreduce(1, 1);
+                mark(2);
                 for (size_t s = 0; s < slabs.size(); s++) {
                     if (vec == 1) launch_update_xr<1>(slabs[s], slot_old, nparts[s]);
                     else launch_update_xr<vec_width<T>()>(slabs[s], slot_old, nparts[s]);
                 }
+                mark(3);
                 launch_projection(nparts);
+                mark(4);
                 for (size_t s = 0; s < slabs.size(); s++) {
                     if (vec == 1) launch_update_p<1>(slabs[s], slot_old, slot_new, 0, nparts[s]);
                     else launch_update_p<vec_width<T>()>(slabs[s], slot_old, slot_new, 0, nparts[s]);
                 }
+                mark(5);
+                if (sample) nsamples++;
             }
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(h_pinned, slabs[0].sc.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -763,9 +768,19 @@ struct Solver final : SolverBase {
             st->ms_pcg = elapsed(e_setup, e_pcg);
             st->ms_shift = elapsed(e_pcg, e_end);
             st->ms_total = std::chrono::duration<double, std::milli>(wall1 - wall0).count();
-            double acc = 0.;
-            for (int a = 0; a < nsamples; a++) acc += elapsed(*ev[2 * a], *ev[2 * a + 1]);
-            st->ms_stencil_avg = nsamples ? acc / nsamples : 0.;
+            double acc[4] = {0, 0, 0, 0};
+            for (int a = 0; a < nsamples; a++) {
+                acc[0] += elapsed(*ev[kEvPer * a + 0], *ev[kEvPer * a + 1]);
+                acc[1] += elapsed(*ev[kEvPer * a + 2], *ev[kEvPer * a + 3]);
+                acc[2] += elapsed(*ev[kEvPer * a + 3], *ev[kEvPer * a + 4]);
+                acc[3] += elapsed(*ev[kEvPer * a + 4], *ev[kEvPer * a + 5]);
+            }
+            const double inv = nsamples ? 1. / nsamples : 0.;
+            st->ms_stencil_avg = acc[0] * inv;
+            st->ms_update_xr_avg = acc[1] * inv;
+            st->ms_project_avg = acc[2] * inv;
+            st->ms_update_p_avg = acc[3] * inv;
+            st->kernel_samples = nsamples;
             st->bytes_per_iter = 11.0 * (double)N * sizeof(T);
         }
         if (breakdown) throw Error(SHM_ERR_BREAKDOWN, fmt("projected CG broke down at iteration %d (rho=%g, rho0=%g)", it, rho, rho0));

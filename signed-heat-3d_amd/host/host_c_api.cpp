@@ -1,0 +1,147 @@
+// Flat C wrapper around the C++ host layer so that Python tests / bench.py can drive the same code path the
+// headless CLI uses (ctypes cannot call C++ methods).  Not part of the drop-in boundary.
+#include <cstring>
+#include <string>
+
+#include "mesh_io.h"
+#include "signed_heat_grid_solver.h"
+
+using namespace shm_host;
+
+namespace {
+thread_local std::string g_err;
+struct Host {
+    SignedHeatGridSolver solver;
+    VertexPositionGeometry mesh;
+    PointPositionNormalGeometry cloud;
+    bool is_cloud = false;
+    explicit Host(const GridBackendOptions& b) : solver(b) {}
+};
+template <typename F> int guard(F&& f) {
+    try {
+        f();
+        g_err.clear();
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return 1;
+    }
+}
+}  // namespace
+
+extern "C" {
+
+const char* shmh_last_error(void) { return g_err.c_str(); }
+
+void* shmh_new(int device, int precision, double tol, int max_iters, int local_slabs, int verbose) {
+    GridBackendOptions b;
+    b.device = device;
+    b.precision = precision;
+    b.tol = tol;
+    b.maxIters = max_iters;
+    b.localSlabs = local_slabs;
+    Host* h = new Host(b);
+    h->solver.VERBOSE = verbose != 0;
+    return h;
+}
+void shmh_delete(void* h) { delete (Host*)h; }
+
+int shmh_load(void* hv, const char* path) {
+    Host* h = (Host*)hv;
+    return guard([&] {
+        const std::string p(path);
+        const std::string ext = p.substr(p.find_last_of(".") + 1);
+        h->is_cloud = (ext == "pc");  // src/main.cpp:267-268
+        if (h->is_cloud) h->cloud = readPointCloud(p);
+        else h->mesh = readSurfaceMesh(p);
+    });
+}
+
+// counts: [0]=vertices/points [1]=faces
+void shmh_counts(void* hv, int64_t* counts) {
+    Host* h = (Host*)hv;
+    counts[0] = h->is_cloud ? (int64_t)h->cloud.positions.size() : (int64_t)h->mesh.vertexPositions.size();
+    counts[1] = h->is_cloud ? 0 : (int64_t)h->mesh.mesh.nFaces();
+}
+
+int shmh_set_point_areas(void* hv, const double* areas, double h_len) {
+    Host* h = (Host*)hv;
+    return guard([&] {
+        h->cloud.dualAreas.assign(areas, areas + h->cloud.positions.size());
+        h->cloud.meanEdgeLength = h_len;
+    });
+}
+
+// Host pre-processing only (no GPU): centroid[3], radius, h, lambda, n, bbox_min[3], cell -> out[11];
+// pos/wnormal (3S) and area (S) may be NULL.  S is returned through *S_out.
+int shmh_preprocess(void* hv, double tCoef, double hCoef, double scale, double* out, double* pos, double* wn, double* area, int64_t* S_out) {
+    Host* h = (Host*)hv;
+    return guard([&] {
+        Vector3 c;
+        double r, hh;
+        size_t S;
+        if (h->is_cloud) {
+            c = centroid(h->cloud);
+            r = radius(h->cloud, c);
+            if (h->cloud.dualAreas.size() != h->cloud.positions.size() || !(h->cloud.meanEdgeLength > 0.)) estimatePointAreas(h->cloud);
+            hh = h->cloud.meanEdgeLength;
+            S = h->cloud.positions.size();
+        } else {
+            c = centroid(h->mesh);
+            r = radius(h->mesh, c);
+            hh = meanEdgeLength(h->mesh);
+            S = h->mesh.mesh.nFaces();
+        }
+        const double s = r * scale;
+        const size_t n = (size_t)(2 * std::pow(2, hCoef + 3));
+        for (int a = 0; a < 3; a++) out[a] = c[a];
+        out[3] = r;
+        out[4] = hh;
+        out[5] = std::sqrt(1. / (tCoef * hh * hh));
+        out[6] = (double)n;
+        for (int a = 0; a < 3; a++) out[7 + a] = c[a] - s;
+        out[10] = 2. * s / (n - 1);
+        *S_out = (int64_t)S;
+        if (!pos) return;
+        if (h->is_cloud) {
+            for (size_t p = 0; p < S; p++) {
+                const Vector3 w = h->cloud.normals[p] * h->cloud.dualAreas[p];
+                for (int a = 0; a < 3; a++) {
+                    pos[3 * p + a] = h->cloud.positions[p][a];
+                    wn[3 * p + a] = w[a];
+                }
+                area[p] = h->cloud.dualAreas[p];
+            }
+        } else {
+            std::vector<double> areas;
+            std::vector<Vector3> normals;
+            setFaceVectorAreas(h->mesh, areas, normals);
+            for (size_t f = 0; f < S; f++) {
+                const Vector3 b = barycenter(h->mesh, f), w = normals[f] * areas[f];
+                for (int a = 0; a < 3; a++) {
+                    pos[3 * f + a] = b[a];
+                    wn[3 * f + a] = w[a];
+                }
+                area[f] = areas[f];
+            }
+        }
+    });
+}
+
+// computeDistance through the C++ class; phi_out holds n^3 doubles (n from shmh_preprocess).
+int shmh_compute_distance(void* hv, double tCoef, double hCoef, double scale, int rebuild, int fast, double* phi_out, shm_stats* stats) {
+    Host* h = (Host*)hv;
+    return guard([&] {
+        SignedHeat3DOptions o;
+        o.tCoef = tCoef;
+        o.hCoef = hCoef;
+        o.scale = scale;
+        o.rebuild = rebuild != 0;
+        o.fastIntegration = fast != 0;
+        VectorXd phi = h->is_cloud ? h->solver.computeDistance(h->cloud, o) : h->solver.computeDistance(h->mesh, o);
+        std::memcpy(phi_out, phi.data(), phi.size() * sizeof(double));
+        if (stats) *stats = h->solver.lastStats();
+    });
+}
+
+}  // extern "C"

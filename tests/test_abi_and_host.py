@@ -1,0 +1,116 @@
+"""CPU tests (no GPU, no compute calls): the C-ABI library loads and exports every symbol of include/shm_grid.h,
+fails loudly without a device, and the C++ host mirror's pre-processing reproduces the oracle's golden values."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+
+def test_library_exports_every_declared_symbol(shm):
+    lib = shm.load_library()
+    header = open(os.path.join(ROOT, "include", "shm_grid.h")).read()
+    declared = set(re.findall(r"\b(shm_(?:grid|comm|plan)_\w+)\s*\(", header))
+    from signed_heat_3d_amd.grid_abi import ABI_SYMBOLS
+    assert declared == set(ABI_SYMBOLS), declared ^ set(ABI_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.shm_grid_abi_version() == 1
+
+
+def test_no_cpu_fallback(shm):
+    """Without a HIP device the product path must fail loudly (this container has no GPU; on the GPU box the test is
+    vacuous and skipped)."""
+    try:
+        s = shm.GridSolver()
+    except shm.ShmError as e:
+        assert e.status == 2 and "no CPU fallback" in str(e)
+    else:
+        s.close()
+        pytest.skip("a HIP device is present")
+
+
+def test_stats_struct_layout_matches_header(shm):
+    """ctypes mirror of shm_stats must have the same size as the C struct (checked through the C++ host library, which
+    copies an shm_stats by value)."""
+    header = open(os.path.join(ROOT, "include", "shm_grid.h")).read()
+    body = header[header.index("typedef struct {\n    int32_t n, m;"):header.index("} shm_stats;")]
+    fields = re.findall(r"\b(?:int32_t|int64_t|double)\s+([\w, ]+);", body)
+    names = [n.strip() for f in fields for n in f.split(",")]
+    assert names == [n for n, _ in shm.ShmStats._fields_]
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 8])
+def test_slab_plan_is_a_partition(shm, n):
+    for planes in (16, 24, 33, 512):
+        if planes < n:
+            continue
+        ranges = [shm.plan_slab(planes, n, s) for s in range(n)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == planes
+        for a, b in zip(ranges, ranges[1:]):
+            assert a[1] == b[0]
+        sizes = [b - a for a, b in ranges]
+        assert max(sizes) - min(sizes) <= 1 and min(sizes) >= 1
+
+
+@pytest.mark.parametrize("case,path,hc", [("bunny_small_n16", "data/bunny_small.obj", 0.0), ("bunny_small_n24", "data/bunny_small.obj", None),
+                                          ("bunny_small_n32", "data/bunny_small.obj", 1.0), ("polygon_bear_n16", "data/polygon-bear.obj", 0.0)])
+def test_host_mirror_preprocessing_matches_golden(shm, case, path, hc):
+    """centroid / radius / meanEdgeLength / setFaceVectorAreas / barycenter of the C++ host layer vs the oracle."""
+    from signed_heat_3d_amd.host_abi import HostSolver
+    d = load_golden(case)
+    if hc is None:
+        hc = float(d["hCoef"])
+    h = HostSolver(os.path.join(ROOT, path))
+    r = h.preprocess(hCoef=hc)
+    assert r["n"] == int(d["n"])
+    assert np.abs(r["centroid"] - d["centroid"]).max() < 1e-14
+    assert abs(r["radius"] - float(d["radius"])) < 1e-14
+    assert abs(r["h"] - float(d["h_mesh"])) < 1e-14
+    assert abs(r["lam"] - float(d["lam"])) < 1e-12
+    assert np.abs(r["bbox_min"] - d["bbox_min"]).max() < 1e-14 and abs(r["cell"] - float(d["cell"])) < 1e-15
+    scale = np.abs(d["pos"]).max()
+    assert np.abs(r["pos"] - d["pos"]).max() < 1e-15 * scale
+    assert np.abs(r["wnormal"] - d["wnormal"]).max() < 1e-13 * np.abs(d["wnormal"]).max()
+    assert np.abs(r["area"] - d["area"]).max() < 1e-13 * np.abs(d["area"]).max()
+
+
+def test_host_mirror_strips_unreferenced_vertices(shm):
+    from signed_heat_3d_amd.host_abi import HostSolver
+    g = load_golden("rocker_preproc")
+    h = HostSolver(os.path.join(ROOT, "data", "rocker.obj"))
+    assert h.counts() == (int(g["nV"]), int(g["nF"])) == (8742, 13819)
+    r = h.preprocess(hCoef=2.0)
+    assert np.abs(r["centroid"] - g["centroid"]).max() < 1e-13
+    assert abs(r["radius"] - float(g["radius"])) < 1e-13 and abs(r["h"] - float(g["h_mesh"])) < 1e-13
+    assert abs(r["area"].sum() - float(g["area_sum"])) < 1e-10
+    assert np.abs(r["pos"][:64] - g["pos_head"]).max() < 1e-13 and np.abs(r["wnormal"][:64] - g["wnormal_head"]).max() < 1e-13
+
+
+def test_host_mirror_point_cloud(shm):
+    """.pc loader (src/main.cpp:196-225) and explicit area/h inputs (tufted-triangulation values in the demo)."""
+    from signed_heat_3d_amd.host_abi import HostSolver
+    d = load_golden("bunny_pc_n16")
+    h = HostSolver(os.path.join(ROOT, "data", "bunny.pc"))
+    assert h.counts() == (1430, 0)
+    h.set_point_areas(d["area"], float(d["h_in"]))
+    r = h.preprocess(hCoef=0.0)
+    assert np.abs(r["pos"] - d["pos"]).max() < 1e-14 and np.abs(r["wnormal"] - d["wnormal"]).max() < 1e-14
+    assert abs(r["lam"] - float(d["lam"])) < 1e-12 and np.abs(r["bbox_min"] - d["bbox_min"]).max() < 1e-14
+    # headless estimator: plausibility only (mesh dual areas sum 9.4887, h 0.095)
+    h2 = HostSolver(os.path.join(ROOT, "data", "bunny.pc"))
+    r2 = h2.preprocess()
+    assert 0.5 * 9.4887 < r2["area"].sum() < 1.5 * 9.4887
+    assert 0.6 * 0.095 < r2["h"] < 1.4 * 0.095
+
+
+def test_cli_reports_missing_device_or_runs():
+    import subprocess
+    exe = os.path.join(ROOT, "signed-heat-3d_amd", "bin", "shm_grid_cli")
+    p = subprocess.run([exe, "--help"], capture_output=True, text=True)
+    assert p.returncode == 0 and "--h <hCoef>" in p.stdout
+    p = subprocess.run([exe], capture_output=True, text=True)
+    assert p.returncode != 0 and "Please specify a mesh file" in p.stderr
