@@ -78,8 +78,14 @@ typedef struct {
     int32_t scrub_nonfinite;  /* 1 = mesh overload's divYt scrub (:72-74); 0 = point overload (:180) */
     double tol;               /* stop when ||P r|| <= tol * ||P b||;  <=0 -> default 1e-8 (fp64) / 1e-5 (fp32) */
     int32_t max_iters;        /* <=0 -> default 20*n */
-    int32_t check_every;      /* residual is inspected on the host every this many iterations; <=0 -> 32 */
+    int32_t check_every;      /* residual is inspected on the host every this many iterations; <=0 -> 32 (8 with the preconditioner) */
+    int32_t preconditioner;   /* SHM_PRECOND_AUTO | _NONE | _DCT */
 } shm_opts;
+
+/* Preconditioner of the projected CG.  DCT = exact fast Poisson solve (3-D DCT-II diagonalises the reference's
+ * Neumann Laplacian, signed_heat_grid_solver.cpp:278-334) sandwiched between constraint projections; needs n = 2^k,
+ * 16 <= n <= 1024 and a single z-slab.  AUTO picks DCT when available, otherwise NONE (plain projected CG). */
+enum { SHM_PRECOND_AUTO = 0, SHM_PRECOND_NONE = 1, SHM_PRECOND_DCT = 2 };
 
 typedef struct {
     int32_t n, m;             /* grid side; constraint rows (distinct source cells) */
@@ -98,9 +104,11 @@ typedef struct {
     double ms_stencil_avg;    /* q = K p + partial p.q                       2NT algorithmic bytes */
     double ms_update_xr_avg;  /* x += a p, r += a q + partial ||r||^2        6NT */
     double ms_project_avg;    /* gather A r, (A A^T)^-1 matvec, scatter A^T u (m-sized, not N-sized) */
-    double ms_update_p_avg;   /* p = -r + b p                                3NT */
-    int32_t kernel_samples;   /* how many iterations were sampled for the four averages above */
-    double bytes_per_iter;    /* algorithmic HBM bytes per CG iteration of the decomposition launched (11NT) */
+    double ms_update_p_avg;   /* p = -z + b p (z = r without preconditioner)  3NT */
+    double ms_precond_avg;    /* z = M^-1 r: five DCT sweeps (0 without preconditioner)   10NT(+1NT for r.z) */
+    int32_t kernel_samples;   /* how many iterations were sampled for the averages above */
+    int32_t preconditioner;   /* SHM_PRECOND_NONE or SHM_PRECOND_DCT: what actually ran */
+    double bytes_per_iter;    /* algorithmic HBM bytes per CG iteration of the decomposition launched */
 } shm_stats;
 
 /* --- life cycle -------------------------------------------------------------------------------- */
@@ -141,6 +149,9 @@ shm_status shm_grid_apply_laplacian(shm_solver* s, const double* u, double* out)
 shm_status shm_grid_get_constraints(shm_solver* s, int64_t* nodes, double* coeffs, int32_t* m);
 /* v <- v - A^T (A A^T)^-1 A v on the device (the projector inside the CG); v: n^3 doubles, world==1. */
 shm_status shm_grid_apply_projector(shm_solver* s, double* v);
+
+/* out = M^-1 v with the DCT preconditioner alone (no projection); v,out: n^3 doubles on the host (world==1). */
+shm_status shm_grid_apply_preconditioner(shm_solver* s, const double* v, double* out);
 
 /* --- multi-GPU bootstrap ------------------------------------------------------------------------ */
 /* Fill 128 bytes with a fresh ncclUniqueId (rank 0 calls this, the launcher broadcasts the bytes). */

@@ -28,6 +28,7 @@
 
 #include "../../include/shm_grid.h"
 #include "shm_kernels.hip.h"
+#include "shm_dct.hip.h"
 
 namespace shm {
 
@@ -159,6 +160,7 @@ struct SolverBase {
     virtual void apply_laplacian(const double*, double*) = 0;
     virtual void get_constraints(int64_t*, double*, int32_t*) = 0;
     virtual void apply_projector(double*) = 0;
+    virtual void apply_preconditioner(const double*, double*) = 0;
 };
 
 template <typename T> constexpr int vec_width() { return sizeof(T) == 8 ? 2 : 4; }
@@ -167,7 +169,7 @@ template <typename T>
 struct Slab {
     int k0 = 0, k1 = 0, nzl = 0;  // owned global planes [k0,k1)
     size_t plane = 0, nown = 0, ntot = 0;
-    DevArray<T> Y0, Y1, Y2, r /* also divYt */, x, p, q /* also phi */;
+    DevArray<T> Y0, Y1, Y2, r /* also divYt */, x, p, q /* also phi */, z /* preconditioned residual (DCT path only) */;
     DevArray<double> partials, red /* [1+m] */, pq /* [1] */, u /* [m] */, sc;
     // constraint pieces restricted to owned nodes
     DevArray<int> row_ptr, ent_row, node_ptr;
@@ -199,6 +201,13 @@ struct Solver final : SolverBase {
     DevArray<double> Ginv, gjP, gjR, gjC;
     DevArray<int> gjFlag;
     DevArray<double*> d_redptrs;
+    // DCT preconditioner (single slab, n = 2^k)
+    using TP = T;  // precision of the preconditioner sweeps
+    DevArray<TP> W;
+    DevArray<Cplx<TP>> d_tw, d_om;
+    DevArray<TP> d_lam;
+    int log2n = 0;
+    bool precond_ready = false;
     double* h_pinned = nullptr;
     Rccl::comm_t comm = nullptr;
     int vec = 1;  // vector width usable for this n
@@ -311,7 +320,7 @@ struct Solver final : SolverBase {
             // ghosts of p are read only where a neighbour exists, but zero everything once for hygiene
             HIPCHK(hipMemsetAsync(sl.p.p, 0, sl.ntot * sizeof(T), stream));
             HIPCHK(hipMemsetAsync(sl.Y2.p, 0, sl.ntot * sizeof(T), stream));
-            sl.partials.alloc(kMaxPartials);
+            sl.partials.alloc(std::max<size_t>(kMaxPartials, (size_t)n * n / kDctLines + 8));
             sl.pq.alloc(1);
             sl.sc.alloc(SC_COUNT);
             HIPCHK(hipMemsetAsync(sl.sc.p, 0, SC_COUNT * sizeof(double), stream));
@@ -322,6 +331,7 @@ struct Solver final : SolverBase {
             sl.gp.inv_h2 = 1. / (cell * cell);
         }
         HIPCHK(hipStreamSynchronize(stream));
+        precond_ready = false;
         have_problem = true;
         have_conv = have_div = have_phi = have_constraints = false;
         log("[shm] problem set: n=%d N=%zu S=%lld slabs=%d(local %d) vec=%d", n, N, (long long)S, total_slabs, cfg.local_slabs, vec);
@@ -623,9 +633,16 @@ struct Solver final : SolverBase {
         hipLaunchKernelGGL((update_xr_kernel<T, VEC>), dim3(grid), dim3(kBlock), 0, stream, sl.nown / VEC, sl.plane, sl.sc.p, rho_slot, sl.pq.p,
                            sl.x.p, sl.p.p, sl.r.p, sl.q.p, sl.partials.p);
     }
-    template <int VEC> void launch_update_p(Slab<T>& sl, int rho_old, int rho_new, int init, int grid) {
+    template <int VEC> void launch_update_p(Slab<T>& sl, int rho_old, int rho_new, int init, int use_uw, const T* zsrc, int grid) {
         hipLaunchKernelGGL((update_p_kernel<T, VEC>), dim3(grid), dim3(kBlock), 0, stream, sl.nown / VEC, sl.plane, sl.sc.p, rho_old, rho_new,
-                           sl.red.p, init, sl.r.p, sl.p.p, 1);
+                           sl.red.p, init, use_uw, zsrc, sl.p.p);
+    }
+    void update_p_all(int rho_old, int rho_new, int init, bool pre, const std::vector<int>& nparts) {
+        for (size_t s = 0; s < slabs.size(); s++) {
+            const T* zsrc = pre ? slabs[s].z.p : slabs[s].r.p;
+            if (vec == 1) launch_update_p<1>(slabs[s], rho_old, rho_new, init, pre ? 0 : 1, zsrc, nparts[s]);
+            else launch_update_p<vec_width<T>()>(slabs[s], rho_old, rho_new, init, pre ? 0 : 1, zsrc, nparts[s]);
+        }
     }
     template <int VEC> void launch_norm2(Slab<T>& sl, const T* v, int grid) {
         hipLaunchKernelGGL((norm2_kernel<T, VEC>), dim3(grid), dim3(kBlock), 0, stream, sl.nown / VEC, sl.plane, v, sl.partials.p);
@@ -633,20 +650,85 @@ struct Solver final : SolverBase {
 
     int stream_grid(const Slab<T>& sl) const { return grid_for(sl.nown / vec, 2048); }
 
-    // r <- P r on all slabs; leaves red[0] = sum of the first nparts[s] `partials` and sc[SC_UW] = u.w
-    void launch_projection(const std::vector<int>& nparts) {
+    // v <- P v on all slabs (v = r, or z when on_z); leaves red[0] = sum of the first nparts[s] `partials`,
+    // sc[SC_UW] = u.w and optionally sc[SC_RR] (= red[0] - u.w = ||P v||^2 when the partials were those of ||v||^2).
+    void launch_projection(const std::vector<int>& nparts, bool on_z = false, int save_rr = 0) {
         for (size_t s = 0; s < slabs.size(); s++) {
             Slab<T>& sl = slabs[s];
             hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(1 + (m + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, m, sl.row_ptr.p, sl.ent_node.p,
-                               sl.ent_coef.p, sl.r.p, sl.partials.p, nparts[s], sl.red.p);
+                               sl.ent_coef.p, on_z ? sl.z.p : sl.r.p, sl.partials.p, nparts[s], sl.red.p);
         }
         allreduce(0, 1 + m);
         for (Slab<T>& sl : slabs) {
             if (m > 0)
                 hipLaunchKernelGGL(ginv_matvec_kernel, dim3((m + 3) / 4), dim3(kBlock), 0, stream, m, mp, Ginv.p, sl.red.p + 1, sl.u.p);
             hipLaunchKernelGGL((scatter_nodes_kernel<T>), dim3(1 + (sl.n_touched + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sl.n_touched,
-                               sl.node_id.p, sl.node_ptr.p, sl.ent_row.p, sl.nent_coef.p, sl.u.p, sl.red.p + 1, m, sl.sc.p, sl.r.p);
+                               sl.node_id.p, sl.node_ptr.p, sl.ent_row.p, sl.nent_coef.p, sl.u.p, sl.red.p + 1, m, sl.sc.p, save_rr,
+                               on_z ? sl.z.p : sl.r.p);
         }
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // DCT preconditioner
+    bool precond_available() const { return total_slabs == 1 && n >= 16 && n <= 1024 && (n & (n - 1)) == 0; }
+    size_t dct_lds_bytes() const { return (size_t)n * (kDctLines / 2) * sizeof(Cplx<TP>) + (size_t)(n / 2) * sizeof(Cplx<TP>) + 64; }
+
+    void setup_precond() {
+        if (precond_ready) return;
+        log2n = 0;
+        while ((1 << log2n) < n) log2n++;
+        std::vector<Cplx<TP>> tw(n / 2), om(n);
+        std::vector<TP> lam(n);
+        const double pi = 3.14159265358979323846;
+        for (int k = 0; k < n / 2; k++) tw[k] = {(TP)std::cos(-2. * pi * k / n), (TP)std::sin(-2. * pi * k / n)};
+        for (int k = 0; k < n; k++) {
+            om[k] = {(TP)std::cos(-pi * k / (2. * n)), (TP)std::sin(-pi * k / (2. * n))};
+            lam[k] = (TP)((2. - 2. * std::cos(pi * k / n)) / (cell * cell));
+        }
+        d_tw.upload(tw, stream);
+        d_om.upload(om, stream);
+        d_lam.upload(lam, stream);
+        W.alloc(N);
+        slabs[0].z.alloc(slabs[0].ntot);
+        HIPCHK(hipMemsetAsync(slabs[0].z.p, 0, slabs[0].ntot * sizeof(T), stream));
+        HIPCHK(hipStreamSynchronize(stream));  // host vectors go out of scope
+        precond_ready = true;
+    }
+
+    template <int MODE, typename TIn, typename TOut, bool DOT>
+    void launch_dct(const DctParams& P, int ntiles, const TIn* in, TOut* out, const TOut* dotw, double* partials) {
+        auto kern = dct_lines_kernel<TP, TIn, TOut, MODE, DOT>;
+        static size_t configured = 0;  // per instantiation
+        const size_t lds = dct_lds_bytes();
+        if (configured < lds) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            configured = lds;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(kBlock), lds, stream, P, in, out, d_tw.p, d_om.p, d_lam.p, dotw, partials);
+    }
+
+    // z' = M^-1 r (no projection).  Returns the number of partial sums of r.z' written (0 when !dot).
+    int launch_precond(Slab<T>& sl, bool dot) {
+        const long long nn = n, plane = (long long)n * n;
+        const int tiles = (int)(plane / kDctLines);
+        DctParams X{};  // lines along x: 16 consecutive rows per tile
+        X.n = n; X.log2n = log2n; X.l_fastest = 0; X.elem_stride = 1; X.line_stride = nn;
+        X.tiles_a = tiles; X.a_stride = (long long)kDctLines * nn; X.b_stride = 0;
+        X.inv_n3_8 = 8.0 / ((double)n * n * n);
+        DctParams Y = X;  // lines along y: tile = 16 consecutive x at one z
+        Y.l_fastest = 1; Y.elem_stride = nn; Y.line_stride = 1; Y.tiles_a = n / kDctLines; Y.a_stride = kDctLines; Y.b_stride = plane;
+        DctParams Z = Y;  // lines along z: tile = 16 consecutive x at one y
+        Z.elem_stride = plane; Z.b_stride = nn;
+        DctParams Xf = X, Xi = X;
+        Xf.in_off = (long long)sl.plane; Xf.out_off = 0;
+        Xi.in_off = 0; Xi.out_off = (long long)sl.plane;
+        launch_dct<DCT_FWD, T, TP, false>(Xf, tiles, sl.r.p, W.p, (const TP*)nullptr, nullptr);
+        launch_dct<DCT_FWD, TP, TP, false>(Y, tiles, W.p, W.p, (const TP*)nullptr, nullptr);
+        launch_dct<DCT_FUSED, TP, TP, false>(Z, tiles, W.p, W.p, (const TP*)nullptr, nullptr);
+        launch_dct<DCT_INV, TP, TP, false>(Y, tiles, W.p, W.p, (const TP*)nullptr, nullptr);
+        if (dot) launch_dct<DCT_INV, TP, T, true>(Xi, tiles, W.p, sl.z.p, sl.r.p, sl.partials.p);
+        else launch_dct<DCT_INV, TP, T, false>(Xi, tiles, W.p, sl.z.p, (const T*)nullptr, nullptr);
+        return dot ? tiles : 0;
     }
 
     // ------------------------------------------------------------------------------------------
@@ -655,9 +737,18 @@ struct Solver final : SolverBase {
         HIPCHK(hipSetDevice(cfg.device));
         shm_opts o = o_in;
         if (o.fast_integration) throw Error(SHM_ERR_INVALID, "fast_integration (BFS, signed_heat_grid_solver.cpp:224-275) is not implemented on the device yet");
+        bool pre = false;
+        if (o.preconditioner == SHM_PRECOND_DCT) {
+            if (!precond_available()) throw Error(SHM_ERR_INVALID, "DCT preconditioner needs n = 2^k in [16,1024] and a single z-slab");
+            pre = true;
+        } else if (o.preconditioner == SHM_PRECOND_AUTO) {
+            pre = precond_available();
+        } else if (o.preconditioner != SHM_PRECOND_NONE) {
+            throw Error(SHM_ERR_INVALID, "unknown preconditioner");
+        }
         if (!(o.tol > 0.)) o.tol = sizeof(T) == 8 ? 1e-8 : 1e-5;
         if (o.max_iters <= 0) o.max_iters = 20 * n;
-        if (o.check_every <= 0) o.check_every = 32;
+        if (o.check_every <= 0) o.check_every = pre ? 8 : 32;
 
         Event e_start, e_conv, e_div, e_setup, e_pcg, e_end;
         const auto wall0 = std::chrono::steady_clock::now();
@@ -667,10 +758,12 @@ struct Solver final : SolverBase {
         launch_div(o.scrub_nonfinite);
         e_div.record(stream);
         build_constraints();  // host work overlaps the conv kernel; G^-1 on the device
+        if (pre) setup_precond();
         e_setup.record(stream);
 
-        // ---- projected CG: x=0; r=P b; p=-r; loop { q=Kp; a=rho/p.q; x+=a p; r=P(r+a q); p=-r+b p }
-        std::vector<int> nparts(slabs.size());
+        // ---- projected (preconditioned) CG, SURVEY 7.3:
+        //      x=0; r=P b; z=P M^-1 r; p=-z; loop { q=Kp; a=rho/p.q; x+=a p; r=P(r+a q); z=P M^-1 r; rho'=r.z; p=-z+(rho'/rho) p }
+        std::vector<int> nparts(slabs.size()), zparts(slabs.size(), 0);
         for (size_t s = 0; s < slabs.size(); s++) {
             Slab<T>& sl = slabs[s];
             HIPCHK(hipMemsetAsync(sl.x.p, 0, sl.ntot * sizeof(T), stream));
@@ -678,28 +771,30 @@ struct Solver final : SolverBase {
             if (vec == 1) launch_norm2<1>(sl, sl.r.p, nparts[s]);
             else launch_norm2<vec_width<T>()>(sl, sl.r.p, nparts[s]);
         }
-        launch_projection(nparts);
-        for (size_t s = 0; s < slabs.size(); s++) {
-            if (vec == 1) launch_update_p<1>(slabs[s], SC_RHO_A, SC_RHO_A, 1, nparts[s]);
-            else launch_update_p<vec_width<T>()>(slabs[s], SC_RHO_A, SC_RHO_A, 1, nparts[s]);
+        launch_projection(nparts, false, 2);
+        if (pre) {
+            zparts[0] = launch_precond(slabs[0], true);
+            launch_projection(zparts, true, 0);
         }
+        update_p_all(SC_RHO_A, SC_RHO_A, 1, pre, nparts);
         HIPCHK(hipGetLastError());
 
-        // sampled per-kernel timing (events on the solver's stream; 6 events per sampled iteration)
-        const int kMaxSamples = 48, kEvPer = 6;
+        // sampled per-kernel timing (events on the solver's stream; 8 events per sampled iteration)
+        const int kMaxSamples = 32, kEvPer = 8;
         std::vector<std::unique_ptr<Event>> ev;
         if (st) for (int a = 0; a < kEvPer * kMaxSamples; a++) ev.emplace_back(new Event());
         int nsamples = 0;
+        const int sample_stride = pre ? 2 : 8;
 
         int it = 0;
-        double rho0 = 0., rho = 0.;
+        double rr0 = 0., rr = 0.;
         bool converged = false, breakdown = false;
         while (it < o.max_iters && !converged && !breakdown) {
             const int batch_end = std::min(o.max_iters, it + o.check_every);
             for (; it < batch_end; it++) {
                 const int slot_old = (it & 1) ? SC_RHO_B : SC_RHO_A, slot_new = (it & 1) ? SC_RHO_A : SC_RHO_B;
                 halo_exchange_p();
-                const bool sample = st && nsamples < kMaxSamples && (it % 8 == 3);
+                const bool sample = st && nsamples < kMaxSamples && (it % sample_stride == 1);
                 auto mark = [&](int k) {
                     if (sample) ev[kEvPer * nsamples + k]->record(stream);
                 };
@@ -717,23 +812,25 @@ struct Solver final : SolverBase {
                     else launch_update_xr<vec_width<T>()>(slabs[s], slot_old, nparts[s]);
                 }
                 mark(3);
-                launch_projection(nparts);
+                launch_projection(nparts, false, 1);
                 mark(4);
-                for (size_t s = 0; s < slabs.size(); s++) {
-                    if (vec == 1) launch_update_p<1>(slabs[s], slot_old, slot_new, 0, nparts[s]);
-                    else launch_update_p<vec_width<T>()>(slabs[s], slot_old, slot_new, 0, nparts[s]);
-                }
+                if (pre) zparts[0] = launch_precond(slabs[0], true);
                 mark(5);
+                if (pre) launch_projection(zparts, true, 0);
+                mark(6);
+                update_p_all(slot_old, slot_new, 0, pre, nparts);
+                mark(7);
                 if (sample) nsamples++;
             }
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(h_pinned, slabs[0].sc.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
-            rho0 = h_pinned[SC_RHO0];
-            rho = h_pinned[(it & 1) ? SC_RHO_B : SC_RHO_A];
-            if (!std::isfinite(rho) || !std::isfinite(rho0)) breakdown = true;
-            else if (rho <= o.tol * o.tol * rho0) converged = true;  // rho = rr - u.w may round slightly below 0 at convergence
-            log("[shm] it=%d rel_res=%.3e", it, std::sqrt(std::fabs(rho / rho0)));
+            rr0 = h_pinned[SC_RR0];
+            rr = h_pinned[SC_RR];
+            const double rho = h_pinned[(it & 1) ? SC_RHO_B : SC_RHO_A];
+            if (!std::isfinite(rr) || !std::isfinite(rr0) || !std::isfinite(rho)) breakdown = true;
+            else if (rr <= o.tol * o.tol * rr0) converged = true;  // rr = ||r'||^2 - u.w may round slightly below 0 at convergence
+            log("[shm] it=%d rel_res=%.3e", it, std::sqrt(std::fabs(rr / rr0)));
         }
         e_pcg.record(stream);
 
@@ -760,7 +857,7 @@ struct Solver final : SolverBase {
             st->m = m;
             st->S = S;
             st->iters = it;
-            st->rel_residual = std::sqrt(std::fabs(rho / rho0));
+            st->rel_residual = std::sqrt(std::fabs(rr / rr0));
             st->shift = h_pinned[SC_SHIFT];
             st->ms_conv = elapsed(e_start, e_conv);
             st->ms_div = elapsed(e_conv, e_div);
@@ -768,24 +865,29 @@ struct Solver final : SolverBase {
             st->ms_pcg = elapsed(e_setup, e_pcg);
             st->ms_shift = elapsed(e_pcg, e_end);
             st->ms_total = std::chrono::duration<double, std::milli>(wall1 - wall0).count();
-            double acc[4] = {0, 0, 0, 0};
+            double acc[5] = {0, 0, 0, 0, 0};
             for (int a = 0; a < nsamples; a++) {
-                acc[0] += elapsed(*ev[kEvPer * a + 0], *ev[kEvPer * a + 1]);
-                acc[1] += elapsed(*ev[kEvPer * a + 2], *ev[kEvPer * a + 3]);
-                acc[2] += elapsed(*ev[kEvPer * a + 3], *ev[kEvPer * a + 4]);
-                acc[3] += elapsed(*ev[kEvPer * a + 4], *ev[kEvPer * a + 5]);
+                auto el = [&](int i, int j) { return (double)elapsed(*ev[kEvPer * a + i], *ev[kEvPer * a + j]); };
+                acc[0] += el(0, 1);
+                acc[1] += el(2, 3);
+                acc[2] += el(3, 4) + el(5, 6);
+                acc[3] += el(6, 7);
+                acc[4] += el(4, 5);
             }
             const double inv = nsamples ? 1. / nsamples : 0.;
             st->ms_stencil_avg = acc[0] * inv;
             st->ms_update_xr_avg = acc[1] * inv;
             st->ms_project_avg = acc[2] * inv;
             st->ms_update_p_avg = acc[3] * inv;
+            st->ms_precond_avg = pre ? acc[4] * inv : 0.;
             st->kernel_samples = nsamples;
-            st->bytes_per_iter = 11.0 * (double)N * sizeof(T);
+            st->preconditioner = pre ? SHM_PRECOND_DCT : SHM_PRECOND_NONE;
+            // 11NT for the CG sweeps; the five DCT sweeps move 3T + 8TP more (read r twice + write z, 4 in-place sweeps of W)
+            st->bytes_per_iter = 11.0 * (double)N * sizeof(T) + (pre ? (double)N * (3.0 * sizeof(T) + 8.0 * sizeof(TP)) : 0.);
         }
-        if (breakdown) throw Error(SHM_ERR_BREAKDOWN, fmt("projected CG broke down at iteration %d (rho=%g, rho0=%g)", it, rho, rho0));
+        if (breakdown) throw Error(SHM_ERR_BREAKDOWN, fmt("projected CG broke down at iteration %d (rr=%g, rr0=%g)", it, rr, rr0));
         if (!converged) throw Error(SHM_ERR_NOCONV, fmt("projected CG: max_iters=%d reached, rel. residual %.3e > tol %.1e", o.max_iters,
-                                                          std::sqrt(std::fabs(rho / rho0)), o.tol));
+                                                          std::sqrt(std::fabs(rr / rr0)), o.tol));
     }
 
     // ------------------------------------------------------------------------------------------
@@ -881,6 +983,19 @@ struct Solver final : SolverBase {
         have_div = true;
         copy_owned_to_host(SHM_FIELD_DIV, v);
         have_div = false;
+    }
+
+    void apply_preconditioner(const double* v, double* out) override {
+        need_problem();
+        if (!precond_available()) throw Error(SHM_ERR_INVALID, "DCT preconditioner needs n = 2^k in [16,1024] and a single z-slab");
+        HIPCHK(hipSetDevice(cfg.device));
+        setup_precond();
+        upload_owned(v, 1);
+        launch_precond(slabs[0], false);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(slabs[0].q.p, slabs[0].z.p, slabs[0].ntot * sizeof(T), hipMemcpyDeviceToDevice, stream));
+        copy_owned_to_host(SHM_FIELD_PHI, out);
+        have_conv = have_div = have_phi = false;
     }
 };
 
@@ -1024,6 +1139,13 @@ shm_status shm_grid_apply_projector(shm_solver* s, double* v) {
     return guard(s, [&] {
         if (!v) throw shm::Error(SHM_ERR_INVALID, "null argument");
         s->impl->apply_projector(v);
+    });
+}
+
+shm_status shm_grid_apply_preconditioner(shm_solver* s, const double* v, double* out) {
+    return guard(s, [&] {
+        if (!v || !out) throw shm::Error(SHM_ERR_INVALID, "null argument");
+        s->impl->apply_preconditioner(v, out);
     });
 }
 

@@ -297,6 +297,8 @@ enum Scalar : int {
     SC_UW = 3,     // u.w of the current projection
     SC_SHIFT = 4,  // area-weighted mean of phi along the sources
     SC_AREA = 5,   // sum of source areas
+    SC_RR = 6,     // ||P r||^2 of the current residual (convergence test)
+    SC_RR0 = 7,    // ||P b||^2
     SC_COUNT = 8
 };
 // red[] layout (the all-reduced vector): red[0] = scalar partial sum, red[1..m] = w = A r'
@@ -356,27 +358,28 @@ __global__ __launch_bounds__(kBlock) void norm2_kernel(size_t nvec, size_t off, 
     if (threadIdx.x == 0) partials[blockIdx.x] = acc;
 }
 
-// p = -r + beta p  with  rho_new = red[0] - u.w  (||r' - A^T u||^2 = ||r'||^2 - u.w because A A^T u = w),
-// beta = rho_new / rho_old.  init!=0: p = -r, rho0 = rho_new.  Block 0 publishes rho_new.   3NT bytes.
+// p = -z + beta p,  beta = rho_new / rho_old.  Plain projected CG: z = r and rho_new = red[0] - u.w
+// (||r' - A^T u||^2 = ||r'||^2 - u.w because A A^T u = w).  Preconditioned: z = P M^-1 r and rho_new = red[0] = r.z'
+// (z' = M^-1 r before its projection; r.A^T u = 0 because A r = 0).  init!=0: p = -z.  Block 0 publishes rho_new.  3NT bytes.
 template <typename T, int VEC>
 __global__ __launch_bounds__(kBlock) void update_p_kernel(size_t nvec, size_t off, double* __restrict__ sc, int rho_old_slot, int rho_new_slot,
-                                                          const double* __restrict__ red0, int init, const T* __restrict__ r, T* __restrict__ p,
-                                                          int publish) {
-    const double rho_new = *red0 - sc[SC_UW];
+                                                          const double* __restrict__ red0, int init, int use_uw, const T* __restrict__ z,
+                                                          T* __restrict__ p) {
+    const double rho_new = *red0 - (use_uw ? sc[SC_UW] : 0.);
     const double beta_d = init ? 0. : rho_new / sc[rho_old_slot];
     const T beta = (T)beta_d;
     for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += (size_t)gridDim.x * kBlock) {
         const size_t c = off + v * VEC;
-        T rv[VEC], pv[VEC];
-        load_vec<T, VEC>(r + c, rv);
+        T zv[VEC], pv[VEC];
+        load_vec<T, VEC>(z + c, zv);
         if (!init) load_vec<T, VEC>(p + c, pv);
 #pragma unroll
-        for (int e = 0; e < VEC; e++) pv[e] = init ? -rv[e] : (-rv[e] + beta * pv[e]);
+        for (int e = 0; e < VEC; e++) pv[e] = init ? -zv[e] : (-zv[e] + beta * pv[e]);
         store_vec<T, VEC>(p + c, pv);
     }
     // every block has read sc[rho_old_slot] before any block of the NEXT kernel runs; the new value goes
     // to the other slot, so there is no intra-kernel race.
-    if (publish && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         sc[rho_new_slot] = rho_new;
         if (init) sc[SC_RHO0] = rho_new;
     }
@@ -425,13 +428,18 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void scatter_nodes_kernel(int nnodes, const uint32_t* __restrict__ node_id, const int* __restrict__ node_ptr,
                                                                const int* __restrict__ ent_row, const double* __restrict__ ent_coef,
                                                                const double* __restrict__ u, const double* __restrict__ w, int m,
-                                                               double* __restrict__ sc, T* __restrict__ v) {
+                                                               double* __restrict__ sc, int save_rr /*0 no, 1 SC_RR, 2 SC_RR and SC_RR0*/,
+                                                               T* __restrict__ v) {
     __shared__ double lds[8];
     if (blockIdx.x == 0) {
         double s = 0.;
         for (int a = threadIdx.x; a < m; a += kBlock) s += u[a] * w[a];
         s = block_sum(s, lds);
-        if (threadIdx.x == 0) sc[SC_UW] = s;
+        if (threadIdx.x == 0) {
+            sc[SC_UW] = s;
+            if (save_rr) sc[SC_RR] = w[-1] - s;  // w = red+1: red[0] holds ||v||^2 before the projection
+            if (save_rr == 2) sc[SC_RR0] = w[-1] - s;
+        }
         return;
     }
     const int t = (blockIdx.x - 1) * kBlock + threadIdx.x;

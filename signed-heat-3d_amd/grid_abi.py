@@ -19,7 +19,7 @@ STATUS_NAMES = {0: "SHM_OK", 1: "SHM_ERR_INVALID", 2: "SHM_ERR_HIP", 3: "SHM_ERR
 # every symbol include/shm_grid.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = ["shm_grid_create", "shm_grid_destroy", "shm_grid_last_error", "shm_grid_abi_version", "shm_grid_set_problem",
                "shm_grid_solve", "shm_grid_get_phi", "shm_grid_compute_distance", "shm_grid_run_conv", "shm_grid_run_divergence",
-               "shm_grid_get_field", "shm_grid_apply_laplacian", "shm_grid_get_constraints", "shm_grid_apply_projector",
+               "shm_grid_get_field", "shm_grid_apply_laplacian", "shm_grid_get_constraints", "shm_grid_apply_projector", "shm_grid_apply_preconditioner",
                "shm_comm_unique_id", "shm_plan_slab"]
 
 
@@ -44,7 +44,7 @@ class _Grid(C.Structure):
 
 class _Opts(C.Structure):
     _fields_ = [("fast_integration", C.c_int32), ("scrub_nonfinite", C.c_int32), ("tol", C.c_double), ("max_iters", C.c_int32),
-                ("check_every", C.c_int32)]
+                ("check_every", C.c_int32), ("preconditioner", C.c_int32)]
 
 
 class ShmStats(C.Structure):
@@ -52,7 +52,8 @@ class ShmStats(C.Structure):
                 ("shift", C.c_double), ("ms_conv", C.c_double), ("ms_div", C.c_double), ("ms_setup", C.c_double),
                 ("ms_pcg", C.c_double), ("ms_shift", C.c_double), ("ms_total", C.c_double), ("ms_stencil_avg", C.c_double),
                 ("ms_update_xr_avg", C.c_double), ("ms_project_avg", C.c_double), ("ms_update_p_avg", C.c_double),
-                ("kernel_samples", C.c_int32), ("bytes_per_iter", C.c_double)]
+                ("ms_precond_avg", C.c_double), ("kernel_samples", C.c_int32), ("preconditioner", C.c_int32),
+                ("bytes_per_iter", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -90,6 +91,7 @@ def load_library():
     lib.shm_grid_apply_laplacian.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.shm_grid_get_constraints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
     lib.shm_grid_apply_projector.argtypes = [C.c_void_p, C.c_void_p]
+    lib.shm_grid_apply_preconditioner.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.shm_comm_unique_id.argtypes = [C.c_void_p]
     lib.shm_plan_slab.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.shm_plan_slab.restype = None
@@ -166,8 +168,10 @@ class GridSolver:
         total = self.world * self.local_slabs
         return plan_slab(self.n, total, first)[0], plan_slab(self.n, total, first + self.local_slabs - 1)[1]
 
-    def solve(self, tol=0.0, max_iters=0, check_every=0, scrub=True, fast=False, allow_noconv=False):
-        o = _Opts(int(fast), int(scrub), float(tol), int(max_iters), int(check_every))
+    PRECOND = {"auto": 0, "none": 1, "dct": 2}
+
+    def solve(self, tol=0.0, max_iters=0, check_every=0, scrub=True, fast=False, allow_noconv=False, precond="auto"):
+        o = _Opts(int(fast), int(scrub), float(tol), int(max_iters), int(check_every), self.PRECOND[precond])
         st = ShmStats()
         self._chk(self._lib.shm_grid_solve(self._h, C.byref(o), C.byref(st)), allow=(5,) if allow_noconv else ())
         return st
@@ -210,6 +214,12 @@ class GridSolver:
         v = _f64(v).reshape(-1).copy()
         self._chk(self._lib.shm_grid_apply_projector(self._h, v.ctypes.data))
         return v
+
+    def apply_preconditioner(self, v):
+        v = _f64(v).reshape(-1)
+        out = np.empty_like(v)
+        self._chk(self._lib.shm_grid_apply_preconditioner(self._h, v.ctypes.data, out.ctypes.data))
+        return out
 
     def compute_distance(self, pos, wnormal, area, lam, n, bbox_min, cell, **kw):
         """One-shot convenience mirroring shm_grid_compute_distance (set_problem + solve + get_phi)."""

@@ -54,6 +54,7 @@ def oracle_c():
     lib.shmo_set_threads.argtypes = [ci]
     lib.shmo_set_threads.restype = None
     lib.shmo_max_threads.restype = ci
+    lib.shmo_set_threads(min(8, os.cpu_count() or 1))  # tiny problems: hundreds of OpenMP threads would only spin
     return lib
 
 

@@ -85,12 +85,40 @@ def test_projector(shm, case):
     assert np.abs(s.apply_projector(Atw)).max() < 1e-10 * np.abs(Atw).max()
 
 
+@pytest.mark.parametrize("n", [16, 32, 64, 128])
+def test_preconditioner_is_the_dct_pseudo_inverse(shm, n):
+    """M^-1 = C^T D C must equal the pseudo-inverse of K = -L (the 3-D DCT-II diagonalises the Neumann Laplacian):
+    compared with scipy's orthonormal DCT on the host, and checked through K M^-1 v = v - mean(v)."""
+    from scipy.fft import dctn, idctn
+    d = load_golden("bunny_small_n16")
+    h = float(d["cell"]) * 15 / (n - 1)
+    s = shm.GridSolver()
+    s.set_problem(d["pos"], d["wnormal"], d["area"], float(d["lam"]), n, d["bbox_min"], h)
+    rng = np.random.default_rng(n)
+    v = rng.standard_normal(n ** 3)
+    got = s.apply_preconditioner(v)
+    lam1 = (2 - 2 * np.cos(np.pi * np.arange(n) / n)) / h ** 2
+    LAM = lam1[:, None, None] + lam1[None, :, None] + lam1[None, None, :]
+    inv = np.where(LAM > 0, 1 / np.where(LAM > 0, LAM, 1), 0.0)
+    ref = idctn(dctn(v.reshape(n, n, n), type=2, norm="ortho") * inv, type=2, norm="ortho").reshape(-1)
+    assert np.abs(got - ref).max() < 1e-11 * np.abs(ref).max()
+    Lg = s.apply_laplacian(got)      # L M^-1 v = -(v - mean v)
+    assert np.abs(-Lg - (v - v.mean())).max() < 1e-9 * np.abs(v).max()
+
+
+@pytest.mark.parametrize("precond", ["none", "dct"])
 @pytest.mark.parametrize("case,scrub", [("bunny_small_n16", True), ("bunny_small_n24", True), ("bunny_small_n32", True),
                                         ("polygon_bear_n16", True), ("bunny_pc_n16", False), ("bunny_pc_n32", False)])
-def test_phi_matches_lu_golden(shm, case, scrub):
+def test_phi_matches_lu_golden(shm, case, scrub, precond):
     d = load_golden(case)
+    if precond == "dct" and int(d["n"]) & (int(d["n"]) - 1):
+        s = make_solver(shm, d)
+        with pytest.raises(shm.ShmError):          # n = 24 is not a power of two: explicit request must fail loudly
+            s.solve(tol=1e-10, scrub=scrub, precond="dct")
+        return
     s = make_solver(shm, d)
-    st = s.solve(tol=1e-10, scrub=scrub)
+    st = s.solve(tol=1e-10, scrub=scrub, precond=precond)
+    assert st.preconditioner == (2 if precond == "dct" else 1)
     phi, (k0, k1) = s.get_phi()
     assert (k0, k1) == (0, int(d["n"]))
     err = np.abs(phi - d["phi"]).max()
@@ -107,7 +135,20 @@ def test_phi_default_tolerance_inside_gate(shm):
     assert np.abs(phi - d["phi"]).max() < PHI_GATE
 
 
-def test_phi_64_config_c1(shm):
+def test_preconditioner_cuts_iterations(shm):
+    d = load_golden("bunny_small_n32")
+    s = make_solver(shm, d)
+    plain = s.solve(tol=1e-8, precond="none")
+    phi0, _ = s.get_phi()
+    pre = s.solve(tol=1e-8, precond="dct")
+    phi1, _ = s.get_phi()
+    assert pre.iters * 4 < plain.iters, (pre.iters, plain.iters)
+    assert np.abs(phi0 - phi1).max() < 1e-6
+    assert np.abs(phi1 - d["phi"]).max() < PHI_GATE
+
+
+@pytest.mark.parametrize("precond", ["none", "dct"])
+def test_phi_64_config_c1(shm, precond):
     """BASELINE.json configs[0]: bunny_small.obj at 64^3 against the committed LU solution."""
     import os
     from conftest import GOLDEN
@@ -115,7 +156,7 @@ def test_phi_64_config_c1(shm):
         pytest.skip("64^3 LU fixture not generated")
     d = load_golden("bunny_small_n64")
     s = make_solver(shm, d)
-    st = s.solve(tol=1e-9)
+    st = s.solve(tol=1e-9, precond=precond)
     phi, _ = s.get_phi()
     assert np.abs(phi - d["phi"]).max() < 1e-6, st.iters
 
