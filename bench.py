@@ -178,7 +178,7 @@ def main():
         avg = {k: float(np.mean([s[k] for s in stats])) for k in stats[0]}
         # per-kernel algorithmic bytes of the decomposition launched; per rank = per launch
         n_local = N / world
-        pre = int(avg["preconditioner"]) == 2
+        has_pre = int(avg["preconditioner"]) == 2
         TP = T  # the preconditioner sweeps run in the solve precision
         # name: (algorithmic bytes per launch, avg ms per launch, launches per CG iteration)
         kernels = {
@@ -186,7 +186,7 @@ def main():
             "update_xr_kernel": (6 * n_local * T, avg["ms_update_xr_avg"], 1),
             "update_p_kernel": (3 * n_local * T, avg["ms_update_p_avg"], 1),
         }
-        if pre:  # five DCT sweeps (x-fwd, y-fwd, z-fused, y-inv, x-inv+dot): 3T + 8TP bytes per node in total
+        if has_pre:  # five DCT sweeps (x-fwd, y-fwd, z-fused, y-inv, x-inv+dot): 3T + 8TP bytes per node in total
             kernels["dct_lines_kernel"] = (n_local * (3 * T + 8 * TP) / 5.0, avg["ms_precond_avg"] / 5.0, 5)
         kinfo = {k: {"algorithmic_bytes_per_launch": b, "avg_ms_per_launch": ms, "launches_per_iter": cnt,
                      "achieved_GBps": (b / (ms * 1e-3) / 1e9 if ms > 0 else None)}
@@ -208,7 +208,7 @@ def main():
             "config": {"workload": args.workload, "grid": "%d^3" % n, "sources": int(pre["S"]), "constraint_rows": int(avg["m"]),
                        "tol": args.tol if args.tol > 0 else (1e-8 if precision == 64 else 1e-5), "cg_iters": int(avg["iters"]),
                        "rel_residual": avg["rel_residual"], "partition": "z-slabs x%d" % world,
-                       "preconditioner": "dct (exact fast Poisson, sandwiched P M^-1 P)" if pre else "none"},
+                       "preconditioner": "dct (exact fast Poisson, sandwiched P M^-1 P)" if has_pre else "none"},
             "phases_ms": {k: avg[k] for k in ("ms_conv", "ms_div", "ms_setup", "ms_pcg", "ms_shift", "ms_total")},
             "pcg": {"ms_per_iter": avg["ms_pcg"] / max(1.0, avg["iters"]), "algorithmic_bytes_per_iter": avg["bytes_per_iter"] / world,
                     "achieved_GBps": avg["bytes_per_iter"] / world / (avg["ms_pcg"] / max(1.0, avg["iters"]) * 1e-3) / 1e9,
