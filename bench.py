@@ -209,7 +209,7 @@ def main():
                        "tol": args.tol if args.tol > 0 else (1e-8 if precision == 64 else 1e-5), "cg_iters": int(avg["iters"]),
                        "rel_residual": avg["rel_residual"], "partition": "z-slabs x%d" % world,
                        "preconditioner": "dct (exact fast Poisson, sandwiched P M^-1 P)" if has_pre else "none"},
-            "phases_ms": {k: avg[k] for k in ("ms_conv", "ms_div", "ms_setup", "ms_pcg", "ms_shift", "ms_total")},
+            "phases_ms": {k: avg[k] for k in ("ms_conv", "ms_div", "ms_setup", "ms_wait_setup", "ms_pcg", "ms_shift", "ms_total")},
             "pcg": {"ms_per_iter": avg["ms_pcg"] / max(1.0, avg["iters"]), "algorithmic_bytes_per_iter": avg["bytes_per_iter"] / world,
                     "achieved_GBps": avg["bytes_per_iter"] / world / (avg["ms_pcg"] / max(1.0, avg["iters"]) * 1e-3) / 1e9,
                     "frac_of_hbm_peak": avg["bytes_per_iter"] / world / (avg["ms_pcg"] / max(1.0, avg["iters"]) * 1e-3) / 1e9 / HBM_PEAK_GBS,

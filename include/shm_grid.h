@@ -78,7 +78,7 @@ typedef struct {
     int32_t scrub_nonfinite;  /* 1 = mesh overload's divYt scrub (:72-74); 0 = point overload (:180) */
     double tol;               /* stop when ||P r|| <= tol * ||P b||;  <=0 -> default 1e-8 (fp64) / 1e-5 (fp32) */
     int32_t max_iters;        /* <=0 -> default 20*n */
-    int32_t check_every;      /* residual is inspected on the host every this many iterations; <=0 -> 32 (8 with the preconditioner) */
+    int32_t check_every;      /* residual is inspected on the host every this many iterations; <=0 -> 32 (4 with the preconditioner) */
     int32_t preconditioner;   /* SHM_PRECOND_AUTO | _NONE | _DCT */
 } shm_opts;
 
@@ -96,7 +96,8 @@ typedef struct {
     /* device-side timings (hipEvent, ms) */
     double ms_conv;           /* Steps 1+2 */
     double ms_div;            /* D^T Y (+ scrub) */
-    double ms_setup;          /* constraint rows, A A^T, Cholesky + triangular inverse */
+    double ms_setup;          /* constraint rows, A A^T and its blocked Gauss-Jordan inverse; on a 2nd stream, overlapping ms_conv */
+    double ms_wait_setup;     /* time the main stream actually waited for the set-up after the divergence */
     double ms_pcg;            /* projected CG loop */
     double ms_shift;          /* shift + phi write-out */
     double ms_total;          /* whole shm_grid_solve */

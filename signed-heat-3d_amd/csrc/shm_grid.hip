@@ -183,7 +183,8 @@ struct Slab {
 template <typename T>
 struct Solver final : SolverBase {
     shm_config cfg;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // conv, divergence, CG
+    hipStream_t stream2 = nullptr;  // constraint set-up ((A A^T)^-1), overlapped with the Step-1 kernel
     int n = 0;
     size_t N = 0;
     double cell = 0., lambda = 0.;
@@ -221,6 +222,7 @@ struct Solver final : SolverBase {
         if (cfg.device < 0 || cfg.device >= ndev) throw Error(SHM_ERR_INVALID, fmt("device %d out of range [0,%d)", cfg.device, ndev));
         HIPCHK(hipSetDevice(cfg.device));
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
         HIPCHK(hipHostMalloc((void**)&h_pinned, 64 * sizeof(double)));
         if (cfg.world > 1) {
             if (!cfg.rccl_unique_id) throw Error(SHM_ERR_INVALID, "world>1 needs rccl_unique_id");
@@ -236,6 +238,7 @@ struct Solver final : SolverBase {
         if (h_pinned) (void)hipHostFree(h_pinned);
         slabs.clear();
         if (stream) (void)hipStreamDestroy(stream);
+        if (stream2) (void)hipStreamDestroy(stream2);
     }
 
     void log(const char* f, ...) {
@@ -432,6 +435,7 @@ struct Solver final : SolverBase {
 
     // Per-slab CSR pieces, shift items, and G = A A^T (sparse triplets -> dense on device -> inverted).
     void build_constraints() {
+        hipStream_t stream = stream2;  // everything below runs beside the Step-1 kernel of the main stream
         build_rows();
         const size_t plane = (size_t)n * n;
         for (Slab<T>& sl : slabs) {
@@ -544,6 +548,7 @@ struct Solver final : SolverBase {
     }
 
     void invert_G() {
+        hipStream_t stream = stream2;
         const int nb = mp / kGJ;
         gjP.alloc(kGJ * kGJ);
         gjR.alloc((size_t)kGJ * mp);
@@ -748,16 +753,18 @@ struct Solver final : SolverBase {
         }
         if (!(o.tol > 0.)) o.tol = sizeof(T) == 8 ? 1e-8 : 1e-5;
         if (o.max_iters <= 0) o.max_iters = 20 * n;
-        if (o.check_every <= 0) o.check_every = pre ? 8 : 32;
+        if (o.check_every <= 0) o.check_every = pre ? 4 : 32;
 
-        Event e_start, e_conv, e_div, e_setup, e_pcg, e_end;
+        Event e_start, e_conv, e_div, e_setup, e_pcg, e_end, e_s2a, e_s2b;
         const auto wall0 = std::chrono::steady_clock::now();
         e_start.record(stream);
         launch_conv();
         e_conv.record(stream);
         launch_div(o.scrub_nonfinite);
         e_div.record(stream);
-        build_constraints();  // host work overlaps the conv kernel; G^-1 on the device
+        e_s2a.record(stream2);
+        build_constraints();  // on stream2: overlaps the Step-1 kernel; returns once (A A^T)^-1 is ready
+        e_s2b.record(stream2);
         if (pre) setup_precond();
         e_setup.record(stream);
 
@@ -861,7 +868,9 @@ struct Solver final : SolverBase {
             st->shift = h_pinned[SC_SHIFT];
             st->ms_conv = elapsed(e_start, e_conv);
             st->ms_div = elapsed(e_conv, e_div);
-            st->ms_setup = elapsed(e_div, e_setup);
+            HIPCHK(hipEventSynchronize(e_s2b.e));
+            st->ms_setup = elapsed(e_s2a, e_s2b);  // runs on stream2 concurrently with ms_conv
+            st->ms_wait_setup = elapsed(e_div, e_setup);
             st->ms_pcg = elapsed(e_setup, e_pcg);
             st->ms_shift = elapsed(e_pcg, e_end);
             st->ms_total = std::chrono::duration<double, std::milli>(wall1 - wall0).count();

@@ -57,9 +57,52 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
 // =================================================================================================
 constexpr int kSrcTile = 512;
 
-template <typename T> __device__ __forceinline__ T t_exp(T x);
-template <> __device__ __forceinline__ double t_exp<double>(double x) { return exp(x); }
-template <> __device__ __forceinline__ float t_exp<float>(float x) { return __expf(x); }
+// exp(-lambda r)/r evaluated without a division and without the library sqrt: y = rsqrt(r^2) (hardware seed +
+// two Goldschmidt steps), r = r^2 y, 1/r = y.  fp64 exp: range reduction by ln2 (two-term Cody-Waite) + degree-13
+// Taylor polynomial on |f| <= ln2/2 (truncation 4e-18) + ldexp; the argument is always <= 0 and > -745.
+template <typename T> struct YukawaMath;
+template <> struct YukawaMath<double> {
+    static __device__ __forceinline__ void rsqrt_and_sqrt(double x, double& rinv, double& r) {
+        const double y0 = __builtin_amdgcn_rsq(x);
+        double g = x * y0, h = 0.5 * y0;
+        double e = fma(-g, h, 0.5);
+        g = fma(g, e, g);
+        h = fma(h, e, h);
+        e = fma(-g, h, 0.5);
+        g = fma(g, e, g);
+        h = fma(h, e, h);
+        r = g;
+        rinv = h + h;
+    }
+    static __device__ __forceinline__ double exp_neg(double x) {
+        const double kf = rint(x * 1.4426950408889634074);
+        double f = fma(kf, -6.93147180369123816490e-01, x);
+        f = fma(kf, -1.90821492927058770002e-10, f);
+        double p = 1.6059043836821613e-10;                 // 1/13!
+        p = fma(p, f, 2.08767569878681e-09);               // 1/12!
+        p = fma(p, f, 2.505210838544172e-08);              // 1/11!
+        p = fma(p, f, 2.755731922398589e-07);              // 1/10!
+        p = fma(p, f, 2.7557319223985893e-06);             // 1/9!
+        p = fma(p, f, 2.48015873015873e-05);               // 1/8!
+        p = fma(p, f, 1.984126984126984e-04);              // 1/7!
+        p = fma(p, f, 1.3888888888888889e-03);             // 1/6!
+        p = fma(p, f, 8.333333333333333e-03);              // 1/5!
+        p = fma(p, f, 4.1666666666666664e-02);             // 1/4!
+        p = fma(p, f, 1.6666666666666666e-01);             // 1/3!
+        p = fma(p, f, 0.5);
+        p = fma(p, f, 1.0);
+        p = fma(p, f, 1.0);
+        return __builtin_amdgcn_ldexp(p, (int)kf);
+    }
+};
+template <> struct YukawaMath<float> {
+    static __device__ __forceinline__ void rsqrt_and_sqrt(float x, float& rinv, float& r) {
+        const float y0 = __builtin_amdgcn_rsqf(x);  // 1 ulp
+        r = x * y0;
+        rinv = y0;
+    }
+    static __device__ __forceinline__ float exp_neg(float x) { return __expf(x); }
+};
 template <typename T> __device__ __forceinline__ T t_sqrt(T x);
 template <> __device__ __forceinline__ double t_sqrt<double>(double x) { return sqrt(x); }
 template <> __device__ __forceinline__ float t_sqrt<float>(float x) { return sqrtf(x); }
@@ -123,8 +166,9 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
 #pragma unroll
             for (int e = 0; e < NPT; e++) {
                 const T dx = px[e] - sx, dy = py[e] - sy, dz = pz[e] - sz;
-                const T r = t_sqrt<T>(dx * dx + dy * dy + dz * dz);
-                const T g = t_exp<T>(-lam * (r - d0[e])) / r;
+                T r, rinv;
+                YukawaMath<T>::rsqrt_and_sqrt(dx * dx + dy * dy + dz * dz, rinv, r);
+                const T g = YukawaMath<T>::exp_neg(-lam * (r - d0[e])) * rinv;   // r = 0 -> inf*0 = NaN like exp(0)/0 -> inf -> NaN after normalise
                 ax[e] += wx * g; ay[e] += wy * g; az[e] += wz * g;
             }
         }

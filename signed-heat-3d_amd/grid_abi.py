@@ -49,7 +49,7 @@ class _Opts(C.Structure):
 
 class ShmStats(C.Structure):
     _fields_ = [("n", C.c_int32), ("m", C.c_int32), ("S", C.c_int64), ("iters", C.c_int32), ("rel_residual", C.c_double),
-                ("shift", C.c_double), ("ms_conv", C.c_double), ("ms_div", C.c_double), ("ms_setup", C.c_double),
+                ("shift", C.c_double), ("ms_conv", C.c_double), ("ms_div", C.c_double), ("ms_setup", C.c_double), ("ms_wait_setup", C.c_double),
                 ("ms_pcg", C.c_double), ("ms_shift", C.c_double), ("ms_total", C.c_double), ("ms_stencil_avg", C.c_double),
                 ("ms_update_xr_avg", C.c_double), ("ms_project_avg", C.c_double), ("ms_update_p_avg", C.c_double),
                 ("ms_precond_avg", C.c_double), ("kernel_samples", C.c_int32), ("preconditioner", C.c_int32),
