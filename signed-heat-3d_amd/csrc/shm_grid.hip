@@ -676,17 +676,15 @@ struct Solver final : SolverBase {
     // ------------------------------------------------------------------------------------------
     // DCT preconditioner
     bool precond_available() const { return total_slabs == 1 && n >= 16 && n <= 1024 && (n & (n - 1)) == 0; }
-    size_t dct_lds_bytes() const { return (size_t)n * (kDctLines / 2) * sizeof(Cplx<TP>) + (size_t)(n / 2) * sizeof(Cplx<TP>) + 64; }
-
     void setup_precond() {
         if (precond_ready) return;
         log2n = 0;
         while ((1 << log2n) < n) log2n++;
-        std::vector<Cplx<TP>> tw(n / 2), om(n);
+        std::vector<Cplx<TP>> tw(n), om(n);
         std::vector<TP> lam(n);
         const double pi = 3.14159265358979323846;
-        for (int k = 0; k < n / 2; k++) tw[k] = {(TP)std::cos(-2. * pi * k / n), (TP)std::sin(-2. * pi * k / n)};
         for (int k = 0; k < n; k++) {
+            tw[k] = {(TP)std::cos(-2. * pi * k / n), (TP)std::sin(-2. * pi * k / n)};
             om[k] = {(TP)std::cos(-pi * k / (2. * n)), (TP)std::sin(-pi * k / (2. * n))};
             lam[k] = (TP)((2. - 2. * std::cos(pi * k / n)) / (cell * cell));
         }
@@ -700,16 +698,29 @@ struct Solver final : SolverBase {
         precond_ready = true;
     }
 
-    template <int MODE, typename TIn, typename TOut, bool DOT>
-    void launch_dct(const DctParams& P, int ntiles, const TIn* in, TOut* out, const TOut* dotw, double* partials) {
-        auto kern = dct_lines_kernel<TP, TIn, TOut, MODE, DOT>;
-        static size_t configured = 0;  // per instantiation
-        const size_t lds = dct_lds_bytes();
-        if (configured < lds) {
+    template <int MODE, typename TIn, typename TOut, bool DOT, int LOG2N, bool XPASS>
+    void launch_dct_n(const DctParams& P, int ntiles, const TIn* in, TOut* out, const TOut* dotw, double* partials) {
+        auto kern = dct_lines_kernel<TP, TIn, TOut, MODE, DOT, LOG2N, XPASS>;
+        static bool configured = false;  // per instantiation
+        constexpr size_t lds = dct_lds_bytes<LOG2N>(sizeof(Cplx<TP>));
+        if (!configured) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            configured = lds;
+            configured = true;
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(kBlock), lds, stream, P, in, out, d_tw.p, d_om.p, d_lam.p, dotw, partials);
+    }
+    template <int MODE, typename TIn, typename TOut, bool DOT, bool XPASS>
+    void launch_dct(const DctParams& P, int ntiles, const TIn* in, TOut* out, const TOut* dotw, double* partials) {
+        switch (log2n) {
+            case 4: launch_dct_n<MODE, TIn, TOut, DOT, 4, XPASS>(P, ntiles, in, out, dotw, partials); break;
+            case 5: launch_dct_n<MODE, TIn, TOut, DOT, 5, XPASS>(P, ntiles, in, out, dotw, partials); break;
+            case 6: launch_dct_n<MODE, TIn, TOut, DOT, 6, XPASS>(P, ntiles, in, out, dotw, partials); break;
+            case 7: launch_dct_n<MODE, TIn, TOut, DOT, 7, XPASS>(P, ntiles, in, out, dotw, partials); break;
+            case 8: launch_dct_n<MODE, TIn, TOut, DOT, 8, XPASS>(P, ntiles, in, out, dotw, partials); break;
+            case 9: launch_dct_n<MODE, TIn, TOut, DOT, 9, XPASS>(P, ntiles, in, out, dotw, partials); break;
+            case 10: launch_dct_n<MODE, TIn, TOut, DOT, 10, XPASS>(P, ntiles, in, out, dotw, partials); break;
+            default: throw Error(SHM_ERR_INVALID, "DCT preconditioner: unsupported grid size");
+        }
     }
 
     // z' = M^-1 r (no projection).  Returns the number of partial sums of r.z' written (0 when !dot).
@@ -717,22 +728,22 @@ struct Solver final : SolverBase {
         const long long nn = n, plane = (long long)n * n;
         const int tiles = (int)(plane / kDctLines);
         DctParams X{};  // lines along x: 16 consecutive rows per tile
-        X.n = n; X.log2n = log2n; X.l_fastest = 0; X.elem_stride = 1; X.line_stride = nn;
+        X.elem_stride = 1; X.line_stride = nn;
         X.tiles_a = tiles; X.a_stride = (long long)kDctLines * nn; X.b_stride = 0;
         X.inv_n3_8 = 8.0 / ((double)n * n * n);
         DctParams Y = X;  // lines along y: tile = 16 consecutive x at one z
-        Y.l_fastest = 1; Y.elem_stride = nn; Y.line_stride = 1; Y.tiles_a = n / kDctLines; Y.a_stride = kDctLines; Y.b_stride = plane;
+        Y.elem_stride = nn; Y.line_stride = 1; Y.tiles_a = n / kDctLines; Y.a_stride = kDctLines; Y.b_stride = plane;
         DctParams Z = Y;  // lines along z: tile = 16 consecutive x at one y
         Z.elem_stride = plane; Z.b_stride = nn;
         DctParams Xf = X, Xi = X;
         Xf.in_off = (long long)sl.plane; Xf.out_off = 0;
         Xi.in_off = 0; Xi.out_off = (long long)sl.plane;
-        launch_dct<DCT_FWD, T, TP, false>(Xf, tiles, sl.r.p, W.p, (const TP*)nullptr, nullptr);
-        launch_dct<DCT_FWD, TP, TP, false>(Y, tiles, W.p, W.p, (const TP*)nullptr, nullptr);
-        launch_dct<DCT_FUSED, TP, TP, false>(Z, tiles, W.p, W.p, (const TP*)nullptr, nullptr);
-        launch_dct<DCT_INV, TP, TP, false>(Y, tiles, W.p, W.p, (const TP*)nullptr, nullptr);
-        if (dot) launch_dct<DCT_INV, TP, T, true>(Xi, tiles, W.p, sl.z.p, sl.r.p, sl.partials.p);
-        else launch_dct<DCT_INV, TP, T, false>(Xi, tiles, W.p, sl.z.p, (const T*)nullptr, nullptr);
+        launch_dct<DCT_FWD, T, TP, false, true>(Xf, tiles, sl.r.p, W.p, (const TP*)nullptr, nullptr);
+        launch_dct<DCT_FWD, TP, TP, false, false>(Y, tiles, W.p, W.p, (const TP*)nullptr, nullptr);
+        launch_dct<DCT_FUSED, TP, TP, false, false>(Z, tiles, W.p, W.p, (const TP*)nullptr, nullptr);
+        launch_dct<DCT_INV, TP, TP, false, false>(Y, tiles, W.p, W.p, (const TP*)nullptr, nullptr);
+        if (dot) launch_dct<DCT_INV, TP, T, true, true>(Xi, tiles, W.p, sl.z.p, sl.r.p, sl.partials.p);
+        else launch_dct<DCT_INV, TP, T, false, true>(Xi, tiles, W.p, sl.z.p, (const T*)nullptr, nullptr);
         return dot ? tiles : 0;
     }
 

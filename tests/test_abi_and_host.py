@@ -114,3 +114,13 @@ def test_cli_reports_missing_device_or_runs():
     assert p.returncode == 0 and "--h <hCoef>" in p.stdout
     p = subprocess.run([exe], capture_output=True, text=True)
     assert p.returncode != 0 and "Please specify a mesh file" in p.stderr
+
+
+def test_fft_core_on_host(tmp_path):
+    """The Stockham/DCT building blocks the device kernels use (csrc/shm_fft_core.h) are plain C++: run them on the
+    host against naive O(n^2) transforms for every supported length."""
+    import subprocess
+    exe = str(tmp_path / "test_fft_core")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "native", "test_fft_core.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout
