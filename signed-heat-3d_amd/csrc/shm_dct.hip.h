@@ -36,8 +36,11 @@ struct DctParams {
     double inv_n3_8;          // 8/n^3 (product of the three 2/n normalisations; the k=0 halvings are applied per axis)
 };
 
+// Twiddles live in LDS up to n = 256; from n = 512 on they are read from global memory (L1/L2 resident, 8-16 KB) so that
+// two fp64 tiles (73.8 KB each at n = 512) fit in one CU's 160 KB and the load/FFT/store phases of two blocks overlap.
+template <int LOG2N> constexpr bool dct_tw_in_lds() { return LOG2N <= 8; }
 template <int LOG2N> constexpr size_t dct_lds_bytes(size_t cplx_size) {
-    return ((size_t)(1 << LOG2N) * kFftRow + (size_t)(1 << LOG2N)) * cplx_size + 64;
+    return ((size_t)(1 << LOG2N) * kFftRow + (dct_tw_in_lds<LOG2N>() ? (size_t)(1 << LOG2N) : 0)) * cplx_size + 64;
 }
 
 // One Stockham pass over the tile: every thread holds its work items in registers across the barrier.
@@ -79,12 +82,14 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
     constexpr int EPT = (total + kBlock - 1) / kBlock;  // elements per thread (n/16; 1 at n = 16)
     constexpr int CH = EPT < 16 ? EPT : 16;              // register chunk of the global <-> LDS copies
     Cplx<TP>* buf = reinterpret_cast<Cplx<TP>*>(smem);   // [n][kFftRow]
-    Cplx<TP>* tw = buf + (size_t)n * kFftRow;             // [n]
-    double* red = reinterpret_cast<double*>(tw + n);      // [8] block-reduction scratch (all LDS in the dynamic region)
+    Cplx<TP>* tw_l = buf + (size_t)n * kFftRow;           // [n] (only when dct_tw_in_lds)
+    double* red = reinterpret_cast<double*>(tw_l + (dct_tw_in_lds<LOG2N>() ? n : 0));  // [8] block-reduction scratch
+    const Cplx<TP>* tw = dct_tw_in_lds<LOG2N>() ? tw_l : tw_g;
     const int tid = threadIdx.x;
     const int t = blockIdx.x;
     const long long base = (long long)(t % P.tiles_a) * P.a_stride + (long long)(t / P.tiles_a) * P.b_stride;
-    for (int a = tid; a < n; a += kBlock) tw[a] = tw_g[a];
+    if (dct_tw_in_lds<LOG2N>())
+        for (int a = tid; a < n; a += kBlock) tw_l[a] = tw_g[a];
 
     // element index of the a-th element this thread moves: idx = tid + a*256
     //   y/z sweeps: l = idx & 15 (consecutive lanes = consecutive lines = consecutive x), j = idx >> 4

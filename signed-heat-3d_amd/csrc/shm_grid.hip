@@ -222,7 +222,11 @@ struct Solver final : SolverBase {
         if (cfg.device < 0 || cfg.device >= ndev) throw Error(SHM_ERR_INVALID, fmt("device %d out of range [0,%d)", cfg.device, ndev));
         HIPCHK(hipSetDevice(cfg.device));
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+        {   // the set-up stream outranks the main stream so that its short kernels are not starved by the Step-1 kernel
+            int least = 0, greatest = 0;
+            HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIPCHK(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, greatest));
+        }
         HIPCHK(hipHostMalloc((void**)&h_pinned, 64 * sizeof(double)));
         if (cfg.world > 1) {
             if (!cfg.rccl_unique_id) throw Error(SHM_ERR_INVALID, "world>1 needs rccl_unique_id");

@@ -563,35 +563,62 @@ __global__ __launch_bounds__(kBlock) void convert_kernel(size_t count, const TS*
 // =================================================================================================
 constexpr int kGJ = 64;
 
-// step 1: invert the 64x64 pivot block in LDS (Gauss-Jordan, SPD -> no pivoting); 256 threads.
+// step 1: invert the 64x64 pivot block (Gauss-Jordan, SPD -> no pivoting).  256 threads, each owning a 4x4 sub-block
+// in registers; per elimination step only the pivot row and column travel through LDS (double-buffered: one barrier
+// per step).
 __global__ __launch_bounds__(kBlock) void gj_pivot_kernel(double* __restrict__ G, int ld, int kb, double* __restrict__ Pout, int* __restrict__ flag) {
-    __shared__ double a[kGJ][kGJ + 1];
-    __shared__ double colk[kGJ];
-    __shared__ double rowk[kGJ];
+    __shared__ double rowk[2][kGJ], colk[2][kGJ];
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
     const size_t o = (size_t)kb * kGJ;
-    for (int t = threadIdx.x; t < kGJ * kGJ; t += kBlock) a[t / kGJ][t % kGJ] = G[(o + t / kGJ) * ld + o + t % kGJ];
-    __syncthreads();
+    double r[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) r[a][b] = G[(o + ty * 4 + a) * ld + o + tx * 4 + b];
     for (int k = 0; k < kGJ; k++) {
-        const double piv = a[k][k];
+        const int pb = k & 1, kq = k >> 2, kr = k & 3;
+        if (kq == ty) {
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+                if (a == kr) {
+#pragma unroll
+                    for (int b = 0; b < 4; b++) rowk[pb][tx * 4 + b] = r[a][b];
+                }
+        }
+        if (kq == tx) {
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (b == kr) {
+#pragma unroll
+                    for (int a = 0; a < 4; a++) colk[pb][ty * 4 + a] = r[a][b];
+                }
+        }
+        __syncthreads();
+        const double piv = rowk[pb][k];
         if (threadIdx.x == 0 && !(piv > 0.)) *flag = 1;
-        if (threadIdx.x < kGJ) {
-            colk[threadIdx.x] = a[threadIdx.x][k];
-            rowk[threadIdx.x] = a[k][threadIdx.x];
-        }
-        __syncthreads();
         const double ip = 1. / piv;
-        for (int t = threadIdx.x; t < kGJ * kGJ; t += kBlock) {
-            const int i = t / kGJ, j = t % kGJ;
-            double v;
-            if (i == k && j == k) v = ip;
-            else if (i == k) v = rowk[j] * ip;
-            else if (j == k) v = -colk[i] * ip;
-            else v = a[i][j] - colk[i] * rowk[j] * ip;
-            a[i][j] = v;
-        }
-        __syncthreads();
+        double rv[4], cv[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) rv[b] = rowk[pb][tx * 4 + b];
+#pragma unroll
+        for (int a = 0; a < 4; a++) cv[a] = colk[pb][ty * 4 + a];
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const bool ik = (ty * 4 + a) == k, jk = (tx * 4 + b) == k;
+                double v;
+                if (ik && jk) v = ip;
+                else if (ik) v = rv[b] * ip;
+                else if (jk) v = -cv[a] * ip;
+                else v = r[a][b] - cv[a] * rv[b] * ip;
+                r[a][b] = v;
+            }
     }
-    for (int t = threadIdx.x; t < kGJ * kGJ; t += kBlock) Pout[t] = a[t / kGJ][t % kGJ];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) Pout[(ty * 4 + a) * kGJ + tx * 4 + b] = r[a][b];
 }
 
 // step 2: R[:, jb] = P * G[kb, jb] and C[ib, :] = G[ib, kb] for every block index != kb.
