@@ -26,15 +26,28 @@ namespace shm {
 enum DctMode : int { DCT_FWD = 0, DCT_INV = 1, DCT_FUSED = 2 };
 constexpr int kDctLines = 2 * kFftLC;  // real lines per tile
 
-struct DctParams {
-    long long elem_stride;    // distance between consecutive elements of a line
-    long long line_stride;    // distance between consecutive lines of a tile
-    int tiles_a;              // tile t -> base = (t % tiles_a) * a_stride + (t / tiles_a) * b_stride
+// Address of element k of line l of tile t:
+//   off + (t % tiles_a) a_stride + (t / tiles_a) b_stride + l line_stride + (k >> seg_shift) seg_stride + (k & seg_mask) elem_stride
+// The segment term expresses the packed all-to-all layout of the multi-slab y sweeps ([dest slab][z][y_local][x]);
+// plain layouts use seg_shift = 30 (k < 2^30 -> no segment).
+struct DctAddr {
+    long long off;          // ghost-plane offset of the CG vectors
     long long a_stride, b_stride;
-    long long in_off, out_off;  // element offsets added to the in/out pointers (ghost plane of the CG vectors)
-    // FUSED only: spectral coordinates of line l of tile t: kx = (t % tiles_a)*16 + l ; ky = t / tiles_a
-    double inv_n3_8;          // 8/n^3 (product of the three 2/n normalisations; the k=0 halvings are applied per axis)
+    long long line_stride;  // distance between consecutive lines of a tile
+    long long elem_stride;  // distance between consecutive elements of a line (inside a segment)
+    long long seg_stride;
+    int seg_shift, seg_mask;
 };
+struct DctParams {
+    int tiles_a;
+    DctAddr in, out;
+    // FUSED only: spectral coordinates of line l of tile t: kx = (t % tiles_a)*16 + l ; ky = ky0 + t / tiles_a
+    int ky0;
+    double inv_n3_8;        // 8/n^3 (product of the three 2/n normalisations; the k=0 halvings are applied per axis)
+};
+__device__ __forceinline__ long long dct_addr(const DctAddr& A, long long base, int l, int k) {
+    return A.off + base + (long long)l * A.line_stride + (long long)(k >> A.seg_shift) * A.seg_stride + (long long)(k & A.seg_mask) * A.elem_stride;
+}
 
 // Twiddles live in LDS up to n = 256; from n = 512 on they are read from global memory (L1/L2 resident, 8-16 KB) so that
 // two fp64 tiles (73.8 KB each at n = 512) fit in one CU's 160 KB and the load/FFT/store phases of two blocks overlap.
@@ -87,7 +100,8 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
     const Cplx<TP>* tw = dct_tw_in_lds<LOG2N>() ? tw_l : tw_g;
     const int tid = threadIdx.x;
     const int t = blockIdx.x;
-    const long long base = (long long)(t % P.tiles_a) * P.a_stride + (long long)(t / P.tiles_a) * P.b_stride;
+    const long long base_in = (long long)(t % P.tiles_a) * P.in.a_stride + (long long)(t / P.tiles_a) * P.in.b_stride;
+    const long long base_out = (long long)(t % P.tiles_a) * P.out.a_stride + (long long)(t / P.tiles_a) * P.out.b_stride;
     if (dct_tw_in_lds<LOG2N>())
         for (int a = tid; a < n; a += kBlock) tw_l[a] = tw_g[a];
 
@@ -105,7 +119,7 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
         for (int a = 0; a < CH; a++) {
             const int idx = tid + (a0 + a) * kBlock;
             if (total % kBlock == 0 || idx < total)
-                v[a] = (TP)in[P.in_off + base + (long long)line_of(idx) * P.line_stride + (long long)elem_of(idx) * P.elem_stride];
+                v[a] = (TP)in[dct_addr(P.in, base_in, line_of(idx), elem_of(idx))];
         }
 #pragma unroll
         for (int a = 0; a < CH; a++) {
@@ -133,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
                     const int l = line_of(idx), k = elem_of(idx), c = l >> 1;
                     TP xa, xb;
                     dct_fwd_post<TP>(buf[k * kFftRow + c], buf[((n - k) & (n - 1)) * kFftRow + c], om_g[k], xa, xb);
-                    out[P.out_off + base + (long long)l * P.line_stride + (long long)k * P.elem_stride] = (TOut)((l & 1) ? xb : xa);
+                    out[dct_addr(P.out, base_out, l, k)] = (TOut)((l & 1) ? xb : xa);
                 }
             }
         }
@@ -142,7 +156,7 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
 
     // ---------------- spectral step on (k, n-k) pairs, k = 0..n/2 ----------------
     {
-        const int kx0 = (t % P.tiles_a) * L, ky = t / P.tiles_a;
+        const int kx0 = (t % P.tiles_a) * L, ky = P.ky0 + t / P.tiles_a;
         constexpr int pairs = (n / 2 + 1) * kFftLC;
         for (int b = tid; b < pairs; b += kBlock) {
             const int c = b & (kFftLC - 1), k = b >> 3;
@@ -187,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
             for (int a = 0; a < CH; a++) {
                 const int idx = tid + (a0 + a) * kBlock;
                 if (total % kBlock == 0 || idx < total)
-                    dv[a] = dot_with[P.out_off + base + (long long)line_of(idx) * P.line_stride + (long long)elem_of(idx) * P.elem_stride];
+                    dv[a] = dot_with[dct_addr(P.out, base_out, line_of(idx), elem_of(idx))];
             }
         }
 #pragma unroll
@@ -196,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
             if (total % kBlock == 0 || idx < total) {
                 const int l = line_of(idx), j = elem_of(idx);
                 const TP v = reinterpret_cast<const TP*>(&buf[makhoul_slot(j, n) * kFftRow + (l >> 1)])[l & 1];
-                out[P.out_off + base + (long long)l * P.line_stride + (long long)j * P.elem_stride] = (TOut)v;
+                out[dct_addr(P.out, base_out, l, j)] = (TOut)v;
                 if (DOT) acc += (double)v * (double)dv[a];
             }
         }

@@ -176,6 +176,7 @@ struct Slab {
     DevArray<uint32_t> ent_node, node_id;
     DevArray<double> ent_coef, nent_coef;
     DevArray<ShiftItem> shift_items;
+    DevArray<T> W1, W2;  // DCT work arrays (precision TP == T); W2 only with several slabs (packed transposes)
     int n_touched = 0, n_shift = 0;
     GridParams gp{};
 };
@@ -204,7 +205,6 @@ struct Solver final : SolverBase {
     DevArray<double*> d_redptrs;
     // DCT preconditioner (single slab, n = 2^k)
     using TP = T;  // precision of the preconditioner sweeps
-    DevArray<TP> W;
     DevArray<Cplx<TP>> d_tw, d_om;
     DevArray<TP> d_lam;
     int log2n = 0;
@@ -679,7 +679,12 @@ struct Solver final : SolverBase {
 
     // ------------------------------------------------------------------------------------------
     // DCT preconditioner
-    bool precond_available() const { return total_slabs == 1 && n >= 16 && n <= 1024 && (n & (n - 1)) == 0; }
+    // n = 2^k in [16,1024]; with P > 1 slabs: P | n and both the z-slab and the y-pencil hold whole 16-line tiles' worth of rows
+    bool precond_available() const {
+        if (n < 16 || n > 1024 || (n & (n - 1)) != 0) return false;
+        if (total_slabs == 1) return true;
+        return (total_slabs & (total_slabs - 1)) == 0 && n % total_slabs == 0;
+    }
     void setup_precond() {
         if (precond_ready) return;
         log2n = 0;
@@ -695,9 +700,12 @@ struct Solver final : SolverBase {
         d_tw.upload(tw, stream);
         d_om.upload(om, stream);
         d_lam.upload(lam, stream);
-        W.alloc(N);
-        slabs[0].z.alloc(slabs[0].ntot);
-        HIPCHK(hipMemsetAsync(slabs[0].z.p, 0, slabs[0].ntot * sizeof(T), stream));
+        for (Slab<T>& sl : slabs) {
+            sl.W1.alloc(sl.nown);
+            if (total_slabs > 1) sl.W2.alloc(sl.nown);
+            sl.z.alloc(sl.ntot);
+            HIPCHK(hipMemsetAsync(sl.z.p, 0, sl.ntot * sizeof(T), stream));
+        }
         HIPCHK(hipStreamSynchronize(stream));  // host vectors go out of scope
         precond_ready = true;
     }
@@ -727,28 +735,116 @@ struct Solver final : SolverBase {
         }
     }
 
-    // z' = M^-1 r (no projection).  Returns the number of partial sums of r.z' written (0 when !dot).
-    int launch_precond(Slab<T>& sl, bool dot) {
+    static DctAddr plain_addr(long long off, long long a_stride, long long b_stride, long long line_stride, long long elem_stride) {
+        DctAddr A{};
+        A.off = off; A.a_stride = a_stride; A.b_stride = b_stride; A.line_stride = line_stride; A.elem_stride = elem_stride;
+        A.seg_stride = 0; A.seg_shift = 30; A.seg_mask = (1 << 30) - 1;
+        return A;
+    }
+
+    // transport: block q of src[slab g] -> block g of dst[slab q] for all slab pairs (blocks of `blk` elements): the
+    // transposition between z-slabs and y-pencils of the distributed DCT.  Local pairs are device copies; pairs on other
+    // ranks travel as grouped ncclSend/ncclRecv (an all-to-all over xGMI).
+    void alltoall_blocks(bool w1_to_w2, size_t blk) {
+        auto srcp = [&](Slab<T>& sl) { return w1_to_w2 ? sl.W1.p : sl.W2.p; };
+        auto dstp = [&](Slab<T>& sl) { return w1_to_w2 ? sl.W2.p : sl.W1.p; };
+        const int ls = cfg.local_slabs;
+        for (int a = 0; a < ls; a++)
+            for (int b = 0; b < ls; b++)
+                HIPCHK(hipMemcpyAsync(dstp(slabs[b]) + (size_t)(first_slab + a) * blk, srcp(slabs[a]) + (size_t)(first_slab + b) * blk, blk * sizeof(T),
+                                      hipMemcpyDeviceToDevice, stream));
+        if (comm) {
+            Rccl& R = Rccl::get();
+            const int dt = sizeof(T) == 8 ? Rccl::kFloat64 : Rccl::kFloat32;
+            R.chk(R.GroupStart(), "ncclGroupStart");
+            for (int peer = 0; peer < cfg.world; peer++) {
+                if (peer == cfg.rank) continue;
+                // sends ordered (my slab a, peer slab b); the peer posts its receives in that same order
+                for (int a = 0; a < ls; a++)
+                    for (int b = 0; b < ls; b++)
+                        R.chk(R.Send(srcp(slabs[a]) + (size_t)(peer * ls + b) * blk, blk, dt, peer, comm, stream), "ncclSend(a2a)");
+                for (int b = 0; b < ls; b++)      // peer's slab b sent ...
+                    for (int a = 0; a < ls; a++)  // ... its block for my slab a
+                        R.chk(R.Recv(dstp(slabs[a]) + (size_t)(peer * ls + b) * blk, blk, dt, peer, comm, stream), "ncclRecv(a2a)");
+            }
+            R.chk(R.GroupEnd(), "ncclGroupEnd");
+        }
+    }
+
+    // z' = M^-1 r on every slab (no projection).  dot: also leave the partial sums of r.z' in sl.partials; returns
+    // their count per slab.  One slab: x-fwd, y-fwd, z-fused, y-inv, x-inv in place on W1.  P slabs: the y sweeps write /
+    // read the packed layout [dest slab][z_local][y_local][x] and two all-to-alls turn z-slabs into y-pencils and back.
+    int launch_precond(bool dot) {
         const long long nn = n, plane = (long long)n * n;
-        const int tiles = (int)(plane / kDctLines);
-        DctParams X{};  // lines along x: 16 consecutive rows per tile
-        X.elem_stride = 1; X.line_stride = nn;
-        X.tiles_a = tiles; X.a_stride = (long long)kDctLines * nn; X.b_stride = 0;
-        X.inv_n3_8 = 8.0 / ((double)n * n * n);
-        DctParams Y = X;  // lines along y: tile = 16 consecutive x at one z
-        Y.elem_stride = nn; Y.line_stride = 1; Y.tiles_a = n / kDctLines; Y.a_stride = kDctLines; Y.b_stride = plane;
-        DctParams Z = Y;  // lines along z: tile = 16 consecutive x at one y
-        Z.elem_stride = plane; Z.b_stride = nn;
-        DctParams Xf = X, Xi = X;
-        Xf.in_off = (long long)sl.plane; Xf.out_off = 0;
-        Xi.in_off = 0; Xi.out_off = (long long)sl.plane;
-        launch_dct<DCT_FWD, T, TP, false, true>(Xf, tiles, sl.r.p, W.p, (const TP*)nullptr, nullptr);
-        launch_dct<DCT_FWD, TP, TP, false, false>(Y, tiles, W.p, W.p, (const TP*)nullptr, nullptr);
-        launch_dct<DCT_FUSED, TP, TP, false, false>(Z, tiles, W.p, W.p, (const TP*)nullptr, nullptr);
-        launch_dct<DCT_INV, TP, TP, false, false>(Y, tiles, W.p, W.p, (const TP*)nullptr, nullptr);
-        if (dot) launch_dct<DCT_INV, TP, T, true, true>(Xi, tiles, W.p, sl.z.p, sl.r.p, sl.partials.p);
-        else launch_dct<DCT_INV, TP, T, false, true>(Xi, tiles, W.p, sl.z.p, (const T*)nullptr, nullptr);
-        return dot ? tiles : 0;
+        const int P = total_slabs;
+        const int nzl = n / P, nyl = n / P;  // planes per slab == pencil rows per slab (P | n)
+        const double inv8 = 8.0 / ((double)n * n * n);
+        const int tiles_slab = (int)((long long)nzl * nn / kDctLines);  // 16-line tiles of one slab for the x and y sweeps
+        int log2nyl = 0;
+        while ((1 << log2nyl) < nyl) log2nyl++;
+        const long long blk = (long long)nzl * nyl * nn;
+        for (int pass = 0; pass < 7; pass++) {
+            if (P == 1 && (pass == 2 || pass == 4)) continue;
+            if (pass == 2) { alltoall_blocks(false, (size_t)blk); continue; }  // packed W2 (z-slabs) -> W1 (y-pencils [z][y_l][x])
+            if (pass == 4) { alltoall_blocks(true, (size_t)blk); continue; }   // W1 (y-pencils) -> packed W2 (z-slabs)
+            for (size_t si = 0; si < slabs.size(); si++) {
+                Slab<T>& sl = slabs[si];
+                const int g = first_slab + (int)si;
+                DctParams Q{};
+                Q.inv_n3_8 = inv8;
+                Q.ky0 = 0;
+                switch (pass) {
+                    case 0:  // x-fwd: r (ghost layout) -> W1 natural [z_l][y][x]; tile = 16 consecutive rows
+                        Q.tiles_a = tiles_slab;
+                        Q.in = plain_addr((long long)sl.plane, (long long)kDctLines * nn, 0, nn, 1);
+                        Q.out = plain_addr(0, (long long)kDctLines * nn, 0, nn, 1);
+                        launch_dct<DCT_FWD, T, TP, false, true>(Q, tiles_slab, sl.r.p, sl.W1.p, (const TP*)nullptr, nullptr);
+                        break;
+                    case 1:  // y-fwd: W1 natural -> (P==1: W1 in place) | (P>1: W2 packed [q][z_l][y_l][x])
+                        Q.tiles_a = n / kDctLines;
+                        Q.in = plain_addr(0, kDctLines, plane, 1, nn);
+                        if (P == 1) {
+                            Q.out = Q.in;
+                            launch_dct<DCT_FWD, TP, TP, false, false>(Q, tiles_slab, sl.W1.p, sl.W1.p, (const TP*)nullptr, nullptr);
+                        } else {
+                            Q.out = plain_addr(0, kDctLines, (long long)nyl * nn, 1, nn);
+                            Q.out.seg_shift = log2nyl; Q.out.seg_mask = nyl - 1; Q.out.seg_stride = blk;
+                            launch_dct<DCT_FWD, TP, TP, false, false>(Q, tiles_slab, sl.W1.p, sl.W2.p, (const TP*)nullptr, nullptr);
+                        }
+                        break;
+                    case 3: {  // z-fused on the y-pencil [z (n)][y_l][x] of W1; tile = 16 consecutive x at one y_l
+                        Q.tiles_a = n / kDctLines;
+                        Q.in = plain_addr(0, kDctLines, nn, 1, (long long)nyl * nn);
+                        Q.out = Q.in;
+                        Q.ky0 = g * nyl;
+                        const int tiles_z = (n / kDctLines) * nyl;
+                        launch_dct<DCT_FUSED, TP, TP, false, false>(Q, tiles_z, sl.W1.p, sl.W1.p, (const TP*)nullptr, nullptr);
+                        break;
+                    }
+                    case 5:  // y-inv: (P==1: W1 in place) | (P>1: W2 packed -> W1 natural)
+                        Q.tiles_a = n / kDctLines;
+                        Q.out = plain_addr(0, kDctLines, plane, 1, nn);
+                        if (P == 1) {
+                            Q.in = Q.out;
+                            launch_dct<DCT_INV, TP, TP, false, false>(Q, tiles_slab, sl.W1.p, sl.W1.p, (const TP*)nullptr, nullptr);
+                        } else {
+                            Q.in = plain_addr(0, kDctLines, (long long)nyl * nn, 1, nn);
+                            Q.in.seg_shift = log2nyl; Q.in.seg_mask = nyl - 1; Q.in.seg_stride = blk;
+                            launch_dct<DCT_INV, TP, TP, false, false>(Q, tiles_slab, sl.W2.p, sl.W1.p, (const TP*)nullptr, nullptr);
+                        }
+                        break;
+                    case 6:  // x-inv: W1 natural -> z (ghost layout) (+ partial r.z')
+                        Q.tiles_a = tiles_slab;
+                        Q.in = plain_addr(0, (long long)kDctLines * nn, 0, nn, 1);
+                        Q.out = plain_addr((long long)sl.plane, (long long)kDctLines * nn, 0, nn, 1);
+                        if (dot) launch_dct<DCT_INV, TP, T, true, true>(Q, tiles_slab, sl.W1.p, sl.z.p, sl.r.p, sl.partials.p);
+                        else launch_dct<DCT_INV, TP, T, false, true>(Q, tiles_slab, sl.W1.p, sl.z.p, (const T*)nullptr, nullptr);
+                        break;
+                    default: break;
+                }
+            }
+        }
+        return dot ? tiles_slab : 0;
     }
 
     // ------------------------------------------------------------------------------------------
@@ -759,7 +855,7 @@ struct Solver final : SolverBase {
         if (o.fast_integration) throw Error(SHM_ERR_INVALID, "fast_integration (BFS, signed_heat_grid_solver.cpp:224-275) is not implemented on the device yet");
         bool pre = false;
         if (o.preconditioner == SHM_PRECOND_DCT) {
-            if (!precond_available()) throw Error(SHM_ERR_INVALID, "DCT preconditioner needs n = 2^k in [16,1024] and a single z-slab");
+            if (!precond_available()) throw Error(SHM_ERR_INVALID, "DCT preconditioner needs n = 2^k in [16,1024] and a power-of-two number of z-slabs dividing n");
             pre = true;
         } else if (o.preconditioner == SHM_PRECOND_AUTO) {
             pre = precond_available();
@@ -795,7 +891,8 @@ struct Solver final : SolverBase {
         }
         launch_projection(nparts, false, 2);
         if (pre) {
-            zparts[0] = launch_precond(slabs[0], true);
+            const int np = launch_precond(true);
+            for (auto& v : zparts) v = np;
             launch_projection(zparts, true, 0);
         }
         update_p_all(SC_RHO_A, SC_RHO_A, 1, pre, nparts);
@@ -836,7 +933,7 @@ struct Solver final : SolverBase {
                 mark(3);
                 launch_projection(nparts, false, 1);
                 mark(4);
-                if (pre) zparts[0] = launch_precond(slabs[0], true);
+                if (pre) launch_precond(true);
                 mark(5);
                 if (pre) launch_projection(zparts, true, 0);
                 mark(6);
@@ -1011,13 +1108,14 @@ struct Solver final : SolverBase {
 
     void apply_preconditioner(const double* v, double* out) override {
         need_problem();
-        if (!precond_available()) throw Error(SHM_ERR_INVALID, "DCT preconditioner needs n = 2^k in [16,1024] and a single z-slab");
+        if (cfg.world != 1) throw Error(SHM_ERR_INVALID, "apply_preconditioner is a single-process test entry point");
+        if (!precond_available()) throw Error(SHM_ERR_INVALID, "DCT preconditioner needs n = 2^k in [16,1024] and a power-of-two number of z-slabs dividing n");
         HIPCHK(hipSetDevice(cfg.device));
         setup_precond();
         upload_owned(v, 1);
-        launch_precond(slabs[0], false);
+        launch_precond(false);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(slabs[0].q.p, slabs[0].z.p, slabs[0].ntot * sizeof(T), hipMemcpyDeviceToDevice, stream));
+        for (Slab<T>& sl : slabs) HIPCHK(hipMemcpyAsync(sl.q.p, sl.z.p, sl.ntot * sizeof(T), hipMemcpyDeviceToDevice, stream));
         copy_owned_to_host(SHM_FIELD_PHI, out);
         have_conv = have_div = have_phi = false;
     }

@@ -161,6 +161,35 @@ def test_phi_64_config_c1(shm, precond):
     assert np.abs(phi - d["phi"]).max() < 1e-6, st.iters
 
 
+@pytest.mark.parametrize("slabs,n", [(2, 32), (4, 32), (8, 64), (2, 16)])
+def test_distributed_preconditioner_matches_single_slab(shm, slabs, n):
+    """Multi-slab DCT (packed y sweeps + two all-to-all transposes, loop-back transport) == single-slab DCT."""
+    d = load_golden("bunny_small_n16")
+    h = float(d["cell"]) * 15 / (n - 1)
+    rng = np.random.default_rng(7)
+    v = rng.standard_normal(n ** 3)
+    s1 = shm.GridSolver()
+    s1.set_problem(d["pos"], d["wnormal"], d["area"], float(d["lam"]), n, d["bbox_min"], h)
+    ref = s1.apply_preconditioner(v)
+    s = shm.GridSolver(local_slabs=slabs)
+    s.set_problem(d["pos"], d["wnormal"], d["area"], float(d["lam"]), n, d["bbox_min"], h)
+    got = s.apply_preconditioner(v)
+    assert np.abs(got - ref).max() < 1e-12 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("slabs", [2, 4])
+def test_local_slabs_with_preconditioner(shm, slabs):
+    d = load_golden("bunny_small_n32")
+    s = make_solver(shm, d, local_slabs=slabs)
+    st = s.solve(tol=1e-10, precond="dct")
+    assert st.preconditioner == 2
+    phi, _ = s.get_phi()
+    assert np.abs(phi - d["phi"]).max() < 1e-7
+    s1 = make_solver(shm, d)
+    st1 = s1.solve(tol=1e-10, precond="dct")
+    assert abs(st.iters - st1.iters) <= 4
+
+
 @pytest.mark.parametrize("slabs", [2, 3, 5])
 def test_local_slabs_match_single_slab(shm, slabs):
     """The z-slab code path (ghost planes, halo copies, per-slab partial sums, straddling constraint rows)
@@ -170,7 +199,7 @@ def test_local_slabs_match_single_slab(shm, slabs):
     s1.solve(tol=1e-10)
     ref, _ = s1.get_phi()
     s = make_solver(shm, d, local_slabs=slabs)
-    s.solve(tol=1e-10)
+    s.solve(tol=1e-10, precond="none")
     phi, (k0, k1) = s.get_phi()
     assert (k0, k1) == (0, 32)
     assert np.abs(phi - ref).max() < 1e-9
