@@ -234,3 +234,40 @@ def test_errors_are_reported(shm):
         s.set_problem(d["pos"], d["wnormal"], d["area"], float(d["lam"]), 16, d["bbox_min"] + 100.0, float(d["cell"]))  # sources outside
     with pytest.raises(shm.ShmError):
         s.set_problem(d["pos"], d["wnormal"], d["area"], -1.0, 16, d["bbox_min"], float(d["cell"]))
+
+
+# ---- fp32 path (BASELINE.json configs[2], configs[4]): "report only" in the north star; here: sanity bounds -----------
+@pytest.mark.parametrize("case", ["bunny_small_n16", "bunny_small_n32", "bunny_pc_n32"])
+@pytest.mark.parametrize("precond", ["none", "dct"])
+def test_fp32_path_tracks_fp64_oracle(shm, case, precond):
+    """fp32 storage/arithmetic with fp64 dot accumulators and the per-node exponent offset in Step 1 (SURVEY trap #4).
+    Tolerance 2e-3 absolute on phi (range ~[-0.5, 4.6]): fp32 CG at kappa ~1e4..1e5 cannot do better."""
+    d = load_golden(case)
+    s = make_solver(shm, d, precision=shm.SHM_F32)
+    st = s.solve(scrub="pc" not in case, precond=precond, allow_noconv=True)
+    phi, _ = s.get_phi()
+    assert np.isfinite(phi).all()
+    err = np.abs(phi - d["phi"]).max()
+    assert err < 2e-3, (err, st.iters, st.rel_residual)
+
+
+def test_fp32_conv_exponent_offset_prevents_underflow(shm):
+    """A grid 40x larger than the source cloud: lambda*d ~ 400 at the corners, exp() underflows in fp32 (and even the
+    unnormalised fp64 sum is ~1e-170) -- the per-node offset keeps every direction finite and equal to the fp64 one."""
+    d = load_golden("bunny_small_n16")
+    n = 16
+    lam = float(d["lam"]) * 8.0
+    bbox = d["bbox_min"] * 3.0
+    cell = float(d["cell"]) * 3.0
+    Y = {}
+    for prec in (shm.SHM_F64, shm.SHM_F32):
+        s = shm.GridSolver(precision=prec)
+        s.set_problem(d["pos"], d["wnormal"], d["area"], lam, n, bbox, cell)
+        s.run_conv()
+        Y[prec] = np.stack([s.get_field(k) for k in (0, 1, 2)], axis=1)
+    assert np.isfinite(Y[shm.SHM_F32]).all()
+    ok = np.isfinite(Y[shm.SHM_F64]).all(axis=1)
+    assert ok.mean() > 0.9
+    # directions agree wherever fp64 itself is well conditioned (away from the medial axis the agreement is ~1e-4)
+    dots = (Y[shm.SHM_F64][ok] * Y[shm.SHM_F32][ok]).sum(axis=1)
+    assert np.median(1 - dots) < 1e-6
