@@ -228,8 +228,8 @@ struct Solver final : SolverBase {
             HIPCHK(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, greatest));
         }
         HIPCHK(hipHostMalloc((void**)&h_pinned, 64 * sizeof(double)));
-        if (cfg.world > 1) {
-            if (!cfg.rccl_unique_id) throw Error(SHM_ERR_INVALID, "world>1 needs rccl_unique_id");
+        if (cfg.world > 1 && !cfg.rccl_unique_id) throw Error(SHM_ERR_INVALID, "world>1 needs rccl_unique_id");
+        if (cfg.rccl_unique_id) {  // also with world == 1: a one-rank communicator exercises the RCCL path
             Rccl& R = Rccl::get();
             Rccl::unique_id id;
             memcpy(&id, cfg.rccl_unique_id, sizeof id);
@@ -437,10 +437,46 @@ struct Solver final : SolverBase {
         mp = ((m + kGJ - 1) / kGJ) * kGJ;
     }
 
+    // shift items: every source contributes one bilinear evaluation per z-plane of its cell (:405-431); the owner of the
+    // plane evaluates it, so the slabs sum to the reference's nested lerp.
+    void build_shift_items(hipStream_t stream) {
+        const size_t plane = (size_t)n * n;
+        for (Slab<T>& sl : slabs) {
+            std::vector<ShiftItem> items;
+            for (int64_t s = 0; s < S; s++) {
+                const double* b = &h_pos[3 * s];
+                const int i = (int)std::floor((b[0] - bbox_min[0]) / cell);
+                const int j = (int)std::floor((b[1] - bbox_min[1]) / cell);
+                const int k = (int)std::floor((b[2] - bbox_min[2]) / cell);
+                const double tx = (b[0] - (i * cell + bbox_min[0])) / cell;
+                const double ty = (b[1] - (j * cell + bbox_min[1])) / cell;
+                const double tz = (b[2] - (k * cell + bbox_min[2])) / cell;
+                for (int dz = 0; dz < 2; dz++) {
+                    const int kz = k + dz;
+                    if (kz < sl.k0 || kz >= sl.k1) continue;
+                    ShiftItem it;
+                    it.node = (uint32_t)((size_t)i + (size_t)j * n + (size_t)(kz - sl.k0 + 1) * plane);
+                    it.pad = 0.f;
+                    it.tx = tx;
+                    it.ty = ty;
+                    it.weight = h_area[s] * (dz == 0 ? (1. - tz) : tz);
+                    items.push_back(it);
+                }
+            }
+            sl.n_shift = (int)items.size();
+            sl.shift_items.upload(items, stream);
+        }
+    }
+    void build_shift_items_only() {
+        build_shift_items(stream);
+        HIPCHK(hipStreamSynchronize(stream));
+    }
+
     // Per-slab CSR pieces, shift items, and G = A A^T (sparse triplets -> dense on device -> inverted).
     void build_constraints() {
         hipStream_t stream = stream2;  // everything below runs beside the Step-1 kernel of the main stream
         build_rows();
+        build_shift_items(stream);
         const size_t plane = (size_t)n * n;
         for (Slab<T>& sl : slabs) {
             const int64_t lo = (int64_t)sl.k0 * (int64_t)plane, hi = (int64_t)sl.k1 * (int64_t)plane;
@@ -483,30 +519,6 @@ struct Solver final : SolverBase {
             sl.nent_coef.upload(nent_coef, stream);
             sl.red.alloc((size_t)m + 1);
             sl.u.alloc((size_t)std::max(m, 1));
-            // shift items: every source contributes one bilinear evaluation per z-plane of its cell (:405-431)
-            std::vector<ShiftItem> items;
-            for (int64_t s = 0; s < S; s++) {
-                const double* b = &h_pos[3 * s];
-                const int i = (int)std::floor((b[0] - bbox_min[0]) / cell);
-                const int j = (int)std::floor((b[1] - bbox_min[1]) / cell);
-                const int k = (int)std::floor((b[2] - bbox_min[2]) / cell);
-                const double tx = (b[0] - (i * cell + bbox_min[0])) / cell;
-                const double ty = (b[1] - (j * cell + bbox_min[1])) / cell;
-                const double tz = (b[2] - (k * cell + bbox_min[2])) / cell;
-                for (int dz = 0; dz < 2; dz++) {
-                    const int kz = k + dz;
-                    if (kz < sl.k0 || kz >= sl.k1) continue;
-                    ShiftItem it;
-                    it.node = (uint32_t)((size_t)i + (size_t)j * n + (size_t)(kz - sl.k0 + 1) * plane);
-                    it.pad = 0.f;
-                    it.tx = tx;
-                    it.ty = ty;
-                    it.weight = h_area[s] * (dz == 0 ? (1. - tz) : tz);
-                    items.push_back(it);
-                }
-            }
-            sl.n_shift = (int)items.size();
-            sl.shift_items.upload(items, stream);
         }
         // ---- G = A A^T as triplets via a node -> entries map
         std::unordered_map<int64_t, std::vector<std::pair<int, double>>> node_map;
@@ -848,11 +860,68 @@ struct Solver final : SolverBase {
     }
 
     // ------------------------------------------------------------------------------------------
+    // shift + phi (:110-111), shared by the constrained solve and the fast path; x holds -phi.
+    void launch_shift_and_phi() {
+        for (Slab<T>& sl : slabs) {
+            const int g = std::max(1, std::min(256, (sl.n_shift + kBlock - 1) / kBlock));
+            hipLaunchKernelGGL((shift_partial_kernel<T>), dim3(g), dim3(kBlock), 0, stream, sl.n_shift, sl.shift_items.p, n, sl.x.p, sl.partials.p);
+            hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, stream, sl.partials.p, g, sl.pq.p);
+        }
+        allreduce(1, 1);
+        for (Slab<T>& sl : slabs)
+            hipLaunchKernelGGL((write_phi_kernel<T>), dim3(grid_for(sl.nown, 4096)), dim3(kBlock), 0, stream, sl.nown, sl.plane, sl.x.p, sl.pq.p, area_sum,
+                               sl.sc.p, sl.q.p);
+        HIPCHK(hipGetLastError());
+    }
+
+    // fastIntegration: three families of prefix scans (see bfs_* kernels); slabs are chained bottom-up through the
+    // top plane of x (device copy between local slabs, ncclSend/ncclRecv between ranks).
+    void solve_fast(const shm_opts& o, shm_stats* st, Event& e_start, Event& e_conv, Event& e_div, std::chrono::steady_clock::time_point wall0) {
+        (void)o;
+        Event e_int, e_end;
+        build_shift_items_only();
+        Rccl* R = comm ? &Rccl::get() : nullptr;
+        const int dt = sizeof(T) == 8 ? Rccl::kFloat64 : Rccl::kFloat32;
+        for (size_t si = 0; si < slabs.size(); si++) {
+            Slab<T>& sl = slabs[si];
+            if (sl.k0 == 0) {
+                hipLaunchKernelGGL((bfs_plane0_kernel<T>), dim3(1), dim3(std::min(1024, ((n + 63) / 64) * 64)), 0, stream, n, cell, bbox_min[0], bbox_min[1],
+                                   sl.Y0.p, sl.Y1.p, sl.Y2.p, sl.x.p);
+            } else if (si == 0) {
+                R->chk(R->Recv(sl.x.p, sl.plane, dt, cfg.rank - 1, comm, stream), "ncclRecv(bfs)");  // low ghost <- top plane of the rank below
+            }
+            hipLaunchKernelGGL((bfs_z_kernel<T>), dim3((unsigned)((sl.plane + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, sl.gp, cell, bbox_min[2], sl.Y0.p,
+                               sl.Y1.p, sl.Y2.p, sl.x.p);
+            const T* top = sl.x.p + (size_t)sl.nzl * sl.plane;
+            if (si + 1 < slabs.size()) HIPCHK(hipMemcpyAsync(slabs[si + 1].x.p, top, sl.plane * sizeof(T), hipMemcpyDeviceToDevice, stream));
+            else if (comm && cfg.rank < cfg.world - 1) R->chk(R->Send(top, sl.plane, dt, cfg.rank + 1, comm, stream), "ncclSend(bfs)");
+        }
+        HIPCHK(hipGetLastError());
+        e_int.record(stream);
+        launch_shift_and_phi();
+        e_end.record(stream);
+        HIPCHK(hipMemcpyAsync(h_pinned, slabs[0].sc.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        have_phi = true;
+        if (st) {
+            memset(st, 0, sizeof *st);
+            st->n = n;
+            st->S = S;
+            st->shift = h_pinned[SC_SHIFT];
+            st->ms_conv = elapsed(e_start, e_conv);
+            st->ms_div = elapsed(e_conv, e_div);
+            st->ms_pcg = elapsed(e_div, e_int);  // the integration that replaces the solve
+            st->ms_shift = elapsed(e_int, e_end);
+            st->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+            st->preconditioner = SHM_PRECOND_NONE;
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------
     void solve(const shm_opts& o_in, shm_stats* st) override {
         need_problem();
         HIPCHK(hipSetDevice(cfg.device));
         shm_opts o = o_in;
-        if (o.fast_integration) throw Error(SHM_ERR_INVALID, "fast_integration (BFS, signed_heat_grid_solver.cpp:224-275) is not implemented on the device yet");
         bool pre = false;
         if (o.preconditioner == SHM_PRECOND_DCT) {
             if (!precond_available()) throw Error(SHM_ERR_INVALID, "DCT preconditioner needs n = 2^k in [16,1024] and a power-of-two number of z-slabs dividing n");
@@ -873,6 +942,10 @@ struct Solver final : SolverBase {
         e_conv.record(stream);
         launch_div(o.scrub_nonfinite);
         e_div.record(stream);
+        if (o.fast_integration) {
+            solve_fast(o, st, e_start, e_conv, e_div, wall0);
+            return;
+        }
         e_s2a.record(stream2);
         build_constraints();  // on stream2: overlaps the Step-1 kernel; returns once (A A^T)^-1 is ready
         e_s2b.record(stream2);
@@ -954,16 +1027,7 @@ struct Solver final : SolverBase {
         e_pcg.record(stream);
 
         // ---- shift + phi (:110-111)
-        for (Slab<T>& sl : slabs) {
-            const int g = std::max(1, std::min(256, (sl.n_shift + kBlock - 1) / kBlock));
-            hipLaunchKernelGGL((shift_partial_kernel<T>), dim3(g), dim3(kBlock), 0, stream, sl.n_shift, sl.shift_items.p, n, sl.x.p, sl.partials.p);
-            hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, stream, sl.partials.p, g, sl.pq.p);
-        }
-        allreduce(1, 1);
-        for (Slab<T>& sl : slabs)
-            hipLaunchKernelGGL((write_phi_kernel<T>), dim3(grid_for(sl.nown, 4096)), dim3(kBlock), 0, stream, sl.nown, sl.plane, sl.x.p, sl.pq.p, area_sum,
-                               sl.sc.p, sl.q.p);
-        HIPCHK(hipGetLastError());
+        launch_shift_and_phi();
         e_end.record(stream);
         HIPCHK(hipMemcpyAsync(h_pinned, slabs[0].sc.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));

@@ -531,6 +531,68 @@ __global__ __launch_bounds__(kBlock) void write_phi_kernel(size_t nown, size_t o
     if (blockIdx.x == 0 && threadIdx.x == 0) sc[SC_SHIFT] = shift;
 }
 
+// =================================================================================================
+// fastIntegration (integrateGreedily, signed_heat_grid_solver.cpp:224-275).  The reference's FIFO BFS from node
+// (0,0,0) visits the grid level by level (i+j+k) and, inside a level, in descending lexicographic (i,j,k) order, so the
+// first visitor ("parent") of a node is  (i,j,k-1) if k>0, else (i,j-1,0) if j>0, else (i-1,0,0)  -- verified against the
+// order-dependent host BFS in tests.  The BFS therefore equals three families of independent prefix scans:
+//   row (.,0,0) along x  ->  plane k=0 along y  ->  every (i,j) column along z,
+// with the reference's step  phi[q] = phi[p] + dot(normalize(Y_p + Y_q), pos(q) - pos(p))  (:245-251).
+// The kernels store x = -phi (the CG convention) so that the shift / write-out kernels are shared.
+// =================================================================================================
+template <typename T>
+__device__ __forceinline__ double bfs_step(const T* __restrict__ Y0, const T* __restrict__ Y1, const T* __restrict__ Y2, size_t p, size_t q,
+                                           double e0, double e1, double e2) {
+    double a0 = (double)Y0[q] + (double)Y0[p], a1 = (double)Y1[q] + (double)Y1[p], a2 = (double)Y2[q] + (double)Y2[p];
+    const double nrm = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+    a0 /= nrm; a1 /= nrm; a2 /= nrm;
+    return a0 * e0 + a1 * e1 + a2 * e2;
+}
+
+// plane k = 0 of the slab that owns it: thread 0 scans the row j = 0 along x, then every thread scans its column along y.
+template <typename T>
+__global__ __launch_bounds__(1024) void bfs_plane0_kernel(int n, double cell, double bx, double by, const T* __restrict__ Y0,
+                                                          const T* __restrict__ Y1, const T* __restrict__ Y2, T* __restrict__ x) {
+    const size_t off = (size_t)n * n;  // owned plane 0 sits after the low ghost plane
+    if (threadIdx.x == 0) {
+        double phi = 0.;
+        x[off] = (T)0;
+        for (int i = 1; i < n; i++) {
+            const double e0 = (i * cell + bx) - ((i - 1) * cell + bx);
+            phi = phi + bfs_step<T>(Y0, Y1, Y2, off + i - 1, off + i, e0, 0., 0.);
+            x[off + i] = (T)(-phi);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        double phi = -(double)x[off + i];
+        for (int j = 1; j < n; j++) {
+            const double e1 = (j * cell + by) - ((j - 1) * cell + by);
+            phi = phi + bfs_step<T>(Y0, Y1, Y2, off + (size_t)(j - 1) * n + i, off + (size_t)j * n + i, 0., e1, 0.);
+            x[off + (size_t)j * n + i] = (T)(-phi);
+        }
+    }
+}
+
+// columns along z for the owned planes; the plane below (low ghost, or owned plane 0 when the slab starts at k = 0)
+// already holds x = -phi.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void bfs_z_kernel(GridParams G, double cell, double bz, const T* __restrict__ Y0, const T* __restrict__ Y1,
+                                                       const T* __restrict__ Y2, T* __restrict__ x) {
+    const size_t plane = (size_t)G.n * G.n;
+    const size_t ij = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (ij >= plane) return;
+    const int kk0 = (G.k0 == 0) ? 1 : 0;  // first owned plane to fill (local owned index); its parent plane is kk0-1
+    double phi = -(double)x[(size_t)kk0 * plane + ij];  // local plane index = owned index + 1 (ghost layout) -> parent at kk0
+    for (int kk = kk0; kk < G.nzl; kk++) {
+        const int k = G.k0 + kk;
+        const double e2 = (k * cell + bz) - ((k - 1) * cell + bz);
+        const size_t q = (size_t)(kk + 1) * plane + ij, pidx = q - plane;
+        phi = phi + bfs_step<T>(Y0, Y1, Y2, pidx, q, 0., 0., e2);
+        x[q] = (T)(-phi);
+    }
+}
+
 // sum the per-slab reduction vectors of the slabs this process owns and write the result back to all of them
 __global__ __launch_bounds__(kBlock) void sum_slabs_kernel(int nslabs, double* const* __restrict__ bufs, int count) {
     const int a = blockIdx.x * kBlock + threadIdx.x;

@@ -271,3 +271,43 @@ def test_fp32_conv_exponent_offset_prevents_underflow(shm):
     # directions agree wherever fp64 itself is well conditioned (away from the medial axis the agreement is ~1e-4)
     dots = (Y[shm.SHM_F64][ok] * Y[shm.SHM_F32][ok]).sum(axis=1)
     assert np.median(1 - dots) < 1e-6
+
+
+# ---- fastIntegration (--f): integrateGreedily, signed_heat_grid_solver.cpp:224-275 ---------------------------------------
+@pytest.mark.parametrize("n", [16, 32])
+@pytest.mark.parametrize("slabs", [1, 2, 5])
+def test_fast_integration_matches_bfs_golden(shm, n, slabs):
+    """The device path (three families of prefix scans) must reproduce the reference's order-dependent FIFO BFS."""
+    d = load_golden("bunny_small_fast_n%d" % n)
+    s = make_solver(shm, d, local_slabs=slabs)
+    st = s.solve(fast=True)
+    phi, _ = s.get_phi()
+    assert abs(st.shift - float(d["shift"])) < 1e-9
+    assert np.abs(phi - d["phi"]).max() < 1e-9
+
+
+def test_fast_integration_matches_c_oracle_odd_size(shm, oracle_c):
+    d = load_golden("bunny_small_n16")
+    n = 23
+    cell = float(d["cell"]) * 15 / (n - 1)
+    s = shm.GridSolver()
+    s.set_problem(d["pos"], d["wnormal"], d["area"], float(d["lam"]), n, d["bbox_min"], cell)
+    s.solve(fast=True)
+    phi, _ = s.get_phi()
+    ref = np.zeros(n ** 3)
+    st = np.zeros(5)
+    oracle_c.shmo_compute_distance(n, c_(d["bbox_min"]), cell, len(d["area"]), c_(d["pos"]).reshape(-1), c_(d["wnormal"]).reshape(-1),
+                                   c_(d["area"]), float(d["lam"]), 1, 1, 0.0, 0, ref, st)
+    assert np.abs(phi - ref).max() < 1e-9
+
+
+def test_rccl_single_rank_communicator(shm):
+    """world=1 with an ncclUniqueId: the library loads librccl, creates a 1-rank communicator and routes its reductions
+    through ncclAllReduce on the solver's stream (the multi-GPU code path, minus the peers)."""
+    d = load_golden("bunny_small_n16")
+    uid = shm.comm_unique_id()
+    assert len(uid) == 128
+    s = make_solver(shm, d, world=1, rank=0, rccl_unique_id=uid)
+    st = s.solve(tol=1e-10)
+    phi, _ = s.get_phi()
+    assert np.abs(phi - d["phi"]).max() < 1e-7
