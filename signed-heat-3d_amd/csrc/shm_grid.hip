@@ -357,17 +357,15 @@ struct Solver final : SolverBase {
             P.kk_begin = (sl.k0 > 0) ? 0 : 1;                  // low ghost plane exists globally?
             P.kk_end = (sl.k1 < n) ? sl.nzl + 2 : sl.nzl + 1;  // high ghost plane exists globally?
             P.k0 = sl.k0;
-            for (int a = 0; a < 3; a++) {
-                P.bbox_min[a] = bbox_min[a];
-                P.center[a] = src_center[a];
-            }
+            for (int a = 0; a < 3; a++) P.bbox_min[a] = bbox_min[a];
             P.cell = cell;
             P.lambda = lambda;
-            P.radius = src_radius;
             P.S = (int)S;
-            const size_t total = (size_t)(P.kk_end - P.kk_begin) * sl.plane;
+            P.tiles_x = (n + kConvTile - 1) / kConvTile;
+            P.tiles_y = P.tiles_x;
+            const int tiles_z = (P.kk_end - P.kk_begin + kConvTile - 1) / kConvTile;
             constexpr int NPT = 2;
-            const unsigned grid = (unsigned)((total + (size_t)kBlock * NPT - 1) / ((size_t)kBlock * NPT));
+            const unsigned grid = (unsigned)(P.tiles_x * P.tiles_y * tiles_z);
             hipLaunchKernelGGL((conv_normalize_kernel<T, NPT>), dim3(grid), dim3(kBlock), 0, stream, P, d_src.p, sl.Y0.p, sl.Y1.p, sl.Y2.p);
         }
         HIPCHK(hipGetLastError());

@@ -112,46 +112,67 @@ struct ConvParams {
     int kk_begin;       // first local plane (0 = low ghost) to evaluate
     int kk_end;         // one past the last local plane
     int k0;             // global k of local plane 1 (first owned plane)
+    int tiles_x, tiles_y;  // 8x8x8-node tiles per axis (tiles_z = gridDim.x / (tiles_x*tiles_y))
     double bbox_min[3];
     double cell;
     double lambda;
-    double center[3];   // bounding-sphere centre / radius of the sources (fp32 exponent offset only)
-    double radius;
     int S;
 };
 
+constexpr int kConvTile = 8;  // 8x8x8 nodes per workgroup, 2 per lane
+
+// Workgroup = one compact 8x8x8 tile of nodes (2 per lane), so that a single exponent offset per workgroup is tight:
+//   T = float: d0 = max(0, min_s |c_tile - b_s| - r_tile) is a lower bound of every (node, source) distance of the tile and
+//   exceeds the true nearest distance by at most the tile diameter (lambda * 14h ~ 4), so exp(-lambda (r - d0)) of the
+//   nearest source never underflows; the common factor exp(lambda d0) cancels in X/|X|.
+//   T = double: d0 = 0 -- the reference's own arithmetic (fp64 underflows only beyond lambda r ~ 745).
 template <typename T, int NPT>
 __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, const T* __restrict__ src /* [S][6]: pos xyz, wn xyz */,
                                                                 T* __restrict__ Y0, T* __restrict__ Y1, T* __restrict__ Y2) {
+    static_assert(NPT * kBlock == kConvTile * kConvTile * kConvTile, "tile = NPT nodes per lane");
     __shared__ T tile[kSrcTile * 6];
-    const size_t plane = (size_t)P.n * P.n;
-    const size_t first = (size_t)P.kk_begin * plane;
-    const size_t total = (size_t)(P.kk_end - P.kk_begin) * plane;
-    const size_t base = (size_t)blockIdx.x * (kBlock * NPT) + threadIdx.x;
+    __shared__ float red[kBlock / kWave];
+    const int n = P.n;
+    const size_t plane = (size_t)n * n;
+    const int bt = blockIdx.x;
+    const int tz = bt / (P.tiles_x * P.tiles_y), trem = bt - tz * (P.tiles_x * P.tiles_y);
+    const int ty = trem / P.tiles_x, tx = trem - ty * P.tiles_x;
+    const int i0 = tx * kConvTile, j0 = ty * kConvTile, kk0 = P.kk_begin + tz * kConvTile;
 
-    T px[NPT], py[NPT], pz[NPT], ax[NPT], ay[NPT], az[NPT], d0[NPT];
+    T px[NPT], py[NPT], pz[NPT], ax[NPT], ay[NPT], az[NPT];
     bool live[NPT];
+    size_t vidx[NPT];
 #pragma unroll
     for (int e = 0; e < NPT; e++) {
-        size_t v = base + (size_t)e * kBlock;
-        live[e] = v < total;
-        if (!live[e]) v = total - 1;
-        v += first;
-        const int kk = (int)(v / plane);
-        const int rem = (int)(v - (size_t)kk * plane);
-        const int j = rem / P.n, i = rem - j * P.n;
+        const int id = threadIdx.x + e * kBlock;
+        int i = i0 + (id & 7), j = j0 + ((id >> 3) & 7), kk = kk0 + (id >> 6);
+        live[e] = i < n && j < n && kk < P.kk_end;
+        i = min(i, n - 1); j = min(j, n - 1); kk = min(kk, P.kk_end - 1);
+        vidx[e] = (size_t)kk * plane + (size_t)j * n + i;
         const int k = P.k0 + kk - 1;
         // indicesToNodePosition: (i,j,k)*cellSize + bboxMin, evaluated in double like the reference
-        const double x = i * P.cell + P.bbox_min[0], y = j * P.cell + P.bbox_min[1], z = k * P.cell + P.bbox_min[2];
-        px[e] = (T)x; py[e] = (T)y; pz[e] = (T)z;
+        px[e] = (T)(i * P.cell + P.bbox_min[0]);
+        py[e] = (T)(j * P.cell + P.bbox_min[1]);
+        pz[e] = (T)(k * P.cell + P.bbox_min[2]);
         ax[e] = ay[e] = az[e] = (T)0;
-        if (sizeof(T) == 4) {
-            const double dx = x - P.center[0], dy = y - P.center[1], dz = z - P.center[2];
-            const double dd = sqrt(dx * dx + dy * dy + dz * dz) - P.radius;
-            d0[e] = (T)(dd > 0. ? dd : 0.);
-        } else {
-            d0[e] = (T)0;
+    }
+    T d0 = (T)0;
+    if (sizeof(T) == 4) {
+        // tile centre / circumscribed radius, then the block-wide minimum distance to the sources
+        const float cx = (float)((i0 + 3.5) * P.cell + P.bbox_min[0]), cy = (float)((j0 + 3.5) * P.cell + P.bbox_min[1]);
+        const float cz = (float)((P.k0 + kk0 - 1 + 3.5) * P.cell + P.bbox_min[2]);
+        const float rt = (float)(3.5 * 1.7320508075688772 * P.cell);
+        float dmin = 3.0e38f;
+        for (int s = threadIdx.x; s < P.S; s += kBlock) {
+            const float dx = cx - (float)src[(size_t)s * 6], dy = cy - (float)src[(size_t)s * 6 + 1], dz = cz - (float)src[(size_t)s * 6 + 2];
+            dmin = fminf(dmin, dx * dx + dy * dy + dz * dz);
         }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, off, kWave));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dmin;
+        __syncthreads();
+        dmin = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+        d0 = (T)fmaxf(0.f, sqrtf(dmin) * 0.999999f - rt * 1.000001f);
     }
     const T lam = (T)P.lambda;
     for (int s0 = 0; s0 < P.S; s0 += kSrcTile) {
@@ -168,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
                 const T dx = px[e] - sx, dy = py[e] - sy, dz = pz[e] - sz;
                 T r, rinv;
                 YukawaMath<T>::rsqrt_and_sqrt(dx * dx + dy * dy + dz * dz, rinv, r);
-                const T g = YukawaMath<T>::exp_neg(-lam * (r - d0[e])) * rinv;   // r = 0 -> inf*0 = NaN like exp(0)/0 -> inf -> NaN after normalise
+                const T g = YukawaMath<T>::exp_neg(-lam * (r - d0)) * rinv;   // r = 0 -> NaN, like exp(0)/0 = inf -> NaN after normalise
                 ax[e] += wx * g; ay[e] += wy * g; az[e] += wz * g;
             }
         }
@@ -176,11 +197,15 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
 #pragma unroll
     for (int e = 0; e < NPT; e++) {
         if (!live[e]) continue;
-        const size_t v = first + base + (size_t)e * kBlock;
-        const T nrm = t_sqrt<T>(ax[e] * ax[e] + ay[e] * ay[e] + az[e] * az[e]);
-        Y0[v] = ax[e] / nrm;  // 0/0 -> NaN exactly like X /= X.norm() (:61)
-        Y1[v] = ay[e] / nrm;
-        Y2[v] = az[e] / nrm;
+        T x0 = ax[e], x1 = ay[e], x2 = az[e];
+        if (sizeof(T) == 4) {  // fp32 only: pre-scale so that the squares cannot underflow (|X| itself may be ~1e-30)
+            const T mx = fmaxf(fmaxf(fabsf((float)x0), fabsf((float)x1)), fabsf((float)x2));
+            x0 /= mx; x1 /= mx; x2 /= mx;  // mx = 0 -> NaN, the reference's 0/0
+        }
+        const T nrm = t_sqrt<T>(x0 * x0 + x1 * x1 + x2 * x2);
+        Y0[vidx[e]] = x0 / nrm;  // 0/0 -> NaN exactly like X /= X.norm() (:61)
+        Y1[vidx[e]] = x1 / nrm;
+        Y2[vidx[e]] = x2 / nrm;
     }
 }
 

@@ -252,13 +252,14 @@ def test_fp32_path_tracks_fp64_oracle(shm, case, precond):
 
 
 def test_fp32_conv_exponent_offset_prevents_underflow(shm):
-    """A grid 40x larger than the source cloud: lambda*d ~ 400 at the corners, exp() underflows in fp32 (and even the
-    unnormalised fp64 sum is ~1e-170) -- the per-node offset keeps every direction finite and equal to the fp64 one."""
+    """lambda*d ~ 400 at the grid corners: exp() underflows in fp32 (it flushes beyond ~87) while fp64 still holds
+    ~1e-170.  The per-tile offset keeps every fp32 direction finite and equal to the fp64 one."""
     d = load_golden("bunny_small_n16")
     n = 16
-    lam = float(d["lam"]) * 8.0
-    bbox = d["bbox_min"] * 3.0
-    cell = float(d["cell"]) * 3.0
+    lam = float(d["lam"]) * 4.0
+    c = d["bbox_min"] + 7.5 * float(d["cell"])
+    bbox = c - 2.0 * (c - d["bbox_min"])
+    cell = float(d["cell"]) * 2.0
     Y = {}
     for prec in (shm.SHM_F64, shm.SHM_F32):
         s = shm.GridSolver(precision=prec)
@@ -270,7 +271,7 @@ def test_fp32_conv_exponent_offset_prevents_underflow(shm):
     assert ok.mean() > 0.9
     # directions agree wherever fp64 itself is well conditioned (away from the medial axis the agreement is ~1e-4)
     dots = (Y[shm.SHM_F64][ok] * Y[shm.SHM_F32][ok]).sum(axis=1)
-    assert np.median(1 - dots) < 1e-6
+    assert np.median(1 - dots) < 1e-6 and np.quantile(1 - dots, 0.99) < 1e-3
 
 
 # ---- fastIntegration (--f): integrateGreedily, signed_heat_grid_solver.cpp:224-275 ---------------------------------------
