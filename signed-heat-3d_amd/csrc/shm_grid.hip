@@ -361,6 +361,7 @@ struct Solver final : SolverBase {
             P.cell = cell;
             P.lambda = lambda;
             P.S = (int)S;
+            P.exact_offset = (lambda * 14.0 * cell > 30.0) ? 1 : 0;  // tile-diameter bound looser than e^-30: per-node offsets
             P.tiles_x = (n + kConvTile - 1) / kConvTile;
             P.tiles_y = P.tiles_x;
             const int tiles_z = (P.kk_end - P.kk_begin + kConvTile - 1) / kConvTile;
@@ -465,9 +466,17 @@ struct Solver final : SolverBase {
             sl.shift_items.upload(items, stream);
         }
     }
+    // device tables of the per-slab reduction buffers for the loop-back sum ([0,ns): red, [ns,2ns): pq)
+    void upload_red_tables(hipStream_t stream) {
+        std::vector<double*> ptrs;
+        for (Slab<T>& sl : slabs) ptrs.push_back(sl.red.p);
+        for (Slab<T>& sl : slabs) ptrs.push_back(sl.pq.p);
+        d_redptrs.upload(ptrs, stream);
+        HIPCHK(hipStreamSynchronize(stream));  // ptrs is a stack object
+    }
     void build_shift_items_only() {
         build_shift_items(stream);
-        HIPCHK(hipStreamSynchronize(stream));
+        upload_red_tables(stream);
     }
 
     // Per-slab CSR pieces, shift items, and G = A A^T (sparse triplets -> dense on device -> inverted).
@@ -551,12 +560,7 @@ struct Solver final : SolverBase {
                            d_tval.p, Ginv.p);
         HIPCHK(hipGetLastError());
         invert_G();
-        {   // device tables of the per-slab reduction buffers for the loop-back sum
-            std::vector<double*> ptrs;
-            for (Slab<T>& sl : slabs) ptrs.push_back(sl.red.p);
-            for (Slab<T>& sl : slabs) ptrs.push_back(sl.pq.p);
-            d_redptrs.upload(ptrs, stream);
-        }
+        upload_red_tables(stream);
         HIPCHK(hipStreamSynchronize(stream));  // d_tidx/d_tval and ptrs go out of scope
         have_constraints = true;
     }

@@ -117,6 +117,7 @@ struct ConvParams {
     double cell;
     double lambda;
     int S;
+    int exact_offset;   // fp32 only: 1 = per-node nearest-source distance (coarse grids: lambda * tile diameter too large)
 };
 
 constexpr int kConvTile = 8;  // 8x8x8 nodes per workgroup, 2 per lane
@@ -156,8 +157,30 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
         pz[e] = (T)(k * P.cell + P.bbox_min[2]);
         ax[e] = ay[e] = az[e] = (T)0;
     }
-    T d0 = (T)0;
-    if (sizeof(T) == 4) {
+    T d0[NPT];
+#pragma unroll
+    for (int e = 0; e < NPT; e++) d0[e] = (T)0;
+    if (sizeof(T) == 4 && P.exact_offset) {
+        // coarse grid: one extra sweep over the sources for the exact nearest distance of every node
+        float m2[NPT];
+#pragma unroll
+        for (int e = 0; e < NPT; e++) m2[e] = 3.0e38f;
+        for (int s0 = 0; s0 < P.S; s0 += kSrcTile) {
+            const int cnt = min(kSrcTile, P.S - s0);
+            __syncthreads();
+            for (int a = threadIdx.x; a < cnt * 6; a += kBlock) tile[a] = src[(size_t)s0 * 6 + a];
+            __syncthreads();
+            for (int s = 0; s < cnt; s++) {
+#pragma unroll
+                for (int e = 0; e < NPT; e++) {
+                    const float dx = (float)px[e] - (float)tile[6 * s], dy = (float)py[e] - (float)tile[6 * s + 1], dz = (float)pz[e] - (float)tile[6 * s + 2];
+                    m2[e] = fminf(m2[e], dx * dx + dy * dy + dz * dz);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < NPT; e++) d0[e] = (T)(sqrtf(m2[e]) * 0.99999f);
+    } else if (sizeof(T) == 4) {
         // tile centre / circumscribed radius, then the block-wide minimum distance to the sources
         const float cx = (float)((i0 + 3.5) * P.cell + P.bbox_min[0]), cy = (float)((j0 + 3.5) * P.cell + P.bbox_min[1]);
         const float cz = (float)((P.k0 + kk0 - 1 + 3.5) * P.cell + P.bbox_min[2]);
@@ -172,7 +195,9 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dmin;
         __syncthreads();
         dmin = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
-        d0 = (T)fmaxf(0.f, sqrtf(dmin) * 0.999999f - rt * 1.000001f);
+        const T d0t = (T)fmaxf(0.f, sqrtf(dmin) * 0.999999f - rt * 1.000001f);
+#pragma unroll
+        for (int e = 0; e < NPT; e++) d0[e] = d0t;
     }
     const T lam = (T)P.lambda;
     for (int s0 = 0; s0 < P.S; s0 += kSrcTile) {
@@ -189,7 +214,7 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
                 const T dx = px[e] - sx, dy = py[e] - sy, dz = pz[e] - sz;
                 T r, rinv;
                 YukawaMath<T>::rsqrt_and_sqrt(dx * dx + dy * dy + dz * dz, rinv, r);
-                const T g = YukawaMath<T>::exp_neg(-lam * (r - d0)) * rinv;   // r = 0 -> NaN, like exp(0)/0 = inf -> NaN after normalise
+                const T g = YukawaMath<T>::exp_neg(-lam * (r - d0[e])) * rinv;   // r = 0 -> NaN, like exp(0)/0 = inf -> NaN after normalise
                 ax[e] += wx * g; ay[e] += wy * g; az[e] += wz * g;
             }
         }

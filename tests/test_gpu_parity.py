@@ -251,15 +251,16 @@ def test_fp32_path_tracks_fp64_oracle(shm, case, precond):
     assert err < 2e-3, (err, st.iters, st.rel_residual)
 
 
-def test_fp32_conv_exponent_offset_prevents_underflow(shm):
+@pytest.mark.parametrize("coarse", [False, True])
+def test_fp32_conv_exponent_offset_prevents_underflow(shm, coarse):
     """lambda*d ~ 400 at the grid corners: exp() underflows in fp32 (it flushes beyond ~87) while fp64 still holds
     ~1e-170.  The per-tile offset keeps every fp32 direction finite and equal to the fp64 one."""
     d = load_golden("bunny_small_n16")
-    n = 16
+    n = 16 if coarse else 128          # coarse: lambda*cell = 33 -> per-node offsets; fine: lambda*cell = 4 -> per-tile offset
     lam = float(d["lam"]) * 4.0
     c = d["bbox_min"] + 7.5 * float(d["cell"])
     bbox = c - 2.0 * (c - d["bbox_min"])
-    cell = float(d["cell"]) * 2.0
+    cell = float(d["cell"]) * 2.0 * 15 / (n - 1)
     Y = {}
     for prec in (shm.SHM_F64, shm.SHM_F32):
         s = shm.GridSolver(precision=prec)
