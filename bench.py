@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--tol", type=float, default=0.0, help="projected-CG relative residual tolerance (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precond", default="auto", choices=["auto", "none", "dct"])
+    ap.add_argument("--solver", default="auto", choices=["auto", "primal", "dual"])
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -159,12 +160,12 @@ def main():
 
     st = None
     for _ in range(args.warmup):
-        st = solver.solve(tol=args.tol, scrub=scrub, precond=args.precond)
+        st = solver.solve(tol=args.tol, scrub=scrub, precond=args.precond, solver=args.solver)
     barrier()
     t0 = time.perf_counter()
     stats = []
     for _ in range(args.steps):
-        st = solver.solve(tol=args.tol, scrub=scrub, precond=args.precond)
+        st = solver.solve(tol=args.tol, scrub=scrub, precond=args.precond, solver=args.solver)
         stats.append(st.as_dict())
     barrier()
     elapsed = time.perf_counter() - t0
@@ -179,6 +180,7 @@ def main():
         # per-kernel algorithmic bytes of the decomposition launched; per rank = per launch
         n_local = N / world
         has_pre = int(avg["preconditioner"]) == 2
+        is_dual = int(avg["solver"]) == 2
         TP = T  # the preconditioner sweeps run in the solve precision
         # name: (algorithmic bytes per launch, avg ms per launch, launches per CG iteration)
         kernels = {
@@ -186,8 +188,10 @@ def main():
             "update_xr_kernel": (6 * n_local * T, avg["ms_update_xr_avg"], 1),
             "update_p_kernel": (3 * n_local * T, avg["ms_update_p_avg"], 1),
         }
-        if has_pre:  # five DCT sweeps (x-fwd, y-fwd, z-fused, y-inv, x-inv+dot): 3T + 8TP bytes per node in total
-            kernels["dct_lines_kernel"] = (n_local * (3 * T + 8 * TP) / 5.0, avg["ms_precond_avg"] / 5.0, 5)
+        if has_pre:  # five DCT sweeps (x-fwd, y-fwd, z-fused, y-inv, x-inv[+dot]): 3T + 8TP bytes per node (2T + 8TP without the dot)
+            kernels["dct_lines_kernel"] = (n_local * ((2 if is_dual else 3) * T + 8 * TP) / 5.0, avg["ms_precond_avg"] / 5.0, 5)
+        if is_dual:  # the dual solver has no N-sized CG sweeps: its vectors are m-dimensional
+            kernels = {"dct_lines_kernel": kernels["dct_lines_kernel"]}
         kinfo = {k: {"algorithmic_bytes_per_launch": b, "avg_ms_per_launch": ms, "launches_per_iter": cnt,
                      "achieved_GBps": (b / (ms * 1e-3) / 1e9 if ms > 0 else None)}
                  for k, (b, ms, cnt) in kernels.items()}
@@ -208,7 +212,8 @@ def main():
             "config": {"workload": args.workload, "grid": "%d^3" % n, "sources": int(pre["S"]), "constraint_rows": int(avg["m"]),
                        "tol": args.tol if args.tol > 0 else (1e-8 if precision == 64 else 1e-5), "cg_iters": int(avg["iters"]),
                        "rel_residual": avg["rel_residual"], "partition": "z-slabs x%d" % world,
-                       "preconditioner": "dct (exact fast Poisson, sandwiched P M^-1 P)" if has_pre else "none"},
+                       "solver": "dual: CG on the Schur complement A K^+ A^T, K^+ = DCT fast Poisson solve" if is_dual else "primal: projected stencil CG",
+                       "preconditioner": ("G^-1 (A K A^T) G^-1" if is_dual else "dct (exact fast Poisson, sandwiched P M^-1 P)") if has_pre else "none"},
             "phases_ms": {k: avg[k] for k in ("ms_conv", "ms_div", "ms_setup", "ms_wait_setup", "ms_pcg", "ms_shift", "ms_total")},
             "pcg": {"ms_per_iter": avg["ms_pcg"] / max(1.0, avg["iters"]), "algorithmic_bytes_per_iter": avg["bytes_per_iter"] / world,
                     "achieved_GBps": avg["bytes_per_iter"] / world / (avg["ms_pcg"] / max(1.0, avg["iters"]) * 1e-3) / 1e9,

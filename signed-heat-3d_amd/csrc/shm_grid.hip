@@ -176,6 +176,7 @@ struct Slab {
     DevArray<uint32_t> ent_node, node_id;
     DevArray<double> ent_coef, nent_coef;
     DevArray<ShiftItem> shift_items;
+    DevArray<double> dv;  // dual solver m-vectors: mu, r, p, z, t1, t2, g (7 x mp)
     DevArray<T> W1, W2;  // DCT work arrays (precision TP == T); W2 only with several slabs (packed transposes)
     int n_touched = 0, n_shift = 0;
     GridParams gp{};
@@ -203,6 +204,10 @@ struct Solver final : SolverBase {
     DevArray<double> Ginv, gjP, gjR, gjC;
     DevArray<int> gjFlag;
     DevArray<double*> d_redptrs;
+    // dual solver: B = A K A^T (CSR, replicated) and the m-vectors of its CG (per slab, replicated values)
+    DevArray<int> Bptr, Bcol;
+    DevArray<double> Bval;
+    bool have_B = false;
     // DCT preconditioner (single slab, n = 2^k)
     using TP = T;  // precision of the preconditioner sweeps
     DevArray<Cplx<TP>> d_tw, d_om;
@@ -526,12 +531,53 @@ struct Solver final : SolverBase {
             sl.nent_coef.upload(nent_coef, stream);
             sl.red.alloc((size_t)m + 1);
             sl.u.alloc((size_t)std::max(m, 1));
+            sl.dv.alloc((size_t)7 * std::max(mp, 64));
         }
         // ---- G = A A^T as triplets via a node -> entries map
         std::unordered_map<int64_t, std::vector<std::pair<int, double>>> node_map;
         node_map.reserve((size_t)m * 4);
         for (int r = 0; r < m; r++)
             for (int e = 0; e < 8; e++) node_map[rows[r].nodes[e]].push_back({r, rows[r].coeffs[e]});
+        {   // B = A K A^T: K a_i is supported on the 8 cell corners and their in-grid neighbours
+            std::vector<int> bptr(m + 1, 0), bcol;
+            std::vector<double> bval;
+            const double ih2 = 1. / (cell * cell);
+            const int64_t nn = n, pl = (int64_t)n * n;
+            std::unordered_map<int64_t, double> ka;
+            std::unordered_map<int, double> brow;
+            for (int r = 0; r < m; r++) {
+                ka.clear();
+                brow.clear();
+                for (int e = 0; e < 8; e++) {
+                    const int64_t c = rows[r].nodes[e];
+                    const double cf = rows[r].coeffs[e];
+                    const int64_t k = c / pl, j = (c - k * pl) / nn, i = c - k * pl - j * nn;
+                    const int64_t nb[6] = {i > 0 ? c - 1 : -1, i < nn - 1 ? c + 1 : -1, j > 0 ? c - nn : -1, j < nn - 1 ? c + nn : -1,
+                                           k > 0 ? c - pl : -1, k < nn - 1 ? c + pl : -1};
+                    int deg = 0;
+                    for (int a = 0; a < 6; a++)
+                        if (nb[a] >= 0) {
+                            deg++;
+                            ka[nb[a]] -= cf * ih2;
+                        }
+                    ka[c] += deg * cf * ih2;
+                }
+                for (const auto& kv : ka) {
+                    auto itn = node_map.find(kv.first);
+                    if (itn == node_map.end()) continue;
+                    for (const auto& oc : itn->second) brow[oc.first] += kv.second * oc.second;
+                }
+                for (const auto& kv : brow) {
+                    bcol.push_back(kv.first);
+                    bval.push_back(kv.second);
+                }
+                bptr[r + 1] = (int)bcol.size();
+            }
+            Bptr.upload(bptr, stream);
+            Bcol.upload(bcol, stream);
+            Bval.upload(bval, stream);
+            have_B = true;
+        }
         std::unordered_map<uint64_t, double> gmap;
         gmap.reserve((size_t)m * 32);
         for (int r = 0; r < m; r++)
@@ -788,7 +834,17 @@ struct Solver final : SolverBase {
     // z' = M^-1 r on every slab (no projection).  dot: also leave the partial sums of r.z' in sl.partials; returns
     // their count per slab.  One slab: x-fwd, y-fwd, z-fused, y-inv, x-inv in place on W1.  P slabs: the y sweeps write /
     // read the packed layout [dest slab][z_local][y_local][x] and two all-to-alls turn z-slabs into y-pencils and back.
-    int launch_precond(bool dot) {
+    enum ArrSel { ARR_R = 0, ARR_Z = 1, ARR_P = 2, ARR_X = 3, ARR_Q = 4 };
+    static T* arr(Slab<T>& sl, int sel) {
+        switch (sel) {
+            case ARR_R: return sl.r.p;
+            case ARR_Z: return sl.z.p;
+            case ARR_P: return sl.p.p;
+            case ARR_X: return sl.x.p;
+            default: return sl.q.p;
+        }
+    }
+    int launch_precond(bool dot, int in_sel = ARR_R, int out_sel = ARR_Z) {
         const long long nn = n, plane = (long long)n * n;
         const int P = total_slabs;
         const int nzl = n / P, nyl = n / P;  // planes per slab == pencil rows per slab (P | n)
@@ -812,7 +868,7 @@ struct Solver final : SolverBase {
                         Q.tiles_a = tiles_slab;
                         Q.in = plain_addr((long long)sl.plane, (long long)kDctLines * nn, 0, nn, 1);
                         Q.out = plain_addr(0, (long long)kDctLines * nn, 0, nn, 1);
-                        launch_dct<DCT_FWD, T, TP, false, true>(Q, tiles_slab, sl.r.p, sl.W1.p, (const TP*)nullptr, nullptr);
+                        launch_dct<DCT_FWD, T, TP, false, true>(Q, tiles_slab, arr(sl, in_sel), sl.W1.p, (const TP*)nullptr, nullptr);
                         break;
                     case 1:  // y-fwd: W1 natural -> (P==1: W1 in place) | (P>1: W2 packed [q][z_l][y_l][x])
                         Q.tiles_a = n / kDctLines;
@@ -851,8 +907,8 @@ struct Solver final : SolverBase {
                         Q.tiles_a = tiles_slab;
                         Q.in = plain_addr(0, (long long)kDctLines * nn, 0, nn, 1);
                         Q.out = plain_addr((long long)sl.plane, (long long)kDctLines * nn, 0, nn, 1);
-                        if (dot) launch_dct<DCT_INV, TP, T, true, true>(Q, tiles_slab, sl.W1.p, sl.z.p, sl.r.p, sl.partials.p);
-                        else launch_dct<DCT_INV, TP, T, false, true>(Q, tiles_slab, sl.W1.p, sl.z.p, (const T*)nullptr, nullptr);
+                        if (dot) launch_dct<DCT_INV, TP, T, true, true>(Q, tiles_slab, sl.W1.p, arr(sl, out_sel), arr(sl, in_sel), sl.partials.p);
+                        else launch_dct<DCT_INV, TP, T, false, true>(Q, tiles_slab, sl.W1.p, arr(sl, out_sel), (const T*)nullptr, nullptr);
                         break;
                     default: break;
                 }
@@ -920,6 +976,134 @@ struct Solver final : SolverBase {
     }
 
     // ------------------------------------------------------------------------------------------
+    // Dual solver (see the block comment above the dual_* kernels): CG on S = A K^+ A^T for the multipliers.
+    void solve_dual(const shm_opts& o, shm_stats* st, Event& e_start, Event& e_conv, Event& e_div, Event& e_setup, Event& e_s2a, Event& e_s2b,
+                    std::chrono::steady_clock::time_point wall0) {
+        Event e_pcg, e_end;
+        const int check_every = o.check_every > 0 ? std::min(o.check_every, 4) : 2;
+        auto mv = [&](Slab<T>& sl, int k) { return sl.dv.p + (size_t)k * mp; };
+        enum { V_MU = 0, V_R = 1, V_P = 2, V_Z = 3, V_T1 = 4, V_T2 = 5, V_G = 6 };
+        const std::vector<int> nopart(slabs.size(), 0);
+        auto gather = [&](int sel) {  // red[1..m] = A * arr(sel), all-reduced
+            for (Slab<T>& sl : slabs)
+                hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(1 + (m + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, m, sl.row_ptr.p, sl.ent_node.p,
+                                   sl.ent_coef.p, arr(sl, sel), sl.partials.p, 0, sl.red.p);
+            allreduce(0, 1 + m);
+        };
+        auto scatter = [&](int vec, int sel, int accumulate) {  // arr(sel) (+)= A^T v
+            for (Slab<T>& sl : slabs)
+                hipLaunchKernelGGL((scatter_rows_to_nodes_kernel<T>), dim3((sl.n_touched + kBlock - 1) / kBlock + 1), dim3(kBlock), 0, stream, sl.n_touched,
+                                   sl.node_id.p, sl.node_ptr.p, sl.ent_row.p, sl.nent_coef.p, mv(sl, vec), accumulate, arr(sl, sel));
+        };
+        auto precondition = [&](int init) {  // z = Pm(G^-1 B G^-1 r); p = z (+ beta p)
+            for (Slab<T>& sl : slabs) {
+                hipLaunchKernelGGL(ginv_matvec_kernel, dim3((m + 3) / 4), dim3(kBlock), 0, stream, m, mp, Ginv.p, mv(sl, V_R), mv(sl, V_T1));
+                hipLaunchKernelGGL(csr_matvec_kernel, dim3((m + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, m, Bptr.p, Bcol.p, Bval.p, mv(sl, V_T1), mv(sl, V_T2));
+                hipLaunchKernelGGL(ginv_matvec_kernel, dim3((m + 3) / 4), dim3(kBlock), 0, stream, m, mp, Ginv.p, mv(sl, V_T2), mv(sl, V_Z));
+                hipLaunchKernelGGL(dual_direction_kernel, dim3(1), dim3(kDualBlock), 0, stream, m, init, mv(sl, V_R), mv(sl, V_Z), mv(sl, V_P), sl.sc.p);
+            }
+        };
+        // ---- g = A K^+ b  and  sum(b)
+        launch_precond(false, ARR_R, ARR_Z);
+        gather(ARR_Z);
+        for (Slab<T>& sl : slabs) {
+            HIPCHK(hipMemcpyAsync(mv(sl, V_G), sl.red.p + 1, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            const int g = grid_for(sl.nown, 1024);
+            hipLaunchKernelGGL((sum_kernel<T>), dim3(g), dim3(kBlock), 0, stream, sl.nown, sl.plane, sl.r.p, sl.partials.p);
+            hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, stream, sl.partials.p, g, sl.pq.p);
+        }
+        allreduce(1, 1);
+        for (Slab<T>& sl : slabs) {
+            hipLaunchKernelGGL(dual_init_mu_kernel, dim3(1), dim3(kDualBlock), 0, stream, m, sl.pq.p, mv(sl, V_MU), sl.sc.p);
+            HIPCHK(hipMemsetAsync(sl.p.p, 0, sl.ntot * sizeof(T), stream));  // w = A^T nu lives in p: zero outside the touched nodes
+        }
+        // ---- r = Pm(g - S mu), z, p
+        scatter(V_MU, ARR_P, 0);
+        launch_precond(false, ARR_P, ARR_Z);
+        gather(ARR_Z);
+        for (Slab<T>& sl : slabs)
+            hipLaunchKernelGGL(dual_init_residual_kernel, dim3(1), dim3(kDualBlock), 0, stream, m, mv(sl, V_G), sl.red.p + 1, mv(sl, V_R), sl.sc.p);
+        precondition(1);
+        HIPCHK(hipGetLastError());
+
+        const int kMaxSamples = 32;
+        std::vector<std::unique_ptr<Event>> ev;
+        if (st) for (int a = 0; a < 3 * kMaxSamples; a++) ev.emplace_back(new Event());
+        int nsamples = 0, it = 0;
+        double rr0 = 0., rr = 0.;
+        bool converged = false, breakdown = false;
+        while (it < o.max_iters && !converged && !breakdown) {
+            const int batch_end = std::min(o.max_iters, it + check_every);
+            for (; it < batch_end; it++) {
+                const bool sample = st && nsamples < kMaxSamples;
+                scatter(V_P, ARR_P, 0);
+                if (sample) ev[3 * nsamples]->record(stream);
+                launch_precond(false, ARR_P, ARR_Z);
+                if (sample) ev[3 * nsamples + 1]->record(stream);
+                gather(ARR_Z);
+                for (Slab<T>& sl : slabs)
+                    hipLaunchKernelGGL(dual_update_kernel, dim3(1), dim3(kDualBlock), 0, stream, m, sl.red.p + 1, mv(sl, V_P), mv(sl, V_MU), mv(sl, V_R), sl.sc.p);
+                precondition(0);
+                if (sample) {
+                    ev[3 * nsamples + 2]->record(stream);
+                    nsamples++;
+                }
+            }
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(h_pinned, slabs[0].sc.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            rr0 = h_pinned[SC_RR0];
+            rr = h_pinned[SC_RR];
+            if (!std::isfinite(rr) || !std::isfinite(rr0) || !std::isfinite(h_pinned[SC_RZ])) breakdown = true;
+            else if (rr <= o.tol * o.tol * rr0) converged = true;
+            log("[shm] dual it=%d rel_res=%.3e", it, std::sqrt(std::fabs(rr / rr0)));
+        }
+        // ---- x = K^+ (A^T mu - b)   (the additive constant cancels in the shift)
+        for (Slab<T>& sl : slabs)
+            hipLaunchKernelGGL((negate_kernel<T>), dim3(grid_for(sl.ntot, 4096)), dim3(kBlock), 0, stream, sl.ntot, sl.r.p, sl.q.p);
+        scatter(V_MU, ARR_Q, 1);
+        launch_precond(false, ARR_Q, ARR_X);
+        e_pcg.record(stream);
+        launch_shift_and_phi();
+        e_end.record(stream);
+        HIPCHK(hipMemcpyAsync(h_pinned, slabs[0].sc.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        have_phi = true;
+        have_div = false;  // r still holds b, but q (= phi now) and p were reused
+        if (st) {
+            memset(st, 0, sizeof *st);
+            st->n = n;
+            st->m = m;
+            st->S = S;
+            st->iters = it;
+            st->rel_residual = std::sqrt(std::fabs(rr / rr0));
+            st->shift = h_pinned[SC_SHIFT];
+            st->ms_conv = elapsed(e_start, e_conv);
+            st->ms_div = elapsed(e_conv, e_div);
+            HIPCHK(hipEventSynchronize(e_s2b.e));
+            st->ms_setup = elapsed(e_s2a, e_s2b);
+            st->ms_wait_setup = elapsed(e_div, e_setup);
+            st->ms_pcg = elapsed(e_setup, e_pcg);
+            st->ms_shift = elapsed(e_pcg, e_end);
+            st->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+            double a_dct = 0., a_rest = 0.;
+            for (int a = 0; a < nsamples; a++) {
+                a_dct += elapsed(*ev[3 * a], *ev[3 * a + 1]);
+                a_rest += elapsed(*ev[3 * a + 1], *ev[3 * a + 2]);
+            }
+            st->ms_precond_avg = nsamples ? a_dct / nsamples : 0.;
+            st->ms_project_avg = nsamples ? a_rest / nsamples : 0.;  // gather, m-vector algebra, 2 G^-1 mat-vecs, B mat-vec
+            st->kernel_samples = nsamples;
+            st->preconditioner = SHM_PRECOND_DCT;
+            st->solver = SHM_SOLVER_DUAL;
+            st->bytes_per_iter = (double)N * (3.0 * sizeof(T) + 8.0 * sizeof(TP)) - (double)N * sizeof(T);  // five DCT sweeps, no r.z read
+        }
+        if (breakdown) throw Error(SHM_ERR_BREAKDOWN, fmt("dual CG broke down at iteration %d (rr=%g, rr0=%g)", it, rr, rr0));
+        if (!converged) throw Error(SHM_ERR_NOCONV, fmt("dual CG: max_iters=%d reached, rel. residual %.3e > tol %.1e", o.max_iters,
+                                                          std::sqrt(std::fabs(rr / rr0)), o.tol));
+    }
+
+    // ------------------------------------------------------------------------------------------
     void solve(const shm_opts& o_in, shm_stats* st) override {
         need_problem();
         HIPCHK(hipSetDevice(cfg.device));
@@ -951,8 +1135,21 @@ struct Solver final : SolverBase {
         e_s2a.record(stream2);
         build_constraints();  // on stream2: overlaps the Step-1 kernel; returns once (A A^T)^-1 is ready
         e_s2b.record(stream2);
-        if (pre) setup_precond();
+        bool dual = false;
+        if (o.solver == SHM_SOLVER_DUAL) {
+            if (!precond_available()) throw Error(SHM_ERR_INVALID, "the dual solver needs the DCT: n = 2^k in [16,1024] and a power-of-two number of z-slabs dividing n");
+            dual = true;
+        } else if (o.solver == SHM_SOLVER_AUTO) {
+            dual = precond_available() && o.preconditioner != SHM_PRECOND_NONE;
+        } else if (o.solver != SHM_SOLVER_PRIMAL) {
+            throw Error(SHM_ERR_INVALID, "unknown solver");
+        }
+        if (pre || dual) setup_precond();
         e_setup.record(stream);
+        if (dual) {
+            solve_dual(o, st, e_start, e_conv, e_div, e_setup, e_s2a, e_s2b, wall0);
+            return;
+        }
 
         // ---- projected (preconditioned) CG, SURVEY 7.3:
         //      x=0; r=P b; z=P M^-1 r; p=-z; loop { q=Kp; a=rho/p.q; x+=a p; r=P(r+a q); z=P M^-1 r; rho'=r.z; p=-z+(rho'/rho) p }
@@ -1069,6 +1266,7 @@ struct Solver final : SolverBase {
             st->ms_precond_avg = pre ? acc[4] * inv : 0.;
             st->kernel_samples = nsamples;
             st->preconditioner = pre ? SHM_PRECOND_DCT : SHM_PRECOND_NONE;
+            st->solver = SHM_SOLVER_PRIMAL;
             // 11NT for the CG sweeps; the five DCT sweeps move 3T + 8TP more (read r twice + write z, 4 in-place sweeps of W)
             st->bytes_per_iter = 11.0 * (double)N * sizeof(T) + (pre ? (double)N * (3.0 * sizeof(T) + 8.0 * sizeof(TP)) : 0.);
         }

@@ -393,7 +393,9 @@ enum Scalar : int {
     SC_AREA = 5,   // sum of source areas
     SC_RR = 6,     // ||P r||^2 of the current residual (convergence test)
     SC_RR0 = 7,    // ||P b||^2
-    SC_COUNT = 8
+    SC_RZ = 8,     // dual solver: r.z of the current iteration
+    SC_SUMB = 9,   // dual solver: sum of the right-hand side b (compatibility condition sum(mu) = sum(b))
+    SC_COUNT = 16
 };
 // red[] layout (the all-reduced vector): red[0] = scalar partial sum, red[1..m] = w = A r'
 
@@ -641,6 +643,138 @@ __global__ __launch_bounds__(kBlock) void bfs_z_kernel(GridParams G, double cell
         phi = phi + bfs_step<T>(Y0, Y1, Y2, pidx, q, 0., 0., e2);
         x[q] = (T)(-phi);
     }
+}
+
+// =================================================================================================
+// Dual (Schur-complement) solver of the KKT system  [[L, A^T],[A, 0]] [x; mu] = [b; 0]  (signed_heat_grid_solver.cpp:101-107):
+// with K = -L and K^+ its pseudo-inverse (the DCT solve):  x = K^+ (A^T mu - b) + c 1,  S mu + c 1 = A K^+ b,  1^T mu = 1^T b,
+// S = A K^+ A^T (m x m, SPD).  CG on S restricted to {sum(nu) = 0}, preconditioned by G^-1 (A K A^T) G^-1 (G = A A^T):
+// all CG vectors are m-dimensional; per iteration one K^+ (five DCT sweeps), one scatter A^T p, one gather A v, two dense
+// G^-1 mat-vecs and one sparse (A K A^T) mat-vec.  The constant c drops out of phi after the shift (:110-111).
+// The single-workgroup kernels below do the m-vector algebra with device-resident scalars.
+// =================================================================================================
+constexpr int kDualBlock = 1024;
+
+__device__ __forceinline__ double block_sum_1024(double v, double* lds /* >= 17 doubles */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();  // protect lds reuse between consecutive calls
+    if (lane == 0) lds[w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.;
+        for (int a = 0; a < kDualBlock / kWave; a++) s += lds[a];
+        lds[16] = s;
+    }
+    __syncthreads();
+    return lds[16];
+}
+
+// w[node] (+)= sum_e coef * v[row]   (node-major lists; accumulate = 0: assignment, the touched set is fixed so the rest of w stays 0)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scatter_rows_to_nodes_kernel(int nnodes, const uint32_t* __restrict__ node_id, const int* __restrict__ node_ptr,
+                                                                       const int* __restrict__ ent_row, const double* __restrict__ ent_coef,
+                                                                       const double* __restrict__ v, int accumulate, T* __restrict__ w) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= nnodes) return;
+    double s = 0.;
+    for (int e = node_ptr[t]; e < node_ptr[t + 1]; e++) s += ent_coef[e] * v[ent_row[e]];
+    w[node_id[t]] = (T)((accumulate ? (double)w[node_id[t]] : 0.) + s);
+}
+
+// y = B x for the sparse m x m matrix B = A K A^T (CSR); one thread per row
+__global__ __launch_bounds__(kBlock) void csr_matvec_kernel(int m, const int* __restrict__ ptr, const int* __restrict__ col, const double* __restrict__ val,
+                                                            const double* __restrict__ x, double* __restrict__ y) {
+    const int r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= m) return;
+    double s = 0.;
+    for (int e = ptr[r]; e < ptr[r + 1]; e++) s += val[e] * x[col[e]];
+    y[r] = s;
+}
+
+// out = -in over the whole ghost-layout array (right-hand side A^T mu - b is completed by a scatter-accumulate)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void negate_kernel(size_t count, const T* __restrict__ in, T* __restrict__ out) {
+    for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < count; v += (size_t)gridDim.x * kBlock) out[v] = -in[v];
+}
+
+// partial sum of the owned entries of v
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sum_kernel(size_t nown, size_t off, const T* __restrict__ v, double* __restrict__ partials) {
+    __shared__ double red[8];
+    double acc = 0.;
+    for (size_t a = (size_t)blockIdx.x * kBlock + threadIdx.x; a < nown; a += (size_t)gridDim.x * kBlock) acc += (double)v[off + a];
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+// init: mu = (sum b / m) 1;  (called once; sumb = all-reduced sum of b in red0)
+__global__ __launch_bounds__(kDualBlock) void dual_init_mu_kernel(int m, const double* __restrict__ sumb, double* __restrict__ mu, double* __restrict__ sc) {
+    const double v = *sumb / (double)m;
+    for (int a = threadIdx.x; a < m; a += kDualBlock) mu[a] = v;
+    if (threadIdx.x == 0) sc[SC_SUMB] = *sumb;
+}
+
+// r = Pm(g - S mu)  with Smu given;  rr0 = r.r
+__global__ __launch_bounds__(kDualBlock) void dual_init_residual_kernel(int m, const double* __restrict__ g, const double* __restrict__ Smu,
+                                                                        double* __restrict__ r, double* __restrict__ sc) {
+    __shared__ double lds[17];
+    double s = 0.;
+    for (int a = threadIdx.x; a < m; a += kDualBlock) s += g[a] - Smu[a];
+    const double mean = block_sum_1024(s, lds) / (double)m;
+    double rr = 0.;
+    for (int a = threadIdx.x; a < m; a += kDualBlock) {
+        const double v = g[a] - Smu[a] - mean;
+        r[a] = v;
+        rr += v * v;
+    }
+    rr = block_sum_1024(rr, lds);
+    if (threadIdx.x == 0) {
+        sc[SC_RR] = rr;
+        sc[SC_RR0] = rr;
+    }
+}
+
+// z = Pm(z);  rz_new = r.z;  init: p = z, else p = z + (rz_new/rz) p;  rz = rz_new
+__global__ __launch_bounds__(kDualBlock) void dual_direction_kernel(int m, int init, const double* __restrict__ r, double* __restrict__ z,
+                                                                    double* __restrict__ p, double* __restrict__ sc) {
+    __shared__ double lds[17];
+    double s = 0.;
+    for (int a = threadIdx.x; a < m; a += kDualBlock) s += z[a];
+    const double mean = block_sum_1024(s, lds) / (double)m;
+    double rz = 0.;
+    for (int a = threadIdx.x; a < m; a += kDualBlock) {
+        const double v = z[a] - mean;
+        z[a] = v;
+        rz += r[a] * v;
+    }
+    rz = block_sum_1024(rz, lds);
+    const double beta = init ? 0. : rz / sc[SC_RZ];
+    for (int a = threadIdx.x; a < m; a += kDualBlock) p[a] = init ? z[a] : z[a] + beta * p[a];
+    __syncthreads();
+    if (threadIdx.x == 0) sc[SC_RZ] = rz;
+}
+
+// Sp = Pm(Sp);  alpha = rz / (p.Sp);  mu += alpha p;  r -= alpha Sp;  rr = r.r
+__global__ __launch_bounds__(kDualBlock) void dual_update_kernel(int m, const double* __restrict__ Sp, const double* __restrict__ p, double* __restrict__ mu,
+                                                                 double* __restrict__ r, double* __restrict__ sc) {
+    __shared__ double lds[17];
+    double s = 0.;
+    for (int a = threadIdx.x; a < m; a += kDualBlock) s += Sp[a];
+    const double mean = block_sum_1024(s, lds) / (double)m;
+    double pSp = 0.;
+    for (int a = threadIdx.x; a < m; a += kDualBlock) pSp += p[a] * (Sp[a] - mean);
+    pSp = block_sum_1024(pSp, lds);
+    const double alpha = sc[SC_RZ] / pSp;
+    double rr = 0.;
+    for (int a = threadIdx.x; a < m; a += kDualBlock) {
+        mu[a] += alpha * p[a];
+        const double v = r[a] - alpha * (Sp[a] - mean);
+        r[a] = v;
+        rr += v * v;
+    }
+    rr = block_sum_1024(rr, lds);
+    if (threadIdx.x == 0) sc[SC_RR] = rr;
 }
 
 // sum the per-slab reduction vectors of the slabs this process owns and write the result back to all of them

@@ -44,7 +44,7 @@ class _Grid(C.Structure):
 
 class _Opts(C.Structure):
     _fields_ = [("fast_integration", C.c_int32), ("scrub_nonfinite", C.c_int32), ("tol", C.c_double), ("max_iters", C.c_int32),
-                ("check_every", C.c_int32), ("preconditioner", C.c_int32)]
+                ("check_every", C.c_int32), ("preconditioner", C.c_int32), ("solver", C.c_int32)]
 
 
 class ShmStats(C.Structure):
@@ -53,7 +53,7 @@ class ShmStats(C.Structure):
                 ("ms_pcg", C.c_double), ("ms_shift", C.c_double), ("ms_total", C.c_double), ("ms_stencil_avg", C.c_double),
                 ("ms_update_xr_avg", C.c_double), ("ms_project_avg", C.c_double), ("ms_update_p_avg", C.c_double),
                 ("ms_precond_avg", C.c_double), ("kernel_samples", C.c_int32), ("preconditioner", C.c_int32),
-                ("bytes_per_iter", C.c_double)]
+                ("solver", C.c_int32), ("bytes_per_iter", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -170,8 +170,10 @@ class GridSolver:
 
     PRECOND = {"auto": 0, "none": 1, "dct": 2}
 
-    def solve(self, tol=0.0, max_iters=0, check_every=0, scrub=True, fast=False, allow_noconv=False, precond="auto"):
-        o = _Opts(int(fast), int(scrub), float(tol), int(max_iters), int(check_every), self.PRECOND[precond])
+    SOLVER = {"auto": 0, "primal": 1, "dual": 2}
+
+    def solve(self, tol=0.0, max_iters=0, check_every=0, scrub=True, fast=False, allow_noconv=False, precond="auto", solver="auto"):
+        o = _Opts(int(fast), int(scrub), float(tol), int(max_iters), int(check_every), self.PRECOND[precond], self.SOLVER[solver])
         st = ShmStats()
         self._chk(self._lib.shm_grid_solve(self._h, C.byref(o), C.byref(st)), allow=(5,) if allow_noconv else ())
         return st

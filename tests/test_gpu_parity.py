@@ -106,19 +106,29 @@ def test_preconditioner_is_the_dct_pseudo_inverse(shm, n):
     assert np.abs(-Lg - (v - v.mean())).max() < 1e-9 * np.abs(v).max()
 
 
-@pytest.mark.parametrize("precond", ["none", "dct"])
+MODES = {"primal-plain": dict(solver="primal", precond="none"), "primal-dct": dict(solver="primal", precond="dct"),
+         "dual": dict(solver="dual")}
+
+
+@pytest.mark.parametrize("mode", sorted(MODES))
 @pytest.mark.parametrize("case,scrub", [("bunny_small_n16", True), ("bunny_small_n24", True), ("bunny_small_n32", True),
                                         ("polygon_bear_n16", True), ("bunny_pc_n16", False), ("bunny_pc_n32", False)])
-def test_phi_matches_lu_golden(shm, case, scrub, precond):
+def test_phi_matches_lu_golden(shm, case, scrub, mode):
+    """All three solvers of the KKT system (plain projected CG, DCT-preconditioned projected CG, dual Schur-complement CG)
+    against the reference-equivalent sparse-LU solution."""
     d = load_golden(case)
-    if precond == "dct" and int(d["n"]) & (int(d["n"]) - 1):
+    kw = MODES[mode]
+    if mode != "primal-plain" and int(d["n"]) & (int(d["n"]) - 1):
         s = make_solver(shm, d)
-        with pytest.raises(shm.ShmError):          # n = 24 is not a power of two: explicit request must fail loudly
-            s.solve(tol=1e-10, scrub=scrub, precond="dct")
+        with pytest.raises(shm.ShmError):          # n = 24 is not a power of two: an explicit DCT request must fail loudly
+            s.solve(tol=1e-10, scrub=scrub, **kw)
+        st = s.solve(tol=1e-10, scrub=scrub)       # ... while AUTO falls back to the plain stencil CG
+        assert st.solver == 1 and st.preconditioner == 1
         return
     s = make_solver(shm, d)
-    st = s.solve(tol=1e-10, scrub=scrub, precond=precond)
-    assert st.preconditioner == (2 if precond == "dct" else 1)
+    st = s.solve(tol=1e-10, scrub=scrub, **kw)
+    assert st.solver == (2 if mode == "dual" else 1)
+    assert st.preconditioner == (1 if mode == "primal-plain" else 2)
     phi, (k0, k1) = s.get_phi()
     assert (k0, k1) == (0, int(d["n"]))
     err = np.abs(phi - d["phi"]).max()
@@ -138,17 +148,20 @@ def test_phi_default_tolerance_inside_gate(shm):
 def test_preconditioner_cuts_iterations(shm):
     d = load_golden("bunny_small_n32")
     s = make_solver(shm, d)
-    plain = s.solve(tol=1e-8, precond="none")
+    plain = s.solve(tol=1e-8, solver="primal", precond="none")
     phi0, _ = s.get_phi()
-    pre = s.solve(tol=1e-8, precond="dct")
+    pre = s.solve(tol=1e-8, solver="primal", precond="dct")
     phi1, _ = s.get_phi()
+    dual = s.solve(tol=1e-8, solver="dual")
+    phi2, _ = s.get_phi()
     assert pre.iters * 4 < plain.iters, (pre.iters, plain.iters)
-    assert np.abs(phi0 - phi1).max() < 1e-6
-    assert np.abs(phi1 - d["phi"]).max() < PHI_GATE
+    assert dual.iters <= pre.iters, (dual.iters, pre.iters)
+    assert np.abs(phi0 - phi1).max() < 1e-6 and np.abs(phi0 - phi2).max() < 1e-6
+    assert np.abs(phi1 - d["phi"]).max() < PHI_GATE and np.abs(phi2 - d["phi"]).max() < PHI_GATE
 
 
-@pytest.mark.parametrize("precond", ["none", "dct"])
-def test_phi_64_config_c1(shm, precond):
+@pytest.mark.parametrize("mode", sorted(MODES))
+def test_phi_64_config_c1(shm, mode):
     """BASELINE.json configs[0]: bunny_small.obj at 64^3 against the committed LU solution."""
     import os
     from conftest import GOLDEN
@@ -156,7 +169,7 @@ def test_phi_64_config_c1(shm, precond):
         pytest.skip("64^3 LU fixture not generated")
     d = load_golden("bunny_small_n64")
     s = make_solver(shm, d)
-    st = s.solve(tol=1e-9, precond=precond)
+    st = s.solve(tol=1e-9, **MODES[mode])
     phi, _ = s.get_phi()
     assert np.abs(phi - d["phi"]).max() < 1e-6, st.iters
 
@@ -177,16 +190,17 @@ def test_distributed_preconditioner_matches_single_slab(shm, slabs, n):
     assert np.abs(got - ref).max() < 1e-12 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("mode", ["primal-dct", "dual"])
 @pytest.mark.parametrize("slabs", [2, 4])
-def test_local_slabs_with_preconditioner(shm, slabs):
+def test_local_slabs_with_preconditioner(shm, slabs, mode):
     d = load_golden("bunny_small_n32")
     s = make_solver(shm, d, local_slabs=slabs)
-    st = s.solve(tol=1e-10, precond="dct")
+    st = s.solve(tol=1e-10, **MODES[mode])
     assert st.preconditioner == 2
     phi, _ = s.get_phi()
     assert np.abs(phi - d["phi"]).max() < 1e-7
     s1 = make_solver(shm, d)
-    st1 = s1.solve(tol=1e-10, precond="dct")
+    st1 = s1.solve(tol=1e-10, **MODES[mode])
     assert abs(st.iters - st1.iters) <= 4
 
 
@@ -238,13 +252,13 @@ def test_errors_are_reported(shm):
 
 # ---- fp32 path (BASELINE.json configs[2], configs[4]): "report only" in the north star; here: sanity bounds -----------
 @pytest.mark.parametrize("case", ["bunny_small_n16", "bunny_small_n32", "bunny_pc_n32"])
-@pytest.mark.parametrize("precond", ["none", "dct"])
-def test_fp32_path_tracks_fp64_oracle(shm, case, precond):
+@pytest.mark.parametrize("mode", sorted(MODES))
+def test_fp32_path_tracks_fp64_oracle(shm, case, mode):
     """fp32 storage/arithmetic with fp64 dot accumulators and the per-node exponent offset in Step 1 (SURVEY trap #4).
     Tolerance 2e-3 absolute on phi (range ~[-0.5, 4.6]): fp32 CG at kappa ~1e4..1e5 cannot do better."""
     d = load_golden(case)
     s = make_solver(shm, d, precision=shm.SHM_F32)
-    st = s.solve(scrub="pc" not in case, precond=precond, allow_noconv=True)
+    st = s.solve(scrub="pc" not in case, allow_noconv=True, **MODES[mode])
     phi, _ = s.get_phi()
     assert np.isfinite(phi).all()
     err = np.abs(phi - d["phi"]).max()
