@@ -193,8 +193,11 @@ struct Solver final : SolverBase {
     double bbox_min[3] = {0, 0, 0};
     int64_t S = 0;
     std::vector<double> h_pos, h_wn, h_area;
-    double src_center[3] = {0, 0, 0}, src_radius = 0., area_sum = 0.;
-    DevArray<T> d_src;  // [S][6]
+    double area_sum = 0., conv_far_gap = 0.;
+    int n_clusters = 0;
+    DevArray<T> d_src;          // [Spad][6] Morton-sorted, padded to whole clusters
+    DevArray<float> d_src32;    // same in fp32 (far clusters of the fp64 path)
+    DevArray<float> d_clusters; // [n_clusters][4] bounding spheres
     std::vector<Slab<T>> slabs;
     int total_slabs = 1, first_slab = 0;
     bool have_problem = false, have_conv = false, have_div = false, have_phi = false, have_constraints = false;
@@ -293,26 +296,85 @@ struct Solver final : SolverBase {
                 if (!(d >= 0.) || !(std::floor(d) + 1. <= (double)(n - 1)))
                     throw Error(SHM_ERR_INVALID, fmt("source %lld lies outside the grid cells", (long long)s));
             }
-        // bounding sphere of the sources (fp32 exponent offset) and total area
-        double c[3] = {0, 0, 0};
-        for (int64_t s = 0; s < S; s++)
-            for (int a = 0; a < 3; a++) c[a] += h_pos[3 * s + a];
-        for (int a = 0; a < 3; a++) src_center[a] = c[a] / (double)S;
-        src_radius = 0.;
         area_sum = 0.;
-        for (int64_t s = 0; s < S; s++) {
-            double d2 = 0.;
-            for (int a = 0; a < 3; a++) d2 += (h_pos[3 * s + a] - src_center[a]) * (h_pos[3 * s + a] - src_center[a]);
-            src_radius = std::max(src_radius, std::sqrt(d2));
-            area_sum += h_area[s];  // sequential like `normalization += A` (:477)
-        }
-        std::vector<T> packed((size_t)S * 6);
-        for (int64_t s = 0; s < S; s++)
-            for (int a = 0; a < 3; a++) {
-                packed[6 * s + a] = (T)h_pos[3 * s + a];
-                packed[6 * s + 3 + a] = (T)h_wn[3 * s + a];
+        for (int64_t s = 0; s < S; s++) area_sum += h_area[s];  // sequential like `normalization += A` (:477)
+        // Step-1 layout: sources sorted along a Morton curve and cut into clusters of kConvCluster with bounding spheres, so
+        // that a node tile can classify whole clusters as "far" (contribution < e^-25 of the tile's dominant term) and
+        // evaluate them in fp32; near clusters keep the reference's fp64 arithmetic.  Sum order differs from the
+        // reference's (a few ulp); constraint rows and the shift keep the original source order.
+        {
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            for (int64_t s = 0; s < S; s++)
+                for (int a = 0; a < 3; a++) {
+                    lo[a] = std::min(lo[a], h_pos[3 * s + a]);
+                    hi[a] = std::max(hi[a], h_pos[3 * s + a]);
+                }
+            const double ext = std::max({hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2], 1e-300});
+            auto spread = [](uint64_t v) {  // 21 bits -> every third bit
+                v &= 0x1fffff;
+                v = (v | v << 32) & 0x1f00000000ffffULL;
+                v = (v | v << 16) & 0x1f0000ff0000ffULL;
+                v = (v | v << 8) & 0x100f00f00f00f00fULL;
+                v = (v | v << 4) & 0x10c30c30c30c30c3ULL;
+                v = (v | v << 2) & 0x1249249249249249ULL;
+                return v;
+            };
+            std::vector<std::pair<uint64_t, int64_t>> order((size_t)S);
+            for (int64_t s = 0; s < S; s++) {
+                uint64_t code = 0;
+                for (int a = 0; a < 3; a++) {
+                    const uint64_t q = (uint64_t)std::min(1048575.0, std::max(0.0, (h_pos[3 * s + a] - lo[a]) / ext * 1048575.0));
+                    code |= spread(q) << a;
+                }
+                order[(size_t)s] = {code, s};
             }
-        d_src.upload(packed, stream);
+            std::sort(order.begin(), order.end());
+            n_clusters = (int)((S + kConvCluster - 1) / kConvCluster);
+            const int64_t Spad = (int64_t)n_clusters * kConvCluster;
+            std::vector<T> packed((size_t)Spad * 6, (T)0);
+            std::vector<float> packed32((size_t)Spad * 6, 0.f), cl((size_t)n_clusters * 4, 0.f);
+            double amin = 1e300, amax = 0.;
+            for (int64_t t = 0; t < Spad; t++) {
+                const int64_t s = order[(size_t)std::min<int64_t>(t, S - 1)].second;  // padding repeats the last source with zero weight
+                for (int a = 0; a < 3; a++) {
+                    packed[6 * t + a] = (T)h_pos[3 * s + a];
+                    packed32[6 * t + a] = (float)h_pos[3 * s + a];
+                    if (t < S) {
+                        packed[6 * t + 3 + a] = (T)h_wn[3 * s + a];
+                        packed32[6 * t + 3 + a] = (float)h_wn[3 * s + a];
+                    }
+                }
+            }
+            for (int64_t s = 0; s < S; s++) {
+                const double w = std::sqrt(h_wn[3 * s] * h_wn[3 * s] + h_wn[3 * s + 1] * h_wn[3 * s + 1] + h_wn[3 * s + 2] * h_wn[3 * s + 2]);
+                if (w > 0.) amin = std::min(amin, w);
+                amax = std::max(amax, w);
+            }
+            for (int c = 0; c < n_clusters; c++) {
+                double cc[3] = {0, 0, 0};
+                for (int e = 0; e < kConvCluster; e++)
+                    for (int a = 0; a < 3; a++) cc[a] += (double)packed[6 * ((size_t)c * kConvCluster + e) + a];
+                for (int a = 0; a < 3; a++) cc[a] /= kConvCluster;
+                double rad = 0.;
+                for (int e = 0; e < kConvCluster; e++) {
+                    double d2 = 0.;
+                    for (int a = 0; a < 3; a++) {
+                        const double d = (double)packed[6 * ((size_t)c * kConvCluster + e) + a] - cc[a];
+                        d2 += d * d;
+                    }
+                    rad = std::max(rad, std::sqrt(d2));
+                }
+                for (int a = 0; a < 3; a++) cl[4 * (size_t)c + a] = (float)cc[a];
+                cl[4 * (size_t)c + 3] = (float)(rad * 1.00001 + 1e-30);
+            }
+            // far when lambda * (d_lo - r_hi) > 25 + ln(Amax/Amin): the cluster's terms are below e^-25 ~ 1.4e-11 of the
+            // tile's dominant term, so their fp32 rounding (~1e-5 incl. the exponent) stays below 2e-16 of it
+            conv_far_gap = (25.0 + std::log(std::max(1.0, amax / std::max(amin, 1e-300)))) / lambda;
+            d_src.upload(packed, stream);
+            d_src32.upload(packed32, stream);
+            d_clusters.upload(cl, stream);
+            HIPCHK(hipStreamSynchronize(stream));
+        }
 
         vec = (n % vec_width<T>() == 0) ? vec_width<T>() : 1;
         slabs.clear();
@@ -365,14 +427,17 @@ struct Solver final : SolverBase {
             for (int a = 0; a < 3; a++) P.bbox_min[a] = bbox_min[a];
             P.cell = cell;
             P.lambda = lambda;
-            P.S = (int)S;
+            P.S = n_clusters * kConvCluster;
+            P.n_clusters = n_clusters;
+            P.far_gap = (float)conv_far_gap;
             P.exact_offset = (lambda * 14.0 * cell > 30.0) ? 1 : 0;  // tile-diameter bound looser than e^-30: per-node offsets
             P.tiles_x = (n + kConvTile - 1) / kConvTile;
             P.tiles_y = P.tiles_x;
             const int tiles_z = (P.kk_end - P.kk_begin + kConvTile - 1) / kConvTile;
             constexpr int NPT = 2;
             const unsigned grid = (unsigned)(P.tiles_x * P.tiles_y * tiles_z);
-            hipLaunchKernelGGL((conv_normalize_kernel<T, NPT>), dim3(grid), dim3(kBlock), 0, stream, P, d_src.p, sl.Y0.p, sl.Y1.p, sl.Y2.p);
+            hipLaunchKernelGGL((conv_normalize_kernel<T, NPT>), dim3(grid), dim3(kBlock), 0, stream, P, d_src.p, d_src32.p, d_clusters.p, sl.Y0.p, sl.Y1.p,
+                               sl.Y2.p);
         }
         HIPCHK(hipGetLastError());
         have_conv = true;
@@ -1063,6 +1128,8 @@ struct Solver final : SolverBase {
             hipLaunchKernelGGL((negate_kernel<T>), dim3(grid_for(sl.ntot, 4096)), dim3(kBlock), 0, stream, sl.ntot, sl.r.p, sl.q.p);
         scatter(V_MU, ARR_Q, 1);
         launch_precond(false, ARR_Q, ARR_X);
+        gather(ARR_X);  // A x0: constant over the rows at convergence; its mean is the KKT solution's additive constant
+        for (Slab<T>& sl : slabs) hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, stream, sl.red.p + 1, m, sl.sc.p + SC_AXSUM);
         e_pcg.record(stream);
         launch_shift_and_phi();
         e_end.record(stream);
@@ -1077,7 +1144,8 @@ struct Solver final : SolverBase {
             st->S = S;
             st->iters = it;
             st->rel_residual = std::sqrt(std::fabs(rr / rr0));
-            st->shift = h_pinned[SC_SHIFT];
+            // the reference shifts phi_ref = -x_kkt = -(x0 - mean(A x0)); report ITS shift: shift(-x0) + mean(A x0)
+            st->shift = h_pinned[SC_SHIFT] + h_pinned[SC_AXSUM] / (double)m;
             st->ms_conv = elapsed(e_start, e_conv);
             st->ms_div = elapsed(e_conv, e_div);
             HIPCHK(hipEventSynchronize(e_s2b.e));

@@ -116,22 +116,35 @@ struct ConvParams {
     double bbox_min[3];
     double cell;
     double lambda;
-    int S;
-    int exact_offset;   // fp32 only: 1 = per-node nearest-source distance (coarse grids: lambda * tile diameter too large)
+    int S;              // padded to whole clusters
+    int n_clusters;
+    float far_gap;      // fp64 path: a cluster is "far" when d_lo(tile, cluster) - r_hi(tile) > far_gap
+    int exact_offset;   // fp32 path only: 1 = per-node nearest-source distance (coarse grids: lambda * tile diameter too large)
 };
 
-constexpr int kConvTile = 8;  // 8x8x8 nodes per workgroup, 2 per lane
+constexpr int kConvTile = 8;      // 8x8x8 nodes per workgroup, 2 per lane
+constexpr int kConvCluster = 64;  // sources per cluster (Morton-sorted on the host)
+constexpr int kConvChunk = kSrcTile / kConvCluster;  // clusters per LDS fill
 
-// Workgroup = one compact 8x8x8 tile of nodes (2 per lane), so that a single exponent offset per workgroup is tight:
-//   T = float: d0 = max(0, min_s |c_tile - b_s| - r_tile) is a lower bound of every (node, source) distance of the tile and
-//   exceeds the true nearest distance by at most the tile diameter (lambda * 14h ~ 4), so exp(-lambda (r - d0)) of the
-//   nearest source never underflows; the common factor exp(lambda d0) cancels in X/|X|.
-//   T = double: d0 = 0 -- the reference's own arithmetic (fp64 underflows only beyond lambda r ~ 745).
+// Workgroup = one compact 8x8x8 tile of nodes (2 per lane); sources arrive as Morton-sorted clusters of 64 with bounding
+// spheres, staged through LDS 8 clusters at a time and broadcast-read by every lane.
+//   T = double: near clusters use the reference's fp64 arithmetic (no exponent offset).  A cluster whose every term is below
+//     e^-25 of the tile's dominant term (lower distance bound d_lo minus the tile's nearest-source upper bound r_hi exceeds
+//     far_gap) is evaluated in fp32 with the tile offset d0 and folded in as (double)f * exp(-lambda d0): its rounding error
+//     stays below 2e-16 of the sum.  The classification is uniform over the workgroup (no divergence).
+//   T = float: everything in fp32 with d0 = max(0, min_s |c_tile - b_s| - r_tile), a lower bound of every (node, source)
+//     distance that exceeds the nearest one by at most the tile diameter, so exp(-lambda (r - d0)) of the nearest source never
+//     underflows (SURVEY trap #4); the common factor exp(lambda d0) cancels in X/|X|.  Coarse grids (lambda * tile
+//     diameter > 30) take one extra sweep for exact per-node offsets.
 template <typename T, int NPT>
 __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, const T* __restrict__ src /* [S][6]: pos xyz, wn xyz */,
+                                                                const float* __restrict__ src32, const float* __restrict__ clusters,
                                                                 T* __restrict__ Y0, T* __restrict__ Y1, T* __restrict__ Y2) {
     static_assert(NPT * kBlock == kConvTile * kConvTile * kConvTile, "tile = NPT nodes per lane");
+    constexpr bool kMixed = sizeof(T) == 8;
     __shared__ T tile[kSrcTile * 6];
+    __shared__ float tile32[kMixed ? kSrcTile * 6 : 1];
+    __shared__ float cls[kConvChunk * 4];
     __shared__ float red[kBlock / kWave];
     const int n = P.n;
     const size_t plane = (size_t)n * n;
@@ -141,6 +154,7 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
     const int i0 = tx * kConvTile, j0 = ty * kConvTile, kk0 = P.kk_begin + tz * kConvTile;
 
     T px[NPT], py[NPT], pz[NPT], ax[NPT], ay[NPT], az[NPT];
+    float qx[NPT], qy[NPT], qz[NPT], fx[NPT], fy[NPT], fz[NPT];
     bool live[NPT];
     size_t vidx[NPT];
 #pragma unroll
@@ -152,16 +166,34 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
         vidx[e] = (size_t)kk * plane + (size_t)j * n + i;
         const int k = P.k0 + kk - 1;
         // indicesToNodePosition: (i,j,k)*cellSize + bboxMin, evaluated in double like the reference
-        px[e] = (T)(i * P.cell + P.bbox_min[0]);
-        py[e] = (T)(j * P.cell + P.bbox_min[1]);
-        pz[e] = (T)(k * P.cell + P.bbox_min[2]);
+        const double x = i * P.cell + P.bbox_min[0], y = j * P.cell + P.bbox_min[1], z = k * P.cell + P.bbox_min[2];
+        px[e] = (T)x; py[e] = (T)y; pz[e] = (T)z;
+        qx[e] = (float)x; qy[e] = (float)y; qz[e] = (float)z;
         ax[e] = ay[e] = az[e] = (T)0;
+        fx[e] = fy[e] = fz[e] = 0.f;
     }
+    // tile centre / circumscribed radius, then the workgroup-wide minimum distance from the centre to the sources
+    const float cx = (float)((i0 + 3.5) * P.cell + P.bbox_min[0]), cy = (float)((j0 + 3.5) * P.cell + P.bbox_min[1]);
+    const float cz = (float)((P.k0 + kk0 - 1 + 3.5) * P.cell + P.bbox_min[2]);
+    const float rt = (float)(3.5 * 1.7320508075688772 * P.cell) * 1.000001f;
+    float dmin = 3.0e38f;
+    for (int s = threadIdx.x; s < P.S; s += kBlock) {
+        const float dx = cx - (float)src[(size_t)s * 6], dy = cy - (float)src[(size_t)s * 6 + 1], dz = cz - (float)src[(size_t)s * 6 + 2];
+        dmin = fminf(dmin, dx * dx + dy * dy + dz * dz);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, off, kWave));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dmin;
+    __syncthreads();
+    dmin = sqrtf(fminf(fminf(red[0], red[1]), fminf(red[2], red[3])));
+    const float r_hi = dmin * 1.000001f + rt;                   // every node of the tile has a source at most this far
+    const float d0t = fmaxf(0.f, dmin * 0.999999f - rt);        // no source is closer than this to any node of the tile
+
     T d0[NPT];
 #pragma unroll
-    for (int e = 0; e < NPT; e++) d0[e] = (T)0;
-    if (sizeof(T) == 4 && P.exact_offset) {
-        // coarse grid: one extra sweep over the sources for the exact nearest distance of every node
+    for (int e = 0; e < NPT; e++) d0[e] = kMixed ? (T)0 : (T)d0t;
+    if (!kMixed && P.exact_offset) {
+        // coarse grid, fp32 solve: one extra sweep over the sources for the exact nearest distance of every node
         float m2[NPT];
 #pragma unroll
         for (int e = 0; e < NPT; e++) m2[e] = 3.0e38f;
@@ -173,50 +205,71 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
             for (int s = 0; s < cnt; s++) {
 #pragma unroll
                 for (int e = 0; e < NPT; e++) {
-                    const float dx = (float)px[e] - (float)tile[6 * s], dy = (float)py[e] - (float)tile[6 * s + 1], dz = (float)pz[e] - (float)tile[6 * s + 2];
+                    const float dx = qx[e] - (float)tile[6 * s], dy = qy[e] - (float)tile[6 * s + 1], dz = qz[e] - (float)tile[6 * s + 2];
                     m2[e] = fminf(m2[e], dx * dx + dy * dy + dz * dz);
                 }
             }
         }
 #pragma unroll
         for (int e = 0; e < NPT; e++) d0[e] = (T)(sqrtf(m2[e]) * 0.99999f);
-    } else if (sizeof(T) == 4) {
-        // tile centre / circumscribed radius, then the block-wide minimum distance to the sources
-        const float cx = (float)((i0 + 3.5) * P.cell + P.bbox_min[0]), cy = (float)((j0 + 3.5) * P.cell + P.bbox_min[1]);
-        const float cz = (float)((P.k0 + kk0 - 1 + 3.5) * P.cell + P.bbox_min[2]);
-        const float rt = (float)(3.5 * 1.7320508075688772 * P.cell);
-        float dmin = 3.0e38f;
-        for (int s = threadIdx.x; s < P.S; s += kBlock) {
-            const float dx = cx - (float)src[(size_t)s * 6], dy = cy - (float)src[(size_t)s * 6 + 1], dz = cz - (float)src[(size_t)s * 6 + 2];
-            dmin = fminf(dmin, dx * dx + dy * dy + dz * dz);
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, off, kWave));
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dmin;
-        __syncthreads();
-        dmin = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
-        const T d0t = (T)fmaxf(0.f, sqrtf(dmin) * 0.999999f - rt * 1.000001f);
-#pragma unroll
-        for (int e = 0; e < NPT; e++) d0[e] = d0t;
     }
     const T lam = (T)P.lambda;
-    for (int s0 = 0; s0 < P.S; s0 += kSrcTile) {
-        const int cnt = min(kSrcTile, P.S - s0);
+    const float lamf = (float)P.lambda;
+    for (int c0 = 0; c0 < P.n_clusters; c0 += kConvChunk) {
+        const int ncl = min(kConvChunk, P.n_clusters - c0);
+        const int cnt = ncl * kConvCluster;
         __syncthreads();
-        for (int a = threadIdx.x; a < cnt * 6; a += kBlock) tile[a] = src[(size_t)s0 * 6 + a];
+        for (int a = threadIdx.x; a < cnt * 6; a += kBlock) {
+            tile[a] = src[(size_t)c0 * kConvCluster * 6 + a];
+            if (kMixed) tile32[a] = src32[(size_t)c0 * kConvCluster * 6 + a];
+        }
+        if ((int)threadIdx.x < ncl * 4) cls[threadIdx.x] = clusters[(size_t)c0 * 4 + threadIdx.x];
         __syncthreads();
-#pragma unroll 2
-        for (int s = 0; s < cnt; s++) {
-            const T sx = tile[6 * s], sy = tile[6 * s + 1], sz = tile[6 * s + 2];
-            const T wx = tile[6 * s + 3], wy = tile[6 * s + 4], wz = tile[6 * s + 5];
-#pragma unroll
-            for (int e = 0; e < NPT; e++) {
-                const T dx = px[e] - sx, dy = py[e] - sy, dz = pz[e] - sz;
-                T r, rinv;
-                YukawaMath<T>::rsqrt_and_sqrt(dx * dx + dy * dy + dz * dz, rinv, r);
-                const T g = YukawaMath<T>::exp_neg(-lam * (r - d0[e])) * rinv;   // r = 0 -> NaN, like exp(0)/0 = inf -> NaN after normalise
-                ax[e] += wx * g; ay[e] += wy * g; az[e] += wz * g;
+        for (int c = 0; c < ncl; c++) {
+            bool far = false;
+            if (kMixed) {
+                const float dx = cx - cls[4 * c], dy = cy - cls[4 * c + 1], dz = cz - cls[4 * c + 2];
+                const float dlo = sqrtf(dx * dx + dy * dy + dz * dz) * 0.999999f - rt - cls[4 * c + 3];
+                far = (dlo - r_hi) > P.far_gap;   // identical in every lane: a workgroup-uniform branch
             }
+            if (far) {
+#pragma unroll 2
+                for (int s = c * kConvCluster; s < (c + 1) * kConvCluster; s++) {
+                    const float sx = tile32[6 * s], sy = tile32[6 * s + 1], sz = tile32[6 * s + 2];
+                    const float wx = tile32[6 * s + 3], wy = tile32[6 * s + 4], wz = tile32[6 * s + 5];
+#pragma unroll
+                    for (int e = 0; e < NPT; e++) {
+                        const float dx = qx[e] - sx, dy = qy[e] - sy, dz = qz[e] - sz;
+                        float r, rinv;
+                        YukawaMath<float>::rsqrt_and_sqrt(dx * dx + dy * dy + dz * dz, rinv, r);
+                        const float g = YukawaMath<float>::exp_neg(-lamf * (r - d0t)) * rinv;
+                        fx[e] += wx * g; fy[e] += wy * g; fz[e] += wz * g;
+                    }
+                }
+            } else {
+#pragma unroll 2
+                for (int s = c * kConvCluster; s < (c + 1) * kConvCluster; s++) {
+                    const T sx = tile[6 * s], sy = tile[6 * s + 1], sz = tile[6 * s + 2];
+                    const T wx = tile[6 * s + 3], wy = tile[6 * s + 4], wz = tile[6 * s + 5];
+#pragma unroll
+                    for (int e = 0; e < NPT; e++) {
+                        const T dx = px[e] - sx, dy = py[e] - sy, dz = pz[e] - sz;
+                        T r, rinv;
+                        YukawaMath<T>::rsqrt_and_sqrt(dx * dx + dy * dy + dz * dz, rinv, r);
+                        const T g = YukawaMath<T>::exp_neg(-lam * (r - d0[e])) * rinv;   // r = 0 -> NaN, like exp(0)/0 = inf -> NaN after normalise
+                        ax[e] += wx * g; ay[e] += wy * g; az[e] += wz * g;
+                    }
+                }
+            }
+        }
+    }
+    if (kMixed) {
+        const double e0 = YukawaMath<double>::exp_neg(-P.lambda * (double)d0t);
+#pragma unroll
+        for (int e = 0; e < NPT; e++) {
+            ax[e] += (T)((double)fx[e] * e0);
+            ay[e] += (T)((double)fy[e] * e0);
+            az[e] += (T)((double)fz[e] * e0);
         }
     }
 #pragma unroll
@@ -395,6 +448,7 @@ enum Scalar : int {
     SC_RR0 = 7,    // ||P b||^2
     SC_RZ = 8,     // dual solver: r.z of the current iteration
     SC_SUMB = 9,   // dual solver: sum of the right-hand side b (compatibility condition sum(mu) = sum(b))
+    SC_AXSUM = 10, // dual solver: sum_i (A x0)_i  (x_kkt = x0 - mean(A x0): the constant that the shift absorbs)
     SC_COUNT = 16
 };
 // red[] layout (the all-reduced vector): red[0] = scalar partial sum, red[1..m] = w = A r'

@@ -29,6 +29,25 @@ def test_conv_normalize_matches_golden(shm, case):
     assert np.abs(np.linalg.norm(Y, axis=1) - 1).max() < 1e-14
 
 
+@pytest.mark.parametrize("lam_scale,n", [(4.0, 32), (16.0, 24)])
+def test_conv_far_clusters_in_fp32_keep_fp64_accuracy(shm, oracle_c, lam_scale, n):
+    """With a short diffusion length most source clusters are "far" for most node tiles and take the fp32 branch of the
+    fp64 kernel; the normalised field must still agree with the all-fp64 C oracle to rounding."""
+    d = load_golden("bunny_small_n16")
+    lam = float(d["lam"]) * lam_scale
+    cell = float(d["cell"]) * 15 / (n - 1)
+    s = shm.GridSolver()
+    s.set_problem(d["pos"], d["wnormal"], d["area"], lam, n, d["bbox_min"], cell)
+    s.run_conv()
+    Y = np.stack([s.get_field(k) for k in (0, 1, 2)], axis=1)
+    ref = np.zeros(3 * n ** 3)
+    oracle_c.shmo_conv_normalize(n, c_(d["bbox_min"]), cell, len(d["area"]), c_(d["pos"]).reshape(-1), c_(d["wnormal"]).reshape(-1), lam, 0, n, ref)
+    ref = ref.reshape(-1, 3)
+    ok = np.isfinite(ref).all(axis=1)
+    assert ok.mean() > 0.99
+    assert np.abs(Y[ok] - ref[ok]).max() < 1e-10
+
+
 @pytest.mark.parametrize("case,scrub", [("bunny_small_n16", True), ("bunny_small_n32", True), ("bunny_pc_n32", False)])
 def test_divergence_matches_golden(shm, case, scrub):
     d = load_golden(case)
