@@ -228,7 +228,7 @@ def main():
                          "note": "achieved = algorithmic bytes per launch / avg launch duration (HIP events on the solver stream, "
                                  "%d sampled launches per solve)" % int(avg["kernel_samples"])},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only (the extra plain-CG solve below is a collective at N>1)
             try:
                 st_plain = solver.solve(tol=args.tol, scrub=scrub, solver="primal", precond="none")  # untimed: iteration count of the port's algorithm
                 out["cpu_baseline"] = cpu_baseline(pre, int(st_plain.iters), out["config"]["tol"])
