@@ -942,55 +942,64 @@ __global__ __launch_bounds__(kBlock) void gj_panels_kernel(const double* __restr
         double s = 0.;
 #pragma unroll 8
         for (int k = 0; k < kGJ; k++) s += p[i][k] * g[k][j];
-        R[(size_t)i * ld + ob + j] = s;
+        R[(size_t)i * ld + ob + j] = (b == kb) ? p[i][j] : s;  // the pivot block column of R carries P: G[:,kb] = -C P, G[kb,kb] = P
     }
 }
 
-// step 3+4: 64x64 output tile per block, 4x4 outputs per thread, K = 64 through LDS.
-__global__ __launch_bounds__(kBlock) void gj_update_kernel(double* __restrict__ G, int ld, int kb, const double* __restrict__ P,
-                                                           const double* __restrict__ R, const double* __restrict__ C) {
-    __shared__ double cs[kGJ][kGJ + 1];  // C tile  [i][k]
-    __shared__ double rs[kGJ][kGJ + 1];  // R tile  [k][j]  (or P for the column-panel rewrite)
-    const int ib = blockIdx.y, jb = blockIdx.x;
-    const size_t oi = (size_t)ib * kGJ, oj = (size_t)jb * kGJ;
-    const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
-    if (ib == kb && jb == kb) {  // G[kb,kb] = P
-        for (int t = threadIdx.x; t < kGJ * kGJ; t += kBlock) G[(oi + t / kGJ) * ld + oj + t % kGJ] = P[t];
-        return;
-    }
-    if (ib == kb) {  // G[kb, jb] = R
-        for (int t = threadIdx.x; t < kGJ * kGJ; t += kBlock) G[(oi + t / kGJ) * ld + oj + t % kGJ] = R[(size_t)(t / kGJ) * ld + oj + t % kGJ];
-        return;
-    }
-    for (int t = threadIdx.x; t < kGJ * kGJ; t += kBlock) {
-        const int i = t / kGJ, j = t % kGJ;
-        cs[i][j] = C[(oi + i) * kGJ + j];
-        rs[i][j] = (jb == kb) ? P[t] : R[(size_t)i * ld + oj + j];
-    }
-    __syncthreads();
-    double acc[4][4];
+// step 3+4: rank-64 update  G[i,j] -= C[i,:] R[:,j]  with the pivot row / column rewritten on the fly:
+//   rows of the pivot block:     G[kb, j] = R[:, j]        (R's own pivot block column holds P, so G[kb,kb] = P)
+//   columns of the pivot block:  G[i, kb] = -C[i,:] P
+// 128x128 output tile per workgroup, 8x8 outputs per lane (64 FMA per 8 LDS b128 reads), K = 64 in two chunks of 32
+// through LDS (C transposed on the way in so that a lane's 8 row values are contiguous).
+constexpr int kGJTile = 128, kGJK = 32, kGJPad = kGJTile + 2;
+__global__ __launch_bounds__(kBlock) void gj_update_kernel(double* __restrict__ G, int ld, int kb, const double* __restrict__ R,
+                                                           const double* __restrict__ C) {
+    __shared__ __attribute__((aligned(16))) double cs[kGJK][kGJPad];  // C chunk  [k][i]
+    __shared__ __attribute__((aligned(16))) double rs[kGJK][kGJPad];  // R chunk  [k][j]
+    const size_t oi = (size_t)blockIdx.y * kGJTile, oj = (size_t)blockIdx.x * kGJTile;
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    double acc[8][8];
 #pragma unroll
-    for (int a = 0; a < 4; a++)
+    for (int a = 0; a < 8; a++)
 #pragma unroll
-        for (int b = 0; b < 4; b++) acc[a][b] = 0.;
+        for (int b = 0; b < 8; b++) acc[a][b] = 0.;
+    for (int kc = 0; kc < kGJ; kc += kGJK) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < kGJTile * kGJK; t += kBlock) {
+            const int k = t & (kGJK - 1), i = t >> 5;            // C is [ld][64]: 32 consecutive k per row segment
+            cs[k][i] = (oi + i < (size_t)ld) ? C[(oi + i) * kGJ + kc + k] : 0.;
+            const int j = t & (kGJTile - 1), k2 = t >> 7;        // R is [64][ld]: 128 consecutive j per row segment
+            rs[k2][j] = (oj + j < (size_t)ld) ? R[(size_t)(kc + k2) * ld + oj + j] : 0.;
+        }
+        __syncthreads();
 #pragma unroll 4
-    for (int k = 0; k < kGJ; k++) {
-        double cv[4], rv[4];
+        for (int k = 0; k < kGJK; k++) {
+            double cv[8], rv[8];
 #pragma unroll
-        for (int a = 0; a < 4; a++) cv[a] = cs[ty * 4 + a][k];
+            for (int a = 0; a < 8; a += 2) {
+                const double2 t2 = *reinterpret_cast<const double2*>(&cs[k][ty * 8 + a]);
+                cv[a] = t2.x; cv[a + 1] = t2.y;
+                const double2 u2 = *reinterpret_cast<const double2*>(&rs[k][tx * 8 + a]);
+                rv[a] = u2.x; rv[a + 1] = u2.y;
+            }
 #pragma unroll
-        for (int b = 0; b < 4; b++) rv[b] = rs[k][tx * 4 + b];
+            for (int a = 0; a < 8; a++)
 #pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) acc[a][b] += cv[a] * rv[b];
+                for (int b = 0; b < 8; b++) acc[a][b] += cv[a] * rv[b];
+        }
     }
+    const size_t row0 = oi + ty * 8, col0 = oj + tx * 8;
+    if (row0 >= (size_t)ld || col0 >= (size_t)ld) return;
+    const bool prow = (int)(row0 / kGJ) == kb, pcol = (int)(col0 / kGJ) == kb;  // an 8x8 block never straddles a 64-block
+    const size_t o = (size_t)kb * kGJ;
 #pragma unroll
-    for (int a = 0; a < 4; a++)
+    for (int a = 0; a < 8; a++)
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            double* dst = &G[(oi + ty * 4 + a) * ld + oj + tx * 4 + b];
-            *dst = (jb == kb) ? -acc[a][b] : (*dst - acc[a][b]);
+        for (int b = 0; b < 8; b++) {
+            double* dst = &G[(row0 + a) * ld + col0 + b];
+            if (prow) *dst = R[(row0 + a - o) * ld + col0 + b];
+            else if (pcol) *dst = -acc[a][b];
+            else *dst -= acc[a][b];
         }
 }
 
