@@ -678,7 +678,7 @@ struct Solver final : SolverBase {
 
     void invert_G() {
         hipStream_t stream = stream2;
-        const int nb = mp / kGJ, nt = (mp + kGJTile - 1) / kGJTile;
+        const int nb = mp / kGJ;
         gjP.alloc(kGJ * kGJ);
         gjR.alloc((size_t)kGJ * mp);
         gjC.alloc((size_t)mp * kGJ);
@@ -687,7 +687,7 @@ struct Solver final : SolverBase {
         for (int kb = 0; kb < nb; kb++) {
             hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjP.p, gjFlag.p);
             hipLaunchKernelGGL(gj_panels_kernel, dim3(nb), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjP.p, gjR.p, gjC.p);
-            hipLaunchKernelGGL(gj_update_kernel, dim3(nt, nt), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjR.p, gjC.p);
+            hipLaunchKernelGGL(gj_update_kernel, dim3(nb, nb), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjR.p, gjC.p);
         }
         HIPCHK(hipGetLastError());
         int flag = 0;

@@ -949,58 +949,61 @@ __global__ __launch_bounds__(kBlock) void gj_panels_kernel(const double* __restr
 // step 3+4: rank-64 update  G[i,j] -= C[i,:] R[:,j]  with the pivot row / column rewritten on the fly:
 //   rows of the pivot block:     G[kb, j] = R[:, j]        (R's own pivot block column holds P, so G[kb,kb] = P)
 //   columns of the pivot block:  G[i, kb] = -C[i,:] P
-// 128x128 output tile per workgroup, 8x8 outputs per lane (64 FMA per 8 LDS b128 reads), K = 64 in two chunks of 32
-// through LDS (C transposed on the way in so that a lane's 8 row values are contiguous).
-constexpr int kGJTile = 128, kGJK = 32, kGJPad = kGJTile + 2;
+// Dense fp64 GEMM -> matrix cores: v_mfma_f64_16x16x4_f64.  64x64 output tile per workgroup, one 32x32 quadrant per wave
+// (2x2 accumulators of 16x16), K = 64 in two LDS chunks of 32.  Operand layout (one f64 per lane):
+//   A[i = lane&15][k = lane>>4],  B[k = lane>>4][j = lane&15],  D: col = lane&15, row = (lane>>4) + 4*reg.
+typedef double gj_f64x4 __attribute__((ext_vector_type(4)));
+constexpr int kGJK = 32;
 __global__ __launch_bounds__(kBlock) void gj_update_kernel(double* __restrict__ G, int ld, int kb, const double* __restrict__ R,
                                                            const double* __restrict__ C) {
-    __shared__ __attribute__((aligned(16))) double cs[kGJK][kGJPad];  // C chunk  [k][i]
-    __shared__ __attribute__((aligned(16))) double rs[kGJK][kGJPad];  // R chunk  [k][j]
-    const size_t oi = (size_t)blockIdx.y * kGJTile, oj = (size_t)blockIdx.x * kGJTile;
-    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-    double acc[8][8];
+    __shared__ double cs[kGJ][kGJK + 1];  // C chunk  [i][k]
+    __shared__ double rs[kGJK][kGJ + 1];  // R chunk  [k][j]
+    const size_t oi = (size_t)blockIdx.y * kGJ, oj = (size_t)blockIdx.x * kGJ;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    gj_f64x4 acc[2][2];
 #pragma unroll
-    for (int a = 0; a < 8; a++)
+    for (int a = 0; a < 2; a++)
 #pragma unroll
-        for (int b = 0; b < 8; b++) acc[a][b] = 0.;
+        for (int b = 0; b < 2; b++) acc[a][b] = gj_f64x4{0., 0., 0., 0.};
     for (int kc = 0; kc < kGJ; kc += kGJK) {
         __syncthreads();
-        for (int t = threadIdx.x; t < kGJTile * kGJK; t += kBlock) {
-            const int k = t & (kGJK - 1), i = t >> 5;            // C is [ld][64]: 32 consecutive k per row segment
-            cs[k][i] = (oi + i < (size_t)ld) ? C[(oi + i) * kGJ + kc + k] : 0.;
-            const int j = t & (kGJTile - 1), k2 = t >> 7;        // R is [64][ld]: 128 consecutive j per row segment
-            rs[k2][j] = (oj + j < (size_t)ld) ? R[(size_t)(kc + k2) * ld + oj + j] : 0.;
+        for (int t = threadIdx.x; t < kGJ * kGJK; t += kBlock) {
+            const int k = t & (kGJK - 1), i = t >> 5;   // C is [ld][64]: 32 consecutive k per row segment
+            cs[i][k] = C[(oi + i) * kGJ + kc + k];
+            const int j = t & (kGJ - 1), k2 = t >> 6;   // R is [64][ld]: 64 consecutive j per row segment
+            rs[k2][j] = R[(size_t)(kc + k2) * ld + oj + j];
         }
         __syncthreads();
-#pragma unroll 4
-        for (int k = 0; k < kGJK; k++) {
-            double cv[8], rv[8];
 #pragma unroll
-            for (int a = 0; a < 8; a += 2) {
-                const double2 t2 = *reinterpret_cast<const double2*>(&cs[k][ty * 8 + a]);
-                cv[a] = t2.x; cv[a + 1] = t2.y;
-                const double2 u2 = *reinterpret_cast<const double2*>(&rs[k][tx * 8 + a]);
-                rv[a] = u2.x; rv[a + 1] = u2.y;
-            }
+        for (int k0 = 0; k0 < kGJK; k0 += 4) {
+            double af[2], bf[2];
 #pragma unroll
-            for (int a = 0; a < 8; a++)
+            for (int a = 0; a < 2; a++) af[a] = cs[wr * 32 + a * 16 + l15][k0 + l4];
 #pragma unroll
-                for (int b = 0; b < 8; b++) acc[a][b] += cv[a] * rv[b];
+            for (int b = 0; b < 2; b++) bf[b] = rs[k0 + l4][wc * 32 + b * 16 + l15];
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
     }
-    const size_t row0 = oi + ty * 8, col0 = oj + tx * 8;
-    if (row0 >= (size_t)ld || col0 >= (size_t)ld) return;
-    const bool prow = (int)(row0 / kGJ) == kb, pcol = (int)(col0 / kGJ) == kb;  // an 8x8 block never straddles a 64-block
+    const bool prow = (int)blockIdx.y == kb, pcol = (int)blockIdx.x == kb;
     const size_t o = (size_t)kb * kGJ;
 #pragma unroll
-    for (int a = 0; a < 8; a++)
+    for (int a = 0; a < 2; a++)
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
-            double* dst = &G[(row0 + a) * ld + col0 + b];
-            if (prow) *dst = R[(row0 + a - o) * ld + col0 + b];
-            else if (pcol) *dst = -acc[a][b];
-            else *dst -= acc[a][b];
-        }
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const size_t row = oi + wr * 32 + a * 16 + l4 + 4 * r, col = oj + wc * 32 + b * 16 + l15;
+                double* dst = &G[row * ld + col];
+                const double v = acc[a][b][r];
+                if (prow) *dst = R[(row - o) * ld + col];
+                else if (pcol) *dst = -v;
+                else *dst -= v;
+            }
 }
 
 }  // namespace shm
