@@ -74,6 +74,23 @@ template <> struct YukawaMath<double> {
         r = g;
         rinv = h + h;
     }
+    // exp(x) for x <= 0: x = (64 k + j) ln2/64 + f, |f| <= ln2/128; exp(x) = 2^k * T[j] * P5(f) with T[j] = 2^(j/64) from a
+    // 512-byte LDS table (the LDS pipe is otherwise idle in this kernel) and a degree-5 Taylor polynomial (truncation 4e-17).
+    static __device__ __forceinline__ double exp_neg(double x, const double* __restrict__ tab /* LDS: 2^(j/64), j < 64 */) {
+        const double kf = rint(x * 92.33248261689366);               // 64 / ln2
+        double f = fma(kf, -0.010830424695086549, x);                // ln2/64, high part (20 trailing zero bits: kf*hi is exact)
+        f = fma(kf, -1.162596423439437e-12, f);                      // ln2/64, low part
+        const int ki = (int)kf;
+        const double t = tab[ki & 63];
+        double p = 8.3333333333333332e-03;                           // 1/120
+        p = fma(p, f, 4.1666666666666664e-02);
+        p = fma(p, f, 1.6666666666666666e-01);
+        p = fma(p, f, 0.5);
+        p = fma(p, f, 1.0);
+        p = fma(p, f, 1.0);
+        return __builtin_amdgcn_ldexp(t * p, ki >> 6);
+    }
+    // table-free variant (range reduction by ln2 + degree-13 polynomial): the tile epilogue and tests
     static __device__ __forceinline__ double exp_neg(double x) {
         const double kf = rint(x * 1.4426950408889634074);
         double f = fma(kf, -6.93147180369123816490e-01, x);
@@ -102,6 +119,7 @@ template <> struct YukawaMath<float> {
         rinv = y0;
     }
     static __device__ __forceinline__ float exp_neg(float x) { return __expf(x); }
+    static __device__ __forceinline__ float exp_neg(float x, const double*) { return __expf(x); }
 };
 template <typename T> __device__ __forceinline__ T t_sqrt(T x);
 template <> __device__ __forceinline__ double t_sqrt<double>(double x) { return sqrt(x); }
@@ -146,6 +164,8 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
     __shared__ float tile32[kMixed ? kSrcTile * 6 : 1];
     __shared__ float cls[kConvChunk * 4];
     __shared__ float red[kBlock / kWave];
+    __shared__ double exp_tab[64];
+    if (kMixed && threadIdx.x < 64) exp_tab[threadIdx.x] = exp2((double)threadIdx.x * 0.015625);  // correctly rounded 2^(j/64)
     const int n = P.n;
     const size_t plane = (size_t)n * n;
     const int bt = blockIdx.x;
@@ -256,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
                         const T dx = px[e] - sx, dy = py[e] - sy, dz = pz[e] - sz;
                         T r, rinv;
                         YukawaMath<T>::rsqrt_and_sqrt(dx * dx + dy * dy + dz * dz, rinv, r);
-                        const T g = YukawaMath<T>::exp_neg(-lam * (r - d0[e])) * rinv;   // r = 0 -> NaN, like exp(0)/0 = inf -> NaN after normalise
+                        const T g = YukawaMath<T>::exp_neg(-lam * (r - d0[e]), exp_tab) * rinv;   // r = 0 -> NaN, like exp(0)/0 = inf -> NaN after normalise
                         ax[e] += wx * g; ay[e] += wy * g; az[e] += wz * g;
                     }
                 }
