@@ -77,10 +77,12 @@ template <> struct YukawaMath<double> {
     // exp(x) for x <= 0: x = (64 k + j) ln2/64 + f, |f| <= ln2/128; exp(x) = 2^k * T[j] * P5(f) with T[j] = 2^(j/64) from a
     // 512-byte LDS table (the LDS pipe is otherwise idle in this kernel) and a degree-5 Taylor polynomial (truncation 4e-17).
     static __device__ __forceinline__ double exp_neg(double x, const double* __restrict__ tab /* LDS: 2^(j/64), j < 64 */) {
-        const double kf = rint(x * 92.33248261689366);               // 64 / ln2
+        // round-to-nearest by the 1.5*2^52 trick: the integer lands in the low mantissa bits (no v_rndne / v_cvt)
+        const double tm = fma(x, 92.33248261689366, 6755399441055744.0);   // 64/ln2 ; 1.5 * 2^52
+        const double kf = tm - 6755399441055744.0;
+        const int ki = (int)(unsigned)__double_as_longlong(tm);
         double f = fma(kf, -0.010830424695086549, x);                // ln2/64, high part (20 trailing zero bits: kf*hi is exact)
         f = fma(kf, -1.162596423439437e-12, f);                      // ln2/64, low part
-        const int ki = (int)kf;
         const double t = tab[ki & 63];
         double p = 8.3333333333333332e-03;                           // 1/120
         p = fma(p, f, 4.1666666666666664e-02);
