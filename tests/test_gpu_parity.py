@@ -346,3 +346,68 @@ def test_rccl_single_rank_communicator(shm):
     st = s.solve(tol=1e-10)
     phi, _ = s.get_phi()
     assert np.abs(phi - d["phi"]).max() < 1e-7
+
+
+# ---- BASELINE.json's full size (configs[1]: bunny_small.obj, 256^3, fp64): size-independent properties -------------------
+@pytest.fixture(scope="module")
+def full_size(shm):
+    import os
+    from conftest import ROOT
+    from signed_heat_3d_amd.host_abi import HostSolver
+    pre = HostSolver(os.path.join(ROOT, "data", "bunny_small.obj")).preprocess(hCoef=4.0)
+    s = shm.GridSolver()
+    s.set_problem(pre["pos"], pre["wnormal"], pre["area"], pre["lam"], pre["n"], pre["bbox_min"], pre["cell"])
+    s.run_conv()
+    s.run_divergence(True)
+    b = s.get_field(s.FIELD_DIV)
+    st = s.solve()                      # library defaults: dual solver, tol 1e-8
+    phi, _ = s.get_phi()
+    return dict(pre=pre, solver=s, b=b, phi=phi, stats=st)
+
+
+def test_full_size_kkt_stationarity(full_size):
+    """L x + A^T mu = b with x = -phi (:101-108): away from the <= 8m nodes touched by constraint rows the residual
+    L phi + b must vanish; on the touched nodes it is A^T mu.  Uses the independent laplacian_kernel."""
+    f = full_size
+    s, phi, b = f["solver"], f["phi"], f["b"]
+    g = s.apply_laplacian(phi) + b
+    nodes, coeffs = s.get_constraints()
+    touched = np.zeros(phi.size, dtype=bool)
+    touched[nodes.ravel()] = True
+    assert f["stats"].m == nodes.shape[0] == 2842
+    scale = np.abs(b).max()
+    assert np.abs(g[~touched]).max() < 1e-6 * scale
+    assert np.abs(g[touched]).max() > 1e-3 * scale          # the multipliers are not trivially zero
+
+
+def test_full_size_constraints_and_shift(full_size):
+    """A x = 0 up to the common constant absorbed by the shift: all rows of A phi agree; and the area-weighted mean of the
+    trilinear interpolant of phi over ALL sources is zero (:110-111, :466-481)."""
+    f = full_size
+    s, phi, pre = f["solver"], f["phi"], f["pre"]
+    nodes, coeffs = s.get_constraints()
+    rows = (coeffs * phi[nodes]).sum(axis=1)
+    assert rows.max() - rows.min() < 1e-8
+    n, h, b0 = pre["n"], pre["cell"], pre["bbox_min"]
+    t = (pre["pos"] - b0) / h
+    ijk = np.floor(t).astype(np.int64)
+    tx, ty, tz = ((pre["pos"][:, a] - (ijk[:, a] * h + b0[a])) / h for a in range(3))
+    at = lambda di, dj, dk: phi[(ijk[:, 0] + di) + (ijk[:, 1] + dj) * n + (ijk[:, 2] + dk) * n * n]  # noqa: E731
+    v00 = at(0, 0, 0) * (1 - tx) + at(1, 0, 0) * tx
+    v01 = at(0, 0, 1) * (1 - tx) + at(1, 0, 1) * tx
+    v10 = at(0, 1, 0) * (1 - tx) + at(1, 1, 0) * tx
+    v11 = at(0, 1, 1) * (1 - tx) + at(1, 1, 1) * tx
+    v = (v00 * (1 - ty) + v10 * ty) * (1 - tz) + (v01 * (1 - ty) + v11 * ty) * tz
+    assert abs((pre["area"] * v).sum() / pre["area"].sum()) < 1e-10
+
+
+def test_full_size_solvers_agree_and_are_deterministic(full_size):
+    f = full_size
+    s, phi = f["solver"], f["phi"]
+    st2 = s.solve()
+    phi2, _ = s.get_phi()
+    assert np.array_equal(phi, phi2)                        # fixed-order reductions: bit-identical reruns
+    st3 = s.solve(solver="primal", precond="dct")
+    phi3, _ = s.get_phi()
+    assert np.abs(phi3 - phi).max() < 1e-7, (st2.iters, st3.iters)
+    assert phi.argmax() == 0 and abs(phi.max() - 4.474) < 2e-3 and abs(phi.min() + 0.5996) < 2e-3   # profiles/r01_parity_*.json
