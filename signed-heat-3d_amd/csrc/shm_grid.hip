@@ -195,6 +195,7 @@ struct Solver final : SolverBase {
     std::vector<double> h_pos, h_wn, h_area;
     double area_sum = 0., conv_far_gap = 0.;
     int n_clusters = 0;
+    int conv_grid_cap = 1 << 30;
     DevArray<T> d_src;          // [Spad][6] Morton-sorted, padded to whole clusters
     DevArray<float> d_src32;    // same in fp32 (far clusters of the fp64 path)
     DevArray<float> d_clusters; // [n_clusters][4] bounding spheres
@@ -230,6 +231,13 @@ struct Solver final : SolverBase {
         if (cfg.device < 0 || cfg.device >= ndev) throw Error(SHM_ERR_INVALID, fmt("device %d out of range [0,%d)", cfg.device, ndev));
         HIPCHK(hipSetDevice(cfg.device));
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        {
+            hipDeviceProp_t prop;
+            HIPCHK(hipGetDeviceProperties(&prop, cfg.device));
+            const char* e = getenv("SHM_CONV_SLOTS_PER_CU_X16");  // tuning knob: conv workgroups per CU, in 1/16ths (default 64 = 4, the LDS-limited residency: one persistent wave of workgroups)
+            const int x16 = e ? atoi(e) : 64;
+            conv_grid_cap = std::max(1, prop.multiProcessorCount * x16 / 16);
+        }
         {   // the set-up stream outranks the main stream so that its short kernels are not starved by the Step-1 kernel
             int least = 0, greatest = 0;
             HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -435,7 +443,9 @@ struct Solver final : SolverBase {
             P.tiles_y = P.tiles_x;
             const int tiles_z = (P.kk_end - P.kk_begin + kConvTile - 1) / kConvTile;
             constexpr int NPT = 2;
-            const unsigned grid = (unsigned)(P.tiles_x * P.tiles_y * tiles_z);
+            P.n_tiles = P.tiles_x * P.tiles_y * tiles_z;
+            // fewer workgroups than the chip has slots (4 per CU by LDS): the set-up stream's kernels find room beside Step 1
+            const unsigned grid = (unsigned)std::min(P.n_tiles, conv_grid_cap);
             hipLaunchKernelGGL((conv_normalize_kernel<T, NPT>), dim3(grid), dim3(kBlock), 0, stream, P, d_src.p, d_src32.p, d_clusters.p, sl.Y0.p, sl.Y1.p,
                                sl.Y2.p);
         }

@@ -140,6 +140,7 @@ struct ConvParams {
     int n_clusters;
     float far_gap;      // fp64 path: a cluster is "far" when d_lo(tile, cluster) - r_hi(tile) > far_gap
     int exact_offset;   // fp32 path only: 1 = per-node nearest-source distance (coarse grids: lambda * tile diameter too large)
+    int n_tiles;        // total tiles; workgroups stride over them (fewer workgroups than slots leave room for the set-up stream)
 };
 
 constexpr int kConvTile = 8;      // 8x8x8 nodes per workgroup, 2 per lane
@@ -170,7 +171,8 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
     if (kMixed && threadIdx.x < 64) exp_tab[threadIdx.x] = exp2((double)threadIdx.x * 0.015625);  // correctly rounded 2^(j/64)
     const int n = P.n;
     const size_t plane = (size_t)n * n;
-    const int bt = blockIdx.x;
+    for (int bt = blockIdx.x; bt < P.n_tiles; bt += gridDim.x) {
+    __syncthreads();  // LDS reuse between consecutive tiles of this workgroup
     const int tz = bt / (P.tiles_x * P.tiles_y), trem = bt - tz * (P.tiles_x * P.tiles_y);
     const int ty = trem / P.tiles_x, tx = trem - ty * P.tiles_x;
     const int i0 = tx * kConvTile, j0 = ty * kConvTile, kk0 = P.kk_begin + tz * kConvTile;
@@ -307,6 +309,7 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
         Y1[vidx[e]] = x1 / nrm;
         Y2[vidx[e]] = x2 / nrm;
     }
+    }  // tile loop
 }
 
 // =================================================================================================
