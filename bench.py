@@ -223,6 +223,13 @@ def main():
                     "frac_of_hbm_peak": avg["bytes_per_iter"] / world / (avg["ms_pcg"] / max(1.0, avg["iters"]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "ms_project_avg": avg["ms_project_avg"]},
             "kernels": kinfo,
+            # Step 1+2 is compute-bound on the vector ALU: 18 nominal flop per (node, source) pair against the
+            # fp64 / fp32 vector peak; the fp64 inner loop issues 28 fp64 VALU + 1 rsq + 1 ldexp + 3 int ops per pair (ISA count)
+            "step1": {"kernel": "conv_normalize_kernel", "bound": "valu", "pairs": float(N) * float(pre["S"]),
+                      "pairs_per_s": float(N) * float(pre["S"]) / world / (avg["ms_conv"] * 1e-3),
+                      "achieved_TFLOPs_nominal_18_per_pair": 18.0 * float(N) * float(pre["S"]) / world / (avg["ms_conv"] * 1e-3) / 1e12,
+                      "peak_TFLOPs_vector": 78.6 if precision == 64 else 157.3,
+                      "frac": 18.0 * float(N) * float(pre["S"]) / world / (avg["ms_conv"] * 1e-3) / 1e12 / (78.6 if precision == 64 else 157.3)},
             "roofline": {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "note": "achieved = algorithmic bytes per launch / avg launch duration (HIP events on the solver stream, "
