@@ -751,26 +751,25 @@ struct Solver final : SolverBase {
     // ------------------------------------------------------------------------------------------
     struct StencilLaunch {
         dim3 grid, block;
-        int rpb;  // rows per logical block
+        int xchunks, yblocks;
     };
     StencilLaunch stencil_dims(const Slab<T>& sl) const {
         const int per_row = (n + vec - 1) / vec;
         int tx = 1;
         while (tx < per_row && tx < kBlock) tx <<= 1;
-        const int ry = kBlock / tx;
-        const int rows = n * sl.nzl;
-        int rpb = (rows + 4095) / 4096;            // aim at <= 4096 blocks (<= kMaxPartials partial sums)
-        rpb = ((rpb + ry - 1) / ry) * ry;
-        const int nblk = (rows + rpb - 1) / rpb;
-        return {dim3((unsigned)nblk), dim3((unsigned)tx, (unsigned)ry), rpb};
+        const int tyb = kBlock / tx;
+        const int xchunks = (per_row + tx - 1) / tx;
+        const int yblocks = (n + tyb * kStRY - 1) / (tyb * kStRY);
+        const int zchunks = (sl.nzl + kStZC - 1) / kStZC;
+        return {dim3((unsigned)(xchunks * yblocks * zchunks)), dim3((unsigned)tx, (unsigned)tyb), xchunks, yblocks};
     }
 
     void launch_stencil(Slab<T>& sl) {
         const StencilLaunch L = stencil_dims(sl);
         if (vec == 1)
-            hipLaunchKernelGGL((stencil_dot_kernel<T, 1>), L.grid, L.block, 0, stream, sl.gp, L.rpb, sl.p.p, sl.q.p, sl.partials.p);
+            hipLaunchKernelGGL((stencil_dot_kernel<T, 1>), L.grid, L.block, 0, stream, sl.gp, L.xchunks, L.yblocks, sl.p.p, sl.q.p, sl.partials.p);
         else
-            hipLaunchKernelGGL((stencil_dot_kernel<T, vec_width<T>()>), L.grid, L.block, 0, stream, sl.gp, L.rpb, sl.p.p, sl.q.p, sl.partials.p);
+            hipLaunchKernelGGL((stencil_dot_kernel<T, vec_width<T>()>), L.grid, L.block, 0, stream, sl.gp, L.xchunks, L.yblocks, sl.p.p, sl.q.p, sl.partials.p);
     }
 
     template <int VEC> void launch_update_xr(Slab<T>& sl, int rho_slot, int grid) {

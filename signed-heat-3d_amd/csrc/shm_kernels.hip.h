@@ -392,43 +392,93 @@ __device__ __forceinline__ void store_vec(T* p, const T (&v)[VEC]) {
     *reinterpret_cast<V*>(p) = t;
 }
 
+// Register-blocked z-march: a lane owns VEC consecutive x nodes of RY consecutive rows and walks ZC planes keeping the
+// planes k-1, k, k+1 in registers, so every p value is loaded once per (RY x ZC) block plus its halo ((RY+2)/RY in y,
+// (ZC+2)/ZC in z) instead of 5 times; the x neighbours come from the adjacent lanes (wave shuffles), only the two edge lanes
+// of a wave touch memory for them.  blockDim = (TX, TYB), logical blocks ordered x-chunk fastest, then y, then z-chunk, and
+// XCD-remapped so that each XCD sweeps a contiguous range of z-chunks.
+constexpr int kStRY = 4;   // rows per lane
+constexpr int kStZC = 16;  // planes per workgroup
+
 template <typename T, int VEC>
-__global__ __launch_bounds__(kBlock) void stencil_dot_kernel(GridParams G, int rpb, const T* __restrict__ p, T* __restrict__ q,
+__global__ __launch_bounds__(kBlock) void stencil_dot_kernel(GridParams G, int xchunks, int yblocks, const T* __restrict__ p, T* __restrict__ q,
                                                              double* __restrict__ partials) {
     __shared__ double red[8];
+    constexpr int RY = kStRY, ZC = kStZC;
     const int n = G.n;
     const size_t plane = (size_t)n * n;
     const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
-    const int rows = n * G.nzl;
-    const int row_end = min(rows, (int)(lb + 1) * rpb);
+    const int xc = (int)(lb % (unsigned)xchunks), yb = (int)((lb / (unsigned)xchunks) % (unsigned)yblocks), zc = (int)(lb / (unsigned)(xchunks * yblocks));
+    const int i = (xc * (int)blockDim.x + (int)threadIdx.x) * VEC;
+    const int j0 = (yb * (int)blockDim.y + (int)threadIdx.y) * RY;
+    const int kk0 = zc * ZC, kk1 = min(kk0 + ZC, G.nzl);
     const T ih2 = (T)G.inv_h2;
+    const int lane = (threadIdx.y * blockDim.x + threadIdx.x) & 63;
     double acc = 0.;
-    for (int row = (int)lb * rpb + threadIdx.y; row < row_end; row += blockDim.y) {
-        const int kk = row / n, j = row - kk * n;
-        const int k = G.k0 + kk;
-        const size_t rbase = (size_t)(kk + 1) * plane + (size_t)j * n;
-        // neighbour row offsets; an out-of-grid neighbour is the node itself (:299-319)
-        const ptrdiff_t oym = (j > 0) ? -(ptrdiff_t)n : 0, oyp = (j < n - 1) ? (ptrdiff_t)n : 0;
-        const ptrdiff_t ozm = (k > 0) ? -(ptrdiff_t)plane : 0, ozp = (k < n - 1) ? (ptrdiff_t)plane : 0;
-        for (int i = threadIdx.x * VEC; i < n; i += blockDim.x * VEC) {
-            const T* c = p + rbase + i;
-            T pc[VEC], ym[VEC], yp[VEC], zm[VEC], zp[VEC], out[VEC];
-            load_vec<T, VEC>(c, pc);
-            load_vec<T, VEC>(c + oym, ym);
-            load_vec<T, VEC>(c + oyp, yp);
-            load_vec<T, VEC>(c + ozm, zm);
-            load_vec<T, VEC>(c + ozp, zp);
-            const T left = (i > 0) ? c[-1] : pc[0];
-            const T right = (i + VEC < n) ? c[VEC] : pc[VEC - 1];
+    const bool active = i < n && j0 < n;
+    // register planes: cur has the two y-halo rows (index 0 and RY+1)
+    T prv[RY][VEC], cur[RY + 2][VEC], nxt[RY][VEC];
+    auto row_ptr = [&](int kk, int j) { return p + (size_t)(kk + 1) * plane + (size_t)j * n + i; };
+    auto load_row = [&](int kk, int j, T (&dst)[VEC]) {   // clamped row index = "an out-of-grid neighbour is the node itself" in y
+        const int jc = min(max(j, 0), n - 1);
+        if (active) load_vec<T, VEC>(row_ptr(kk, jc), dst);
+    };
+    if (active) {
+        const int kg0 = G.k0 + kk0;
 #pragma unroll
-            for (int e = 0; e < VEC; e++) {
-                const T xm = (e == 0) ? left : pc[e - 1];
-                const T xp = (e == VEC - 1) ? right : pc[e + 1];
-                const T s = (xp + yp[e] + zp[e] + xm + ym[e] + zm[e]) - (T)6 * pc[e];
-                out[e] = -s * ih2;
-                acc += (double)pc[e] * (double)out[e];
+        for (int r = 0; r < RY + 2; r++) load_row(kk0, j0 - 1 + r, cur[r]);
+#pragma unroll
+        for (int r = 0; r < RY; r++) {
+            if (kg0 > 0) load_row(kk0 - 1, j0 + r, prv[r]);
+            else {
+#pragma unroll
+                for (int e = 0; e < VEC; e++) prv[r][e] = cur[r + 1][e];
             }
-            store_vec<T, VEC>(q + rbase + i, out);
+        }
+    }
+    for (int kk = kk0; kk < kk1; kk++) {
+        const int kg = G.k0 + kk;
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < RY; r++) {
+                if (kg < n - 1) load_row(kk + 1, j0 + r, nxt[r]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < VEC; e++) nxt[r][e] = cur[r + 1][e];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RY; r++) {
+            const int j = j0 + r;
+            // x neighbours of the lane's first / last element: from the adjacent lanes, or from memory at the wave's edges
+            T left = __shfl_up(cur[r + 1][VEC - 1], 1, kWave), right = __shfl_down(cur[r + 1][0], 1, kWave);
+            if (active && j < n) {
+                if (threadIdx.x == 0 || lane == 0) left = (i > 0) ? row_ptr(kk, j)[-1] : cur[r + 1][0];
+                if (threadIdx.x == blockDim.x - 1 || lane == 63 || i + VEC >= n) right = (i + VEC < n) ? row_ptr(kk, j)[VEC] : cur[r + 1][VEC - 1];
+                T out[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; e++) {
+                    const T c = cur[r + 1][e];
+                    const T xm = (e == 0) ? left : cur[r + 1][e - 1];
+                    const T xp = (e == VEC - 1) ? right : cur[r + 1][e + 1];
+                    const T s = (xp + cur[r + 2][e] + nxt[r][e] + xm + cur[r][e] + prv[r][e]) - (T)6 * c;
+                    out[e] = -s * ih2;
+                    acc += (double)c * (double)out[e];
+                }
+                store_vec<T, VEC>(q + (size_t)(kk + 1) * plane + (size_t)j * n + i, out);
+            }
+        }
+        if (active && kk + 1 < kk1) {   // rotate the planes and fetch the y-halo rows of the new current plane
+#pragma unroll
+            for (int r = 0; r < RY; r++)
+#pragma unroll
+                for (int e = 0; e < VEC; e++) {
+                    prv[r][e] = cur[r + 1][e];
+                    cur[r + 1][e] = nxt[r][e];
+                }
+            load_row(kk + 1, j0 - 1, cur[0]);
+            load_row(kk + 1, j0 + RY, cur[RY + 1]);
         }
     }
     // block reduction over blockDim.x*blockDim.y == kBlock threads

@@ -239,15 +239,16 @@ def test_local_slabs_match_single_slab(shm, slabs):
     assert np.abs(phi - d["phi"]).max() < 1e-7
 
 
-def test_matches_c_oracle_128(shm, oracle_c):
-    """Same inputs through the HIP path and the C oracle (serial reference loops + projected CG) at 64^3 with a
-    different mesh scale -- a size with no LU fixture."""
+@pytest.mark.parametrize("n,slabs", [(48, 1), (33, 1), (33, 3), (70, 1)])
+def test_matches_c_oracle_128(shm, oracle_c, n, slabs):
+    """Same inputs through the HIP path (plain stencil CG: sizes that are not powers of two, odd sizes without vector loads,
+    several slabs) and the C oracle (serial reference loops + projected CG) -- sizes with no LU fixture."""
     d = load_golden("bunny_small_n16")
-    n = 48
     cell = float(d["cell"]) * 15 / (n - 1)
-    s = shm.GridSolver()
+    s = shm.GridSolver(local_slabs=slabs)
     s.set_problem(d["pos"], d["wnormal"], d["area"], float(d["lam"]), n, d["bbox_min"], cell)
-    s.solve(tol=1e-10)
+    st = s.solve(tol=1e-10)
+    assert st.solver == 1 and st.preconditioner == 1
     phi, _ = s.get_phi()
     ref = np.zeros(n ** 3)
     st = np.zeros(5)
