@@ -751,7 +751,7 @@ struct Solver final : SolverBase {
     // ------------------------------------------------------------------------------------------
     struct StencilLaunch {
         dim3 grid, block;
-        int xchunks, yblocks;
+        int xchunks, yblocks, zc;
     };
     StencilLaunch stencil_dims(const Slab<T>& sl) const {
         const int per_row = (n + vec - 1) / vec;
@@ -760,16 +760,21 @@ struct Solver final : SolverBase {
         const int tyb = kBlock / tx;
         const int xchunks = (per_row + tx - 1) / tx;
         const int yblocks = (n + tyb * kStRY - 1) / (tyb * kStRY);
-        const int zchunks = (sl.nzl + kStZC - 1) / kStZC;
-        return {dim3((unsigned)(xchunks * yblocks * zchunks)), dim3((unsigned)tx, (unsigned)tyb), xchunks, yblocks};
+        // planes per workgroup: as many as possible (less z-halo re-reading) while the grid still has >= ~4 workgroups per CU
+        static const int zc_env = getenv("SHM_STENCIL_ZC") ? atoi(getenv("SHM_STENCIL_ZC")) : 0;
+        int zc = 16;
+        while (zc > 4 && (long long)xchunks * yblocks * ((sl.nzl + zc - 1) / zc) < 1024) zc >>= 1;
+        if (zc_env > 0) zc = zc_env;
+        const int zchunks = (sl.nzl + zc - 1) / zc;
+        return {dim3((unsigned)(xchunks * yblocks * zchunks)), dim3((unsigned)tx, (unsigned)tyb), xchunks, yblocks, zc};
     }
 
     void launch_stencil(Slab<T>& sl) {
         const StencilLaunch L = stencil_dims(sl);
         if (vec == 1)
-            hipLaunchKernelGGL((stencil_dot_kernel<T, 1>), L.grid, L.block, 0, stream, sl.gp, L.xchunks, L.yblocks, sl.p.p, sl.q.p, sl.partials.p);
+            hipLaunchKernelGGL((stencil_dot_kernel<T, 1>), L.grid, L.block, 0, stream, sl.gp, L.xchunks, L.yblocks, L.zc, sl.p.p, sl.q.p, sl.partials.p);
         else
-            hipLaunchKernelGGL((stencil_dot_kernel<T, vec_width<T>()>), L.grid, L.block, 0, stream, sl.gp, L.xchunks, L.yblocks, sl.p.p, sl.q.p, sl.partials.p);
+            hipLaunchKernelGGL((stencil_dot_kernel<T, vec_width<T>()>), L.grid, L.block, 0, stream, sl.gp, L.xchunks, L.yblocks, L.zc, sl.p.p, sl.q.p, sl.partials.p);
     }
 
     template <int VEC> void launch_update_xr(Slab<T>& sl, int rho_slot, int grid) {

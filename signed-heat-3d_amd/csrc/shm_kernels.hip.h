@@ -398,13 +398,12 @@ __device__ __forceinline__ void store_vec(T* p, const T (&v)[VEC]) {
 // of a wave touch memory for them.  blockDim = (TX, TYB), logical blocks ordered x-chunk fastest, then y, then z-chunk, and
 // XCD-remapped so that each XCD sweeps a contiguous range of z-chunks.
 constexpr int kStRY = 4;   // rows per lane
-constexpr int kStZC = 16;  // planes per workgroup
 
 template <typename T, int VEC>
-__global__ __launch_bounds__(kBlock) void stencil_dot_kernel(GridParams G, int xchunks, int yblocks, const T* __restrict__ p, T* __restrict__ q,
+__global__ __launch_bounds__(kBlock) void stencil_dot_kernel(GridParams G, int xchunks, int yblocks, int ZC /* planes per workgroup */, const T* __restrict__ p, T* __restrict__ q,
                                                              double* __restrict__ partials) {
     __shared__ double red[8];
-    constexpr int RY = kStRY, ZC = kStZC;
+    constexpr int RY = kStRY;
     const int n = G.n;
     const size_t plane = (size_t)n * n;
     const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
