@@ -187,7 +187,7 @@ struct Solver final : SolverBase {
     shm_config cfg;
     hipStream_t stream = nullptr;   // conv, divergence, CG
     hipStream_t stream2 = nullptr;  // constraint set-up ((A A^T)^-1), overlapped with the Step-1 kernel
-    int n = 0;
+    int n = 0, alloc_n = -1;
     size_t N = 0;
     double cell = 0., lambda = 0.;
     double bbox_min[3] = {0, 0, 0};
@@ -385,8 +385,13 @@ struct Solver final : SolverBase {
         }
 
         vec = (n % vec_width<T>() == 0) ? vec_width<T>() : 1;
-        slabs.clear();
-        slabs.resize(cfg.local_slabs);
+        // keep the device arrays across calls with the same grid size (the reference's `rebuild=false` reuse, :8): a repeated
+        // computeDistance() then costs no hipMalloc/hipFree
+        if (!(have_problem && n == alloc_n && (int)slabs.size() == cfg.local_slabs)) {
+            slabs.clear();
+            slabs.resize(cfg.local_slabs);
+        }
+        alloc_n = n;
         for (int ls = 0; ls < cfg.local_slabs; ls++) {
             Slab<T>& sl = slabs[ls];
             int32_t k0, k1;
