@@ -163,6 +163,12 @@ shm_status shm_grid_apply_projector(shm_solver* s, double* v);
 /* out = M^-1 v with the DCT preconditioner alone (no projection); v,out: n^3 doubles on the host (world==1). */
 shm_status shm_grid_apply_preconditioner(shm_solver* s, const double* v, double* out);
 
+/* --- isosurface of the resident phi (headless stand-in for the demo's Polyscope marching cubes, src/main.cpp:116-128,167-191):
+ * marching tetrahedra (Kuhn split), inside = phi < isovalue, normals towards increasing phi, vertices welded per grid edge.
+ * Covers the cells whose lower z-plane this process owns.  Call shm_grid_isosurface, size the buffers, then _get_. */
+shm_status shm_grid_isosurface(shm_solver* s, double isovalue, int64_t* n_vertices, int64_t* n_triangles);
+shm_status shm_grid_get_isosurface(shm_solver* s, double* vertices /* [3*nv] */, int64_t* triangles /* [3*nt] */);
+
 /* --- multi-GPU bootstrap ------------------------------------------------------------------------ */
 /* Fill 128 bytes with a fresh ncclUniqueId (rank 0 calls this, the launcher broadcasts the bytes). */
 shm_status shm_comm_unique_id(void* out128);

@@ -161,6 +161,8 @@ struct SolverBase {
     virtual void get_constraints(int64_t*, double*, int32_t*) = 0;
     virtual void apply_projector(double*) = 0;
     virtual void apply_preconditioner(const double*, double*) = 0;
+    virtual void isosurface(double, int64_t*, int64_t*) = 0;
+    virtual void get_isosurface(double*, int64_t*) = 0;
 };
 
 template <typename T> constexpr int vec_width() { return sizeof(T) == 8 ? 2 : 4; }
@@ -728,12 +730,13 @@ struct Solver final : SolverBase {
     }
 
     // transport: fill the ghost planes of `field` (p) from the neighbouring slabs
-    void halo_exchange_p() {
+    void halo_exchange_p() { halo_exchange(ARR_P); }
+    void halo_exchange(int sel) {
         const size_t pb = slabs[0].plane * sizeof(T);
         for (size_t s = 0; s + 1 < slabs.size(); s++) {
             Slab<T>&a = slabs[s], &b = slabs[s + 1];
-            HIPCHK(hipMemcpyAsync(b.p.p, a.p.p + (size_t)a.nzl * a.plane, pb, hipMemcpyDeviceToDevice, stream));                // a top -> b low ghost
-            HIPCHK(hipMemcpyAsync(a.p.p + (size_t)(a.nzl + 1) * a.plane, b.p.p + b.plane, pb, hipMemcpyDeviceToDevice, stream));  // b bottom -> a high ghost
+            HIPCHK(hipMemcpyAsync(arr(b, sel), arr(a, sel) + (size_t)a.nzl * a.plane, pb, hipMemcpyDeviceToDevice, stream));                // a top -> b low ghost
+            HIPCHK(hipMemcpyAsync(arr(a, sel) + (size_t)(a.nzl + 1) * a.plane, arr(b, sel) + b.plane, pb, hipMemcpyDeviceToDevice, stream));  // b bottom -> a high ghost
         }
         if (comm) {
             Rccl& R = Rccl::get();
@@ -742,12 +745,12 @@ struct Solver final : SolverBase {
             const size_t cnt = lo.plane;
             R.chk(R.GroupStart(), "ncclGroupStart");
             if (cfg.rank > 0) {
-                R.chk(R.Send(lo.p.p + lo.plane, cnt, dt, cfg.rank - 1, comm, stream), "ncclSend(lo)");
-                R.chk(R.Recv(lo.p.p, cnt, dt, cfg.rank - 1, comm, stream), "ncclRecv(lo)");
+                R.chk(R.Send(arr(lo, sel) + lo.plane, cnt, dt, cfg.rank - 1, comm, stream), "ncclSend(lo)");
+                R.chk(R.Recv(arr(lo, sel), cnt, dt, cfg.rank - 1, comm, stream), "ncclRecv(lo)");
             }
             if (cfg.rank < cfg.world - 1) {
-                R.chk(R.Send(hi.p.p + (size_t)hi.nzl * hi.plane, cnt, dt, cfg.rank + 1, comm, stream), "ncclSend(hi)");
-                R.chk(R.Recv(hi.p.p + (size_t)(hi.nzl + 1) * hi.plane, cnt, dt, cfg.rank + 1, comm, stream), "ncclRecv(hi)");
+                R.chk(R.Send(arr(hi, sel) + (size_t)hi.nzl * hi.plane, cnt, dt, cfg.rank + 1, comm, stream), "ncclSend(hi)");
+                R.chk(R.Recv(arr(hi, sel) + (size_t)(hi.nzl + 1) * hi.plane, cnt, dt, cfg.rank + 1, comm, stream), "ncclRecv(hi)");
             }
             R.chk(R.GroupEnd(), "ncclGroupEnd");
         }
@@ -1457,6 +1460,67 @@ struct Solver final : SolverBase {
         have_div = false;
     }
 
+    std::vector<double> iso_vertices;
+    std::vector<int64_t> iso_triangles;
+
+    void isosurface(double iso, int64_t* nv, int64_t* nt) override {
+        need_problem();
+        if (!have_phi) throw Error(SHM_ERR_STATE, "no phi: shm_grid_solve has not completed");
+        HIPCHK(hipSetDevice(cfg.device));
+        halo_exchange(ARR_Q);  // phi lives in q; cells of the top owned plane need the plane above
+        iso_vertices.clear();
+        iso_triangles.clear();
+        std::unordered_map<uint64_t, int64_t> weld;
+        for (Slab<T>& sl : slabs) {
+            IsoParams P;
+            P.n = n; P.nzl = sl.nzl; P.k0 = sl.k0;
+            for (int a = 0; a < 3; a++) P.bbox_min[a] = bbox_min[a];
+            P.cell = cell; P.iso = iso;
+            DevArray<unsigned long long> counter, keys, sortk;
+            DevArray<double> pos;
+            counter.alloc(1);
+            HIPCHK(hipMemsetAsync(counter.p, 0, sizeof(unsigned long long), stream));
+            const size_t ncells = (size_t)(n - 1) * (n - 1) * (size_t)std::max(0, std::min(sl.nzl, n - 1 - sl.k0));
+            const int grid = grid_for(ncells, 8192);
+            hipLaunchKernelGGL((iso_kernel<T, false>), dim3(grid), dim3(kBlock), 0, stream, P, sl.q.p, counter.p, (double*)nullptr, (unsigned long long*)nullptr,
+                               (unsigned long long*)nullptr, 0ULL);
+            unsigned long long ntri = 0;
+            HIPCHK(hipMemcpyAsync(&ntri, counter.p, sizeof ntri, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            if (ntri == 0) continue;
+            pos.alloc(ntri * 9);
+            keys.alloc(ntri * 3);
+            sortk.alloc(ntri);
+            HIPCHK(hipMemsetAsync(counter.p, 0, sizeof(unsigned long long), stream));
+            hipLaunchKernelGGL((iso_kernel<T, true>), dim3(grid), dim3(kBlock), 0, stream, P, sl.q.p, counter.p, pos.p, keys.p, sortk.p, ntri);
+            HIPCHK(hipGetLastError());
+            std::vector<double> hpos(ntri * 9);
+            std::vector<unsigned long long> hkeys(ntri * 3), hsort(ntri);
+            HIPCHK(hipMemcpyAsync(hpos.data(), pos.p, hpos.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(hkeys.data(), keys.p, hkeys.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(hsort.data(), sortk.p, hsort.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            // the append order is racy; the (cell, tet, triangle) key restores a deterministic order before welding
+            std::vector<size_t> order(ntri);
+            for (size_t a = 0; a < ntri; a++) order[a] = a;
+            std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return hsort[x] < hsort[y]; });
+            for (size_t a : order)
+                for (int c = 0; c < 3; c++) {
+                    auto ins = weld.insert({hkeys[a * 3 + c], (int64_t)(iso_vertices.size() / 3)});
+                    if (ins.second)
+                        for (int b = 0; b < 3; b++) iso_vertices.push_back(hpos[a * 9 + c * 3 + b]);
+                    iso_triangles.push_back(ins.first->second);
+                }
+        }
+        if (nv) *nv = (int64_t)(iso_vertices.size() / 3);
+        if (nt) *nt = (int64_t)(iso_triangles.size() / 3);
+    }
+
+    void get_isosurface(double* vertices, int64_t* triangles) override {
+        if (vertices && !iso_vertices.empty()) memcpy(vertices, iso_vertices.data(), iso_vertices.size() * sizeof(double));
+        if (triangles && !iso_triangles.empty()) memcpy(triangles, iso_triangles.data(), iso_triangles.size() * sizeof(int64_t));
+    }
+
     void apply_preconditioner(const double* v, double* out) override {
         need_problem();
         if (cfg.world != 1) throw Error(SHM_ERR_INVALID, "apply_preconditioner is a single-process test entry point");
@@ -1620,6 +1684,13 @@ shm_status shm_grid_apply_preconditioner(shm_solver* s, const double* v, double*
         if (!v || !out) throw shm::Error(SHM_ERR_INVALID, "null argument");
         s->impl->apply_preconditioner(v, out);
     });
+}
+
+shm_status shm_grid_isosurface(shm_solver* s, double isovalue, int64_t* n_vertices, int64_t* n_triangles) {
+    return guard(s, [&] { s->impl->isosurface(isovalue, n_vertices, n_triangles); });
+}
+shm_status shm_grid_get_isosurface(shm_solver* s, double* vertices, int64_t* triangles) {
+    return guard(s, [&] { s->impl->get_isosurface(vertices, triangles); });
 }
 
 shm_status shm_comm_unique_id(void* out128) {

@@ -1080,4 +1080,128 @@ __global__ __launch_bounds__(kBlock) void gj_update_kernel(double* __restrict__ 
             }
 }
 
+
+// =================================================================================================
+// Isosurface of the grid phi (headless replacement of the demo's Polyscope marching cubes, src/main.cpp:116-128,167-191):
+// marching tetrahedra on the Kuhn split of every cell (six tets around the 000-111 diagonal; translation invariant, so
+// faces of neighbouring cells agree and the surface is watertight).  inside = phi < iso.  Pass 1 counts, pass 2 appends
+// triangles (three positions + three global edge keys for welding + a sort key that makes the final order deterministic).
+// =================================================================================================
+struct IsoParams {
+    int n, nzl, k0;          // cells (i,j,k): i,j < n-1, k in [k0, min(k0+nzl, n-1))
+    double bbox_min[3];
+    double cell;
+    double iso;
+};
+
+__device__ __constant__ int kKuhnTets[6][4] = {{0, 1, 3, 7}, {0, 1, 5, 7}, {0, 2, 3, 7}, {0, 2, 6, 7}, {0, 4, 5, 7}, {0, 4, 6, 7}};
+
+// number of triangles of one tet given the inside mask of its four vertices
+__device__ __forceinline__ int tet_tris(int mask) {
+    const int c = __popc(mask);
+    return c == 0 || c == 4 ? 0 : (c == 2 ? 2 : 1);
+}
+
+template <typename T, bool EMIT>
+__global__ __launch_bounds__(kBlock) void iso_kernel(IsoParams P, const T* __restrict__ phi /* ghost layout */, unsigned long long* __restrict__ counter,
+                                                     double* __restrict__ tri_pos /* [cap][9] */, unsigned long long* __restrict__ tri_keys /* [cap][3] */,
+                                                     unsigned long long* __restrict__ tri_sort /* [cap] */, unsigned long long cap) {
+    __shared__ double red[8];
+    const int n = P.n, nc = n - 1;
+    const size_t plane = (size_t)n * n;
+    const int kend = min(P.nzl, n - 1 - P.k0);                 // local cell layers
+    const size_t ncells = (size_t)nc * nc * (size_t)max(kend, 0);
+    double mycount = 0.;
+    for (size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x; c < ncells; c += (size_t)gridDim.x * kBlock) {
+        const int kk = (int)(c / ((size_t)nc * nc));
+        const int rem = (int)(c - (size_t)kk * nc * nc);
+        const int j = rem / nc, i = rem - j * nc;
+        const size_t base = (size_t)(kk + 1) * plane + (size_t)j * n + i;
+        double v[8];
+        int inside = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            v[q] = (double)phi[base + (q & 1) + ((q >> 1) & 1) * (size_t)n + ((q >> 2) & 1) * plane];
+            inside |= (v[q] < P.iso ? 1 : 0) << q;
+        }
+        if (inside == 0 || inside == 255) continue;
+        const int k = P.k0 + kk;
+        const unsigned long long gnode = (unsigned long long)i + (unsigned long long)j * n + (unsigned long long)k * plane;
+        for (int t = 0; t < 6; t++) {
+            int tv[4], mask = 0;
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                tv[a] = kKuhnTets[t][a];
+                mask |= ((inside >> tv[a]) & 1) << a;
+            }
+            const int nt = tet_tris(mask);
+            if (nt == 0) continue;
+            if (!EMIT) {
+                mycount += nt;
+                continue;
+            }
+            // order the tet vertices: inside ones first
+            int in_v[4], out_v[4], ni = 0, no = 0;
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                if ((mask >> a) & 1) in_v[ni++] = tv[a];
+                else out_v[no++] = tv[a];
+            }
+            auto corner_pos = [&](int q, double* p) {
+                p[0] = (i + (q & 1)) * P.cell + P.bbox_min[0];
+                p[1] = (j + ((q >> 1) & 1)) * P.cell + P.bbox_min[1];
+                p[2] = (k + ((q >> 2) & 1)) * P.cell + P.bbox_min[2];
+            };
+            auto edge_point = [&](int qa, int qb, double* p, unsigned long long& key) {   // qa inside, qb outside
+                double pa[3], pb[3];
+                corner_pos(qa, pa);
+                corner_pos(qb, pb);
+                const double tt = (P.iso - v[qa]) / (v[qb] - v[qa]);
+#pragma unroll
+                for (int a = 0; a < 3; a++) p[a] = pa[a] + tt * (pb[a] - pa[a]);
+                const unsigned long long ga = gnode + (qa & 1) + ((qa >> 1) & 1) * (unsigned long long)n + ((qa >> 2) & 1) * plane;
+                const unsigned long long gb = gnode + (qb & 1) + ((qb >> 1) & 1) * (unsigned long long)n + ((qb >> 2) & 1) * plane;
+                key = ga < gb ? (ga << 32 | gb) : (gb << 32 | ga);
+            };
+            double pts[4][3];
+            unsigned long long keys[4];
+            int np = 0;
+            if (ni == 1) for (int a = 0; a < 3; a++) { edge_point(in_v[0], out_v[a], pts[np], keys[np]); np++; }
+            else if (ni == 3) for (int a = 0; a < 3; a++) { edge_point(in_v[a], out_v[0], pts[np], keys[np]); np++; }
+            else {  // quad: (i0,o0) (i0,o1) (i1,o1) (i1,o0)
+                edge_point(in_v[0], out_v[0], pts[0], keys[0]);
+                edge_point(in_v[0], out_v[1], pts[1], keys[1]);
+                edge_point(in_v[1], out_v[1], pts[2], keys[2]);
+                edge_point(in_v[1], out_v[0], pts[3], keys[3]);
+                np = 4;
+            }
+            // orientation: normals point from the inside vertices towards the outside ones (increasing phi)
+            double cin[3] = {0, 0, 0}, cout[3] = {0, 0, 0};
+            for (int a = 0; a < ni; a++) { double p[3]; corner_pos(in_v[a], p); for (int b = 0; b < 3; b++) cin[b] += p[b] / ni; }
+            for (int a = 0; a < no; a++) { double p[3]; corner_pos(out_v[a], p); for (int b = 0; b < 3; b++) cout[b] += p[b] / no; }
+            const int tris[2][3] = {{0, 1, 2}, {0, 2, 3}};
+            for (int tr = 0; tr < nt; tr++) {
+                int a0 = tris[tr][0], a1 = tris[tr][1], a2 = tris[tr][2];
+                const double e1[3] = {pts[a1][0] - pts[a0][0], pts[a1][1] - pts[a0][1], pts[a1][2] - pts[a0][2]};
+                const double e2[3] = {pts[a2][0] - pts[a0][0], pts[a2][1] - pts[a0][1], pts[a2][2] - pts[a0][2]};
+                const double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+                if (nx * (cout[0] - cin[0]) + ny * (cout[1] - cin[1]) + nz * (cout[2] - cin[2]) < 0.) { const int sw = a1; a1 = a2; a2 = sw; }
+                const unsigned long long slot = atomicAdd(counter, 1ULL);
+                if (slot < cap) {
+                    const int ord[3] = {a0, a1, a2};
+                    for (int a = 0; a < 3; a++) {
+                        for (int b = 0; b < 3; b++) tri_pos[slot * 9 + a * 3 + b] = pts[ord[a]][b];
+                        tri_keys[slot * 3 + a] = keys[ord[a]];
+                    }
+                    tri_sort[slot] = gnode * 16ULL + (unsigned long long)(t * 2 + tr);
+                }
+            }
+        }
+    }
+    if (!EMIT) {
+        mycount = block_sum(mycount, red);
+        if (threadIdx.x == 0 && mycount > 0.) atomicAdd(counter, (unsigned long long)mycount);
+    }
+}
+
 }  // namespace shm
