@@ -22,11 +22,14 @@ static void usage() {
                  "      --h <hCoef>       Grid resolution: n = 2*2^(hCoef+3) nodes per side (default 0 -> 16^3)\n"
                  "      --t <tCoef>       Diffusion time coefficient (default 1)\n      --fp32            Compute in fp32 (default fp64)\n"
                  "      --tol <x>         Projected-CG relative residual tolerance\n      --device <i>      HIP device ordinal\n"
-                 "      --out <file>      Write phi as raw little-endian float64 (n^3 values, x fastest)\n";
+                 "      --out <file>      Write phi as raw little-endian float64 (n^3 values, x fastest)\n"
+                 "      --iso <value>     Contour phi at this value (default 0) and export the isosurface\n"
+                 "      --export <file>   OBJ file of the isosurface (the demo writes ../export/isosurface.obj)\n";
 }
 
 int main(int argc, char** argv) {
-    std::string path, out;
+    std::string path, out, exportPath;
+    double isoval = 0.;
     SignedHeat3DOptions opts;
     GridBackendOptions backend;
     bool verbose = false;
@@ -49,6 +52,8 @@ int main(int argc, char** argv) {
         else if (s == "--tol") backend.tol = atof(need("--tol"));
         else if (s == "--device") backend.device = atoi(need("--device"));
         else if (s == "--out") out = need("--out");
+        else if (s == "--iso") isoval = atof(need("--iso"));
+        else if (s == "--export") exportPath = need("--export");
         else if (!s.empty() && s[0] == '-') { std::cerr << "Flag could not be matched: " << s << std::endl; usage(); return 1; }
         else path = s;
     }
@@ -77,6 +82,13 @@ int main(int argc, char** argv) {
             std::ofstream f(out, std::ios::binary);
             f.write((const char*)phi.data(), (std::streamsize)(phi.size() * sizeof(double)));
             std::cerr << "phi (" << solver.gridSize() << "^3 float64) written to " << out << std::endl;
+        }
+        if (!exportPath.empty()) {
+            std::vector<Vector3> iv;
+            std::vector<std::array<size_t, 3>> jf;
+            solver.isosurface(isoval, iv, jf);
+            writeSurfaceMesh(iv, jf, exportPath);
+            std::cerr << "Isosurface written to " << exportPath << " (" << iv.size() << " vertices, " << jf.size() << " triangles)" << std::endl;
         }
     } catch (const std::exception& e) {
         std::cerr << "error: " << e.what() << std::endl;

@@ -69,4 +69,12 @@ PointPositionNormalGeometry readPointCloud(const std::string& path) {
     return g;
 }
 
+void writeSurfaceMesh(const std::vector<Vector3>& vertices, const std::vector<std::array<size_t, 3>>& faces, const std::string& path) {
+    std::ofstream out(path);
+    if (!out.is_open()) throw std::runtime_error("Could not open file <" + path + "> for writing.");
+    out.precision(17);
+    for (const Vector3& p : vertices) out << "v " << p.x << " " << p.y << " " << p.z << "\n";
+    for (const auto& f : faces) out << "f " << f[0] + 1 << " " << f[1] + 1 << " " << f[2] + 1 << "\n";
+}
+
 }  // namespace shm_host

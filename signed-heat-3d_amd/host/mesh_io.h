@@ -11,4 +11,6 @@ namespace shm_host {
 VertexPositionGeometry readSurfaceMesh(const std::string& path);
 // `v x y z` -> position, `vn x y z` -> normal, anything else ignored (src/main.cpp:196-225).
 PointPositionNormalGeometry readPointCloud(const std::string& path);
+// Triangle mesh -> Wavefront OBJ (the demo writes ../export/isosurface.obj through geometry-central, src/main.cpp:188-190).
+void writeSurfaceMesh(const std::vector<Vector3>& vertices, const std::vector<std::array<size_t, 3>>& faces, const std::string& path);
 }  // namespace shm_host

@@ -73,6 +73,19 @@ VectorXd SignedHeatGridSolver::solveOnDevice(bool scrub, const SignedHeat3DOptio
     return phi;
 }
 
+void SignedHeatGridSolver::isosurface(double isoval, std::vector<Vector3>& vertices, std::vector<std::array<size_t, 3>>& faces) {
+    if (!handle) throw std::runtime_error("isosurface: computeDistance has not been called");
+    int64_t nv = 0, nt = 0;
+    if (shm_grid_isosurface(handle, isoval, &nv, &nt) != SHM_OK) throw std::runtime_error(std::string("shm_grid_isosurface: ") + shm_grid_last_error(handle));
+    std::vector<double> v((size_t)3 * nv);
+    std::vector<int64_t> f((size_t)3 * nt);
+    if (shm_grid_get_isosurface(handle, v.data(), f.data()) != SHM_OK) throw std::runtime_error(shm_grid_last_error(handle));
+    vertices.resize((size_t)nv);
+    faces.resize((size_t)nt);
+    for (int64_t a = 0; a < nv; a++) vertices[(size_t)a] = Vector3{v[3 * a], v[3 * a + 1], v[3 * a + 2]};
+    for (int64_t a = 0; a < nt; a++) faces[(size_t)a] = {(size_t)f[3 * a], (size_t)f[3 * a + 1], (size_t)f[3 * a + 2]};
+}
+
 VectorXd SignedHeatGridSolver::computeDistance(VertexPositionGeometry& geometry, const SignedHeat3DOptions& options) {
     if (options.rebuild || !gridBuilt) {
         const Vector3 c = centroid(geometry);

@@ -111,7 +111,7 @@ def test_cli_reports_missing_device_or_runs():
     import subprocess
     exe = os.path.join(ROOT, "signed-heat-3d_amd", "bin", "shm_grid_cli")
     p = subprocess.run([exe, "--help"], capture_output=True, text=True)
-    assert p.returncode == 0 and "--h <hCoef>" in p.stdout
+    assert p.returncode == 0 and "--h <hCoef>" in p.stdout and "--export <file>" in p.stdout
     p = subprocess.run([exe], capture_output=True, text=True)
     assert p.returncode != 0 and "Please specify a mesh file" in p.stderr
 
