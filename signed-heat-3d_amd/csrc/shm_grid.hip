@@ -379,7 +379,11 @@ struct Solver final : SolverBase {
             }
             // far when lambda * (d_lo - r_hi) > 25 + ln(Amax/Amin): the cluster's terms are below e^-25 ~ 1.4e-11 of the
             // tile's dominant term, so their fp32 rounding (~1e-5 incl. the exponent) stays below 2e-16 of it
-            conv_far_gap = (25.0 + std::log(std::max(1.0, amax / std::max(amin, 1e-300)))) / lambda;
+            {
+                const char* e = getenv("SHM_CONV_FAR_LOG");  // experiment knob: -ln of the relative size below which a cluster goes to fp32
+                const double far_log = e ? atof(e) : 25.0;
+                conv_far_gap = (far_log + std::log(std::max(1.0, amax / std::max(amin, 1e-300)))) / lambda;
+            }
             d_src.upload(packed, stream);
             d_src32.upload(packed32, stream);
             d_clusters.upload(cl, stream);
