@@ -39,7 +39,7 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured streaming ceiling
 
 
-def cpu_baseline(pre, iters_cpu, tol, seconds_budget=25.0):
+def cpu_baseline(pre, iters_cpu, tol, seconds_budget=25.0, threads=1):
     """Time the C oracle (kind "port": the reference's serial loops restated in C, 1 thread like the reference)
     on a bounded sample: `planes` z-planes of the Step-1 summation (linear in planes) and `cg_its` iterations of
     the host projected CG incl. its set-up, both extrapolated to the full job.  `iters_cpu` is the iteration count
@@ -59,7 +59,7 @@ def cpu_baseline(pre, iters_cpu, tol, seconds_budget=25.0):
     lib.shmo_constraint_rows.restype = ci
     lib.shmo_constrained_solve.argtypes = [ci, cd, f64, ci, i64, f64, cd, ci, f64, f64]
     lib.shmo_set_threads.argtypes = [ci]
-    lib.shmo_set_threads(1)
+    lib.shmo_set_threads(threads)
     n, S = pre["n"], pre["S"]
     N = n ** 3
     bbox = np.ascontiguousarray(pre["bbox_min"])
@@ -67,7 +67,7 @@ def cpu_baseline(pre, iters_cpu, tol, seconds_budget=25.0):
     wn = np.ascontiguousarray(pre["wnormal"]).reshape(-1)
     # --- Step 1+2 on a few z-planes
     pairs_per_plane = n * n * S
-    planes = int(max(1, min(n, round(0.4 * seconds_budget / (pairs_per_plane * 22e-9)))))
+    planes = int(max(1, min(n, round(0.4 * seconds_budget * threads / (pairs_per_plane * 22e-9)))))
     Y = np.zeros(3 * N)
     k0 = n // 2
     t = time.perf_counter()
@@ -98,12 +98,12 @@ def cpu_baseline(pre, iters_cpu, tol, seconds_budget=25.0):
     t_iter = max(1e-9, (time.perf_counter() - t - t_setup)) / cg_its
     total = t_conv + t_div + t_setup + t_iter * iters_cpu
     return {
-        "value": N / total, "unit": "grid-nodes/s", "cores": 1, "kind": "port",
-        "sample": "C port of the reference's serial loops (oracle/shm_oracle.c, gcc -O3 -march=native, 1 thread): Step 1+2 on %d of %d "
+        "value": N / total, "unit": "grid-nodes/s", "cores": threads, "kind": "port",
+        "sample": "C port of the reference's serial loops (oracle/shm_oracle.c, gcc -O3 -march=native, %d thread(s)): Step 1+2 on %d of %d "
                   "z-planes (%.2f s, extrapolated linearly to %.0f s), divergence in full (%.2f s), dense-Cholesky projector set-up "
                   "(%.2f s), %d plain projected-CG iterations (%.3f s each) extrapolated to the %d iterations that algorithm needs at "
                   "tolerance %.1e (count taken from an untimed run of the same plain CG on the GPU)"
-                  % (planes, n, t_conv_sample, t_conv, t_div, t_setup, cg_its, t_iter, iters_cpu, tol),
+                  % (threads, planes, n, t_conv_sample, t_conv, t_div, t_setup, cg_its, t_iter, iters_cpu, tol),
         "seconds_extrapolated": total,
     }
 
@@ -240,6 +240,11 @@ def main():
                 st_plain = solver.solve(tol=args.tol, scrub=scrub, solver="primal", precond="none")  # untimed: iteration count of the port's algorithm
                 out["cpu_baseline"] = cpu_baseline(pre, int(st_plain.iters), out["config"]["tol"])
                 out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+                # the reference is single-threaded; an OpenMP build of the same port on many cores is reported alongside
+                nthr = min(os.cpu_count() or 1, 64)
+                if nthr > 1:
+                    allc = cpu_baseline(pre, int(st_plain.iters), out["config"]["tol"], seconds_budget=8.0, threads=nthr)
+                    out["cpu_baseline"]["openmp"] = {"value": allc["value"], "cores": nthr, "seconds_extrapolated": allc["seconds_extrapolated"]}
             except Exception as e:  # the baseline is informational; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "unit": "grid-nodes/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out))

@@ -6,7 +6,7 @@ for f in data/bunny_small.obj data/polygon-bear.obj data/rocker.obj data/bunny.p
   for h in 0 1 2 3 4; do
     for p in "" "--fp32"; do
       if [ "$h" = "4" ] && [ "$p" = "" ] && [ "$f" = "data/SprayBottle.pc" ]; then continue; fi
-      out=$( { /usr/bin/time -f "%es" $CLI $f --g --V --h $h $p 2>&1; } | grep -E "min:|error|gfx950|^[0-9.]+s$" | tr '\n' ' ')
+      out=$( $CLI $f --g --V --h $h $p 2>&1 | grep -E "min:|error|gfx950|Solve time" | tr '\n' ' ')
       echo "$f h=$h $p :: $out"
     done
   done
