@@ -24,7 +24,10 @@
 namespace shm {
 
 enum DctMode : int { DCT_FWD = 0, DCT_INV = 1, DCT_FUSED = 2 };
-constexpr int kDctLines = 2 * kFftLC;  // real lines per tile
+// complex lines per tile: 8 (16 real lines = one 128-byte row per element row) up to n = 256; 4 from n = 512 on, which halves the
+// tile's LDS footprint (37 KB fp64) so that four workgroups per CU overlap their load / FFT / store phases
+template <int LOG2N> constexpr int dct_lc() { return LOG2N >= 9 ? 4 : 8; }
+constexpr int dct_lines_for(int log2n) { return log2n >= 9 ? 8 : 16; }
 
 // Address of element k of line l of tile t:
 //   off + (t % tiles_a) a_stride + (t / tiles_a) b_stride + l line_stride + (k >> seg_shift) seg_stride + (k & seg_mask) elem_stride
@@ -53,25 +56,26 @@ __device__ __forceinline__ long long dct_addr(const DctAddr& A, long long base, 
 // two fp64 tiles (73.8 KB each at n = 512) fit in one CU's 160 KB and the load/FFT/store phases of two blocks overlap.
 template <int LOG2N> constexpr bool dct_tw_in_lds() { return LOG2N <= 8; }
 template <int LOG2N> constexpr size_t dct_lds_bytes(size_t cplx_size) {
-    return ((size_t)(1 << LOG2N) * kFftRow + (dct_tw_in_lds<LOG2N>() ? (size_t)(1 << LOG2N) : 0)) * cplx_size + 64;
+    return ((size_t)(1 << LOG2N) * (dct_lc<LOG2N>() + 1) + (dct_tw_in_lds<LOG2N>() ? (size_t)(1 << LOG2N) : 0)) * cplx_size + 64;
 }
 
 // One Stockham pass over the tile: every thread holds its work items in registers across the barrier.
 template <typename TP, int LOG2N, int R, int NS, int SIGN>
 __device__ __forceinline__ void dct_fft_pass(Cplx<TP>* buf, const Cplx<TP>* tw, int tid) {
-    constexpr int items = PassGeom<LOG2N, R>::items;
+    constexpr int LC = dct_lc<LOG2N>();
+    constexpr int items = PassGeom<LOG2N, R, LC>::items;
     constexpr int IPT = (items + kBlock - 1) / kBlock;
     Cplx<TP> v[IPT][R];
 #pragma unroll
     for (int a = 0; a < IPT; a++) {
         const int w = tid + a * kBlock;
-        if (items % kBlock == 0 || w < items) pass_load<TP, LOG2N, R, NS, SIGN>(buf, tw, w, v[a]);
+        if (items % kBlock == 0 || w < items) pass_load<TP, LOG2N, R, NS, SIGN, LC>(buf, tw, w, v[a]);
     }
     __syncthreads();
 #pragma unroll
     for (int a = 0; a < IPT; a++) {
         const int w = tid + a * kBlock;
-        if (items % kBlock == 0 || w < items) pass_store<TP, LOG2N, R, NS>(buf, w, v[a]);
+        if (items % kBlock == 0 || w < items) pass_store<TP, LOG2N, R, NS, LC>(buf, w, v[a]);
     }
     __syncthreads();
 }
@@ -91,7 +95,8 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
                                                            const TP* __restrict__ lam_g, const TOut* __restrict__ dot_with,
                                                            double* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int n = 1 << LOG2N, L = kDctLines, total = n * L;
+    constexpr int LC = dct_lc<LOG2N>(), kFftRow = LC + 1, kFftLC = LC;
+    constexpr int n = 1 << LOG2N, L = 2 * LC, LOG2L = ilog2(L), total = n * L;
     constexpr int EPT = (total + kBlock - 1) / kBlock;  // elements per thread (n/16; 1 at n = 16)
     constexpr int CH = EPT < 16 ? EPT : 16;              // register chunk of the global <-> LDS copies
     Cplx<TP>* buf = reinterpret_cast<Cplx<TP>*>(smem);   // [n][kFftRow]
@@ -99,17 +104,17 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
     double* red = reinterpret_cast<double*>(tw_l + (dct_tw_in_lds<LOG2N>() ? n : 0));  // [8] block-reduction scratch
     const Cplx<TP>* tw = dct_tw_in_lds<LOG2N>() ? tw_l : tw_g;
     const int tid = threadIdx.x;
-    const int t = blockIdx.x;
+    const int t = (int)xcd_remap(blockIdx.x, gridDim.x);  // neighbouring tiles (adjacent x chunks of the same rows) share an XCD's L2
     const long long base_in = (long long)(t % P.tiles_a) * P.in.a_stride + (long long)(t / P.tiles_a) * P.in.b_stride;
     const long long base_out = (long long)(t % P.tiles_a) * P.out.a_stride + (long long)(t / P.tiles_a) * P.out.b_stride;
     if (dct_tw_in_lds<LOG2N>())
         for (int a = tid; a < n; a += kBlock) tw_l[a] = tw_g[a];
 
     // element index of the a-th element this thread moves: idx = tid + a*256
-    //   y/z sweeps: l = idx & 15 (consecutive lanes = consecutive lines = consecutive x), j = idx >> 4
+    //   y/z sweeps: l = idx & (L-1) (consecutive lanes = consecutive lines = consecutive x), j = idx >> log2(L)
     //   x sweep   : j = idx & (n-1) (consecutive lanes = consecutive x),                  l = idx >> LOG2N
     auto line_of = [&](int idx) { return XPASS ? (idx >> LOG2N) : (idx & (L - 1)); };
-    auto elem_of = [&](int idx) { return XPASS ? (idx & (n - 1)) : (idx >> 4); };
+    auto elem_of = [&](int idx) { return XPASS ? (idx & (n - 1)) : (idx >> LOG2L); };
 
     // ---------------- load: global -> registers (CH loads in flight) -> LDS ----------------
 #pragma unroll 1
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
         const int kx0 = (t % P.tiles_a) * L, ky = P.ky0 + t / P.tiles_a;
         constexpr int pairs = (n / 2 + 1) * kFftLC;
         for (int b = tid; b < pairs; b += kBlock) {
-            const int c = b & (kFftLC - 1), k = b >> 3;
+            const int c = b & (kFftLC - 1), k = b >> ilog2(kFftLC);
             const int nk = (n - k) & (n - 1);
             const Cplx<TP> omk = om_g[k], omn = om_g[nk];
             TP xa_k, xb_k, xa_n, xb_n;
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
     }
     if (DOT) {
         acc = block_sum(acc, red);
-        if (tid == 0) partials[blockIdx.x] = acc;
+        if (tid == 0) partials[t] = acc;
     }
 }
 

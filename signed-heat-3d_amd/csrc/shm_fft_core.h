@@ -1,7 +1,7 @@
 // In-LDS Stockham FFT building blocks shared by the device kernels (shm_dct.hip.h) and a host unit test
 // (tests/native/test_fft_core.cpp, compiled with g++): everything here is plain C++ marked SHM_HD.
 //
-// A batch of LC complex lines of length n lives in a tile  buf[j * ROW + c]  (j = element, c = line, ROW = LC+1:
+// A batch of LC complex lines (template parameter; 8, or 4 for n >= 512) of length n lives in a tile  buf[j * ROW + c]  (j = element, c = line, ROW = LC+1:
 // one complex of padding per row keeps the x-pass scatter off a single bank).  One pass of radix R reads R elements
 // per work item into registers, multiplies by the inter-pass twiddles, does a register DFT_R and writes back in
 // place (all reads of the tile happen before the barrier, all writes after it):
@@ -24,8 +24,7 @@ template <typename TP> SHM_HD Cplx<TP> cadd(Cplx<TP> a, Cplx<TP> b) { return {a.
 template <typename TP> SHM_HD Cplx<TP> csub(Cplx<TP> a, Cplx<TP> b) { return {a.x - b.x, a.y - b.y}; }
 template <typename TP> SHM_HD Cplx<TP> cconj(Cplx<TP> a) { return {a.x, -a.y}; }
 
-constexpr int kFftLC = 8;            // complex lines per tile (= 16 real lines, two per complex FFT)
-constexpr int kFftRow = kFftLC + 1;  // padded row length in complex elements
+constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 
 // 16th roots of unity: cos(2 pi k/16), sin(2 pi k/16), k = 0..7
 template <typename TP> SHM_HD Cplx<TP> root16(int k, int sign /* -1 forward, +1 inverse */) {
@@ -73,18 +72,18 @@ template <> struct FftPlan<9> { static constexpr int npass = 3; static constexpr
 template <> struct FftPlan<10> { static constexpr int npass = 3; static constexpr int R0 = 16, R1 = 8, R2 = 8; };
 
 // Work items of one pass: (n/R) butterflies x LC lines; item w -> line c = w % LC, butterfly jj = w / LC.
-template <int LOG2N, int R> struct PassGeom {
+template <int LOG2N, int R, int LC> struct PassGeom {
     static constexpr int n = 1 << LOG2N;
-    static constexpr int items = (n / R) * kFftLC;
+    static constexpr int items = (n / R) * LC;
 };
 
 // Phase 1 of a pass (before the barrier): gather + twiddle + register DFT for work item w.
-template <typename TP, int LOG2N, int R, int NS, int SIGN>
+template <typename TP, int LOG2N, int R, int NS, int SIGN, int LC>
 SHM_HD void pass_load(const Cplx<TP>* buf, const Cplx<TP>* tw /* [n]: e^{-2 pi i t/n} */, int w, Cplx<TP> (&v)[R]) {
     constexpr int n = 1 << LOG2N;
-    const int c = w & (kFftLC - 1), jj = w >> 3;
+    const int c = w & (LC - 1), jj = w >> ilog2(LC);
 #pragma unroll
-    for (int r = 0; r < R; r++) v[r] = buf[(jj + r * (n / R)) * kFftRow + c];
+    for (int r = 0; r < R; r++) v[r] = buf[(jj + r * (n / R)) * (LC + 1) + c];
     if (NS > 1) {
         const int k = jj & (NS - 1);
 #pragma unroll
@@ -98,13 +97,13 @@ SHM_HD void pass_load(const Cplx<TP>* buf, const Cplx<TP>* tw /* [n]: e^{-2 pi i
 }
 
 // Phase 2 of a pass (after the barrier): scatter.
-template <typename TP, int LOG2N, int R, int NS>
+template <typename TP, int LOG2N, int R, int NS, int LC>
 SHM_HD void pass_store(Cplx<TP>* buf, int w, const Cplx<TP> (&v)[R]) {
-    const int c = w & (kFftLC - 1), jj = w >> 3;
+    const int c = w & (LC - 1), jj = w >> ilog2(LC);
     const int k = jj & (NS - 1);
     const int j0 = (jj / NS) * NS * R + k;
 #pragma unroll
-    for (int r = 0; r < R; r++) buf[(j0 + r * NS) * kFftRow + c] = v[r];
+    for (int r = 0; r < R; r++) buf[(j0 + r * NS) * (LC + 1) + c] = v[r];
 }
 
 // Makhoul permutation: DCT-II of x = Re(om_k FFT(v)_k) with v[pj(j)] = x[j].

@@ -413,7 +413,7 @@ struct Solver final : SolverBase {
             // ghosts of p are read only where a neighbour exists, but zero everything once for hygiene
             HIPCHK(hipMemsetAsync(sl.p.p, 0, sl.ntot * sizeof(T), stream));
             HIPCHK(hipMemsetAsync(sl.Y2.p, 0, sl.ntot * sizeof(T), stream));
-            sl.partials.alloc(std::max<size_t>(kMaxPartials, (size_t)n * n / kDctLines + 8));
+            sl.partials.alloc(std::max<size_t>(kMaxPartials, (size_t)n * n / 8 + 8));
             sl.pq.alloc(1);
             sl.sc.alloc(SC_COUNT);
             HIPCHK(hipMemsetAsync(sl.sc.p, 0, SC_COUNT * sizeof(double), stream));
@@ -940,7 +940,8 @@ struct Solver final : SolverBase {
         const int P = total_slabs;
         const int nzl = n / P, nyl = n / P;  // planes per slab == pencil rows per slab (P | n)
         const double inv8 = 8.0 / ((double)n * n * n);
-        const int tiles_slab = (int)((long long)nzl * nn / kDctLines);  // 16-line tiles of one slab for the x and y sweeps
+        const int kDctLines = dct_lines_for(log2n);                      // real lines per tile (16, or 8 from n = 512 on)
+        const int tiles_slab = (int)((long long)nzl * nn / kDctLines);  // tiles of one slab for the x and y sweeps
         int log2nyl = 0;
         while ((1 << log2nyl) < nyl) log2nyl++;
         const long long blk = (long long)nzl * nyl * nn;

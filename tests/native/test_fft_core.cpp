@@ -10,19 +10,23 @@
 
 using namespace shm;
 typedef Cplx<double> C;
+#ifndef TEST_LC
+#define TEST_LC 8
+#endif
+constexpr int kFftLC = TEST_LC, kFftRow = TEST_LC + 1;
 
 template <int LOG2N, int R, int NS, int SIGN> static void run_pass(std::vector<C>& buf, const std::vector<C>& tw) {
-    constexpr int items = PassGeom<LOG2N, R>::items;
+    constexpr int items = PassGeom<LOG2N, R, kFftLC>::items;
     std::vector<C> regs((size_t)items * R);
     for (int w = 0; w < items; w++) {  // "before the barrier"
         C v[R];
-        pass_load<double, LOG2N, R, NS, SIGN>(buf.data(), tw.data(), w, v);
+        pass_load<double, LOG2N, R, NS, SIGN, kFftLC>(buf.data(), tw.data(), w, v);
         for (int r = 0; r < R; r++) regs[(size_t)w * R + r] = v[r];
     }
     for (int w = 0; w < items; w++) {  // "after the barrier"
         C v[R];
         for (int r = 0; r < R; r++) v[r] = regs[(size_t)w * R + r];
-        pass_store<double, LOG2N, R, NS>(buf.data(), w, v);
+        pass_store<double, LOG2N, R, NS, kFftLC>(buf.data(), w, v);
     }
 }
 
@@ -65,16 +69,17 @@ template <int LOG2N> static double test_n() {
             }
     }
     // ---- packed DCT-II then DCT-III: 16 real lines
-    std::vector<double> x((size_t)16 * n);
+    constexpr int NL = 2 * kFftLC;
+    std::vector<double> x((size_t)NL * n);
     for (auto& v : x) v = drand48() - 0.5;
     std::vector<C> buf((size_t)n * kFftRow);
-    for (int l = 0; l < 16; l++)
+    for (int l = 0; l < NL; l++)
         for (int j = 0; j < n; j++) {
             double* d = reinterpret_cast<double*>(&buf[(size_t)makhoul_slot(j, n) * kFftRow + (l >> 1)]);
             d[l & 1] = x[(size_t)l * n + j];
         }
     fft_tile<LOG2N, -1>(buf, tw);
-    std::vector<double> X((size_t)16 * n);
+    std::vector<double> X((size_t)NL * n);
     for (int c = 0; c < kFftLC; c++)
         for (int k = 0; k < n; k++) {
             double xa, xb;
@@ -82,7 +87,7 @@ template <int LOG2N> static double test_n() {
             X[(size_t)(2 * c) * n + k] = xa;
             X[(size_t)(2 * c + 1) * n + k] = xb;
         }
-    for (int l = 0; l < 16; l += 5)
+    for (int l = 0; l < NL; l += 5)
         for (int k = 0; k < n; k += (n > 64 ? 5 : 1)) {
             double s = 0;
             for (int j = 0; j < n; j++) s += x[(size_t)l * n + j] * std::cos(pi * (2 * j + 1) * k / (2. * n));
@@ -96,7 +101,7 @@ template <int LOG2N> static double test_n() {
                                                               X[(size_t)(2 * c + 1) * n + nk], om[k]);
         }
     fft_tile<LOG2N, +1>(buf, tw);
-    for (int l = 0; l < 16; l += 3)
+    for (int l = 0; l < NL; l += 3)
         for (int j = 0; j < n; j += (n > 64 ? 3 : 1)) {
             double s = 0;
             for (int k = 0; k < n; k++) s += X[(size_t)l * n + k] * std::cos(pi * (2 * j + 1) * k / (2. * n));

@@ -104,7 +104,7 @@ def test_projector(shm, case):
     assert np.abs(s.apply_projector(Atw)).max() < 1e-10 * np.abs(Atw).max()
 
 
-@pytest.mark.parametrize("n", [16, 32, 64, 128])
+@pytest.mark.parametrize("n", [16, 32, 64, 128, 256, 512])
 def test_preconditioner_is_the_dct_pseudo_inverse(shm, n):
     """M^-1 = C^T D C must equal the pseudo-inverse of K = -L (the 3-D DCT-II diagonalises the Neumann Laplacian):
     compared with scipy's orthonormal DCT on the host, and checked through K M^-1 v = v - mean(v)."""
