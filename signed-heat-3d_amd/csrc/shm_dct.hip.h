@@ -24,10 +24,11 @@
 namespace shm {
 
 enum DctMode : int { DCT_FWD = 0, DCT_INV = 1, DCT_FUSED = 2 };
-// complex lines per tile: 8 (16 real lines = one 128-byte row per element row) up to n = 256; 4 from n = 512 on, which halves the
-// tile's LDS footprint (37 KB fp64) so that four workgroups per CU overlap their load / FFT / store phases
-template <int LOG2N> constexpr int dct_lc() { return LOG2N >= 9 ? 4 : 8; }
-constexpr int dct_lines_for(int log2n) { return log2n >= 9 ? 8 : 16; }
+// complex lines per tile: 8 (16 real lines = one 128-byte row per element row); 4 at n = 1024, where an fp64 tile of 8 would take
+// 147 KB of LDS (one workgroup per CU).  (Measured at n = 512: 4 instead of 8 lines doubles the residency but halves the access
+// granularity to 64 bytes -- no net change, so 512 keeps the full 128-byte rows.)
+template <int LOG2N> constexpr int dct_lc() { return LOG2N >= 10 ? 4 : 8; }
+constexpr int dct_lines_for(int log2n) { return log2n >= 10 ? 8 : 16; }
 
 // Address of element k of line l of tile t:
 //   off + (t % tiles_a) a_stride + (t / tiles_a) b_stride + l line_stride + (k >> seg_shift) seg_stride + (k & seg_mask) elem_stride
