@@ -492,3 +492,18 @@ def test_isosurface_of_a_sphere_known_answer(shm):
     p0, p1, p2 = V[F[:, 0]], V[F[:, 1]], V[F[:, 2]]
     area = 0.5 * np.linalg.norm(np.cross(p1 - p0, p2 - p0), axis=1).sum()
     assert abs(area - 4 * math.pi) < 0.08 * 4 * math.pi
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("SHM_BIG_TESTS"), reason="1024^3 (~100 GB of HBM, minutes): set SHM_BIG_TESTS=1")
+def test_preconditioner_1024_property(shm):
+    """n = 1024 uses 8-line tiles and three Stockham passes: K M^-1 v = v - mean(v), checked with the independent stencil."""
+    d = load_golden("bunny_small_n16")
+    n = 1024
+    h = float(d["cell"]) * 15 / (n - 1)
+    s = shm.GridSolver()
+    s.set_problem(d["pos"], d["wnormal"], d["area"], float(d["lam"]), n, d["bbox_min"], h)
+    rng = np.random.default_rng(3)
+    v = rng.standard_normal(n ** 3)
+    got = s.apply_preconditioner(v)
+    Lg = s.apply_laplacian(got)
+    assert np.abs(-Lg - (v - v.mean())).max() < 1e-8 * np.abs(v).max()
