@@ -980,13 +980,13 @@ __global__ __launch_bounds__(kBlock) void gj_pivot_kernel(double* __restrict__ G
         for (int a = 0; a < 4; a++)
 #pragma unroll
             for (int b = 0; b < 4; b++) {
+                // branch-free selects (v_cndmask): a divergent if/else chain here cost ~1 us per elimination step
                 const bool ik = (ty * 4 + a) == k, jk = (tx * 4 + b) == k;
-                double v;
-                if (ik && jk) v = ip;
-                else if (ik) v = rv[b] * ip;
-                else if (jk) v = -cv[a] * ip;
-                else v = r[a][b] - cv[a] * rv[b] * ip;
-                r[a][b] = v;
+                const double rowv = rv[b] * ip, colv = -cv[a] * ip;
+                const double base = fma(-cv[a], rowv, r[a][b]);
+                const double vk = jk ? ip : rowv;
+                const double vn = jk ? colv : base;
+                r[a][b] = ik ? vk : vn;
             }
     }
 #pragma unroll
