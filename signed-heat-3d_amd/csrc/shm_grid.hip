@@ -76,10 +76,12 @@ struct Rccl {
         return r;
     }
     void load() {
-        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // SHM_RCCL_LIB: tests substitute a shared-memory double (tests/native/rccl_mock.c) to run several ranks on one GPU
+        const char* override_lib = getenv("SHM_RCCL_LIB");
+        const char* names[] = {override_lib ? override_lib : "librccl.so.1", "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* nm : names) {
-            h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-            if (h) break;
+            h = dlopen(nm, RTLD_NOW | (override_lib ? RTLD_LOCAL : RTLD_GLOBAL));
+            if (h || override_lib) break;
         }
         if (!h) throw Error(SHM_ERR_RCCL, std::string("cannot load librccl: ") + dlerror());
 #define SYM(field, name)                                                                    \

@@ -507,3 +507,35 @@ def test_preconditioner_1024_property(shm):
     got = s.apply_preconditioner(v)
     Lg = s.apply_laplacian(got)
     assert np.abs(-Lg - (v - v.mean())).max() < 1e-8 * np.abs(v).max()
+
+
+# ---- several PROCESSES (ranks) on one GPU through a shared-memory double of librccl --------------------------------------
+@pytest.mark.parametrize("world,mode", [(2, "dual"), (4, "dual"), (2, "primal-plain"), (2, "primal-dct"), (4, "fast")])
+def test_multiprocess_ranks_on_one_gpu(shm, tmp_path, world, mode):
+    """The real multi-rank code path (rank-major z-slabs, halo send/recv, all-reduces, the all-to-all transposes of the distributed
+    DCT, the slab-chained fast integration) with one process per rank.  RCCL refuses two ranks on one device, so its nine entry
+    points are replaced by tests/native/rccl_mock.c (SHM_RCCL_LIB) -- everything above the transport is the product code."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    so = str(tmp_path / "librccl_mock.so")
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", os.path.join(ROOT, "tests", "native", "rccl_mock.c"), "-o", so, "-I/opt/rocm/include",
+                           "-D__HIP_PLATFORM_AMD__", "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread"])
+    case = "bunny_small_fast_n32" if mode == "fast" else "bunny_small_n32"
+    uid = ("/shmmock_%d_%s_%d" % (os.getpid(), mode.replace("-", ""), world)).encode().ljust(128, b"\\0")
+    env = dict(os.environ, SHM_RCCL_LIB=so)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multiproc_worker.py"), str(r), str(world), uid.hex(), case, mode, str(tmp_path)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\\n".join(outs)
+    d = load_golden(case)
+    parts, covered = [], 0
+    for r in range(world):
+        k0, k1, iters, shift = np.load(tmp_path / ("meta_%d.npy" % r))
+        assert int(k0) == covered
+        covered = int(k1)
+        parts.append(np.load(tmp_path / ("phi_%d.npy" % r)))
+        assert abs(shift - float(d["shift"])) < 1e-7
+    assert covered == 32
+    assert np.abs(np.concatenate(parts) - d["phi"]).max() < (1e-9 if mode == "fast" else 1e-7)
