@@ -523,12 +523,12 @@ def test_multiprocess_ranks_on_one_gpu(shm, tmp_path, world, mode):
     subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", os.path.join(ROOT, "tests", "native", "rccl_mock.c"), "-o", so, "-I/opt/rocm/include",
                            "-D__HIP_PLATFORM_AMD__", "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread"])
     case = "bunny_small_fast_n32" if mode == "fast" else "bunny_small_n32"
-    uid = ("/shmmock_%d_%s_%d" % (os.getpid(), mode.replace("-", ""), world)).encode().ljust(128, b"\\0")
+    uid = ("/shmmock_%d_%s_%d" % (os.getpid(), mode.replace("-", ""), world)).encode().ljust(128, b"\x00")
     env = dict(os.environ, SHM_RCCL_LIB=so)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multiproc_worker.py"), str(r), str(world), uid.hex(), case, mode, str(tmp_path)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
-    assert all(p.returncode == 0 for p in procs), "\\n".join(outs)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     d = load_golden(case)
     parts, covered = [], 0
     for r in range(world):
