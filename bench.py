@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precond", default="auto", choices=["auto", "none", "dct"])
     ap.add_argument("--solver", default="auto", choices=["auto", "primal", "dual"])
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the bootstrap/timing collectives (gloo + SHM_RCCL_LIB + SHM_BENCH_ONE_DEVICE=1 lets "
+                         "several ranks share one GPU in tests)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -132,6 +135,8 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    if os.environ.get("SHM_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
 
     import shm_import
@@ -141,7 +146,10 @@ def main():
     uid = None
     if world > 1 or os.environ.get("SHM_BENCH_FORCE_DIST"):  # the env knob exercises the RCCL bootstrap with one rank
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
         box = [shm.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         uid = box[0]
@@ -173,7 +181,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist.is_initialized():
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -539,3 +539,26 @@ def test_multiprocess_ranks_on_one_gpu(shm, tmp_path, world, mode):
         assert abs(shift - float(d["shift"])) < 1e-7
     assert covered == 32
     assert np.abs(np.concatenate(parts) - d["phi"]).max() < (1e-9 if mode == "fast" else 1e-7)
+
+
+def test_bench_py_multi_rank_flow_on_one_gpu(tmp_path):
+    """bench.py launched the way the driver launches it for N>1 (torch.distributed.run, one process per rank), with the ranks sharing
+    the one GPU of the test box: gloo for the bootstrap collectives and the shared-memory double for the solver's RCCL calls."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    so = str(tmp_path / "librccl_mock.so")
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", os.path.join(ROOT, "tests", "native", "rccl_mock.c"), "-o", so, "-I/opt/rocm/include",
+                           "-D__HIP_PLATFORM_AMD__", "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread"])
+    env = dict(os.environ, SHM_RCCL_LIB=so, SHM_BENCH_ONE_DEVICE="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29600 + os.getpid() % 300), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--workload", "bunny_small_64_f64", "--dist-backend", "gloo"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["grid"] == "64^3" and d["value"] > 0 and d["scaling"] == "strong"
+    assert "roofline" in d and "cpu_baseline" not in d     # the CPU baseline is an N=1 leg
