@@ -197,7 +197,7 @@ struct Solver final : SolverBase {
     double bbox_min[3] = {0, 0, 0};
     int64_t S = 0;
     std::vector<double> h_pos, h_wn, h_area;
-    double area_sum = 0., conv_far_gap = 0.;
+    double area_sum = 0., conv_far_gap = 0., last_host_setup_ms = 0.;
     int n_clusters = 0;
     int conv_grid_cap = 1 << 30;
     DevArray<T> d_src;          // [Spad][6] Morton-sorted, padded to whole clusters
@@ -575,6 +575,7 @@ struct Solver final : SolverBase {
     // Per-slab CSR pieces, shift items, and G = A A^T (sparse triplets -> dense on device -> inverted).
     void build_constraints() {
         hipStream_t stream = stream2;  // everything below runs beside the Step-1 kernel of the main stream
+        const auto th0 = std::chrono::steady_clock::now();
         build_rows();
         build_shift_items(stream);
         const size_t plane = (size_t)n * n;
@@ -621,21 +622,46 @@ struct Solver final : SolverBase {
             sl.u.alloc((size_t)std::max(m, 1));
             sl.dv.alloc((size_t)7 * std::max(mp, 64));
         }
-        // ---- G = A A^T as triplets via a node -> entries map
-        std::unordered_map<int64_t, std::vector<std::pair<int, double>>> node_map;
-        node_map.reserve((size_t)m * 4);
+        // ---- G = A A^T and B = A K A^T from the (node, row, coef) entries sorted by node: rows meet exactly at shared nodes.
+        //      Sorted vectors instead of hash maps: the host part of the set-up is on the critical path of small / multi-GPU runs.
+        struct Ent { int64_t node; int row; double coef; };
+        std::vector<Ent> ents((size_t)8 * m);
         for (int r = 0; r < m; r++)
-            for (int e = 0; e < 8; e++) node_map[rows[r].nodes[e]].push_back({r, rows[r].coeffs[e]});
-        {   // B = A K A^T: K a_i is supported on the 8 cell corners and their in-grid neighbours
-            std::vector<int> bptr(m + 1, 0), bcol;
-            std::vector<double> bval;
+            for (int e = 0; e < 8; e++) ents[(size_t)8 * r + e] = {rows[r].nodes[e], r, rows[r].coeffs[e]};
+        std::sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.node != y.node ? x.node < y.node : x.row < y.row; });
+        std::vector<int64_t> unode;       // distinct touched nodes, ascending
+        std::vector<int> ustart;          // their entry ranges in `ents`
+        for (size_t e = 0; e < ents.size(); e++)
+            if (e == 0 || ents[e].node != ents[e - 1].node) {
+                unode.push_back(ents[e].node);
+                ustart.push_back((int)e);
+            }
+        ustart.push_back((int)ents.size());
+        typedef std::pair<uint64_t, double> Trip;
+        auto compact = [](std::vector<Trip>& t) {  // sort by key and add up duplicates
+            std::sort(t.begin(), t.end(), [](const Trip& x, const Trip& y) { return x.first < y.first; });
+            size_t w = 0;
+            for (size_t e = 0; e < t.size(); e++) {
+                if (w > 0 && t[w - 1].first == t[e].first) t[w - 1].second += t[e].second;
+                else t[w++] = t[e];
+            }
+            t.resize(w);
+        };
+        std::vector<Trip> gt;
+        gt.reserve((size_t)m * 48);
+        for (size_t u = 0; u < unode.size(); u++)
+            for (int x = ustart[u]; x < ustart[u + 1]; x++)
+                for (int y = ustart[u]; y < ustart[u + 1]; y++)
+                    gt.push_back({(uint64_t)ents[x].row * (uint64_t)mp + (uint64_t)ents[y].row, ents[x].coef * ents[y].coef});
+        compact(gt);
+        {   // B = A K A^T: K a_r is supported on the 8 cell corners of row r and their in-grid neighbours (<= 56 nodes)
+            std::vector<Trip> bt;
+            bt.reserve((size_t)m * 160);
             const double ih2 = 1. / (cell * cell);
             const int64_t nn = n, pl = (int64_t)n * n;
-            std::unordered_map<int64_t, double> ka;
-            std::unordered_map<int, double> brow;
+            std::pair<int64_t, double> ka[56];
             for (int r = 0; r < m; r++) {
-                ka.clear();
-                brow.clear();
+                int nk = 0;
                 for (int e = 0; e < 8; e++) {
                     const int64_t c = rows[r].nodes[e];
                     const double cf = rows[r].coeffs[e];
@@ -643,42 +669,43 @@ struct Solver final : SolverBase {
                     const int64_t nb[6] = {i > 0 ? c - 1 : -1, i < nn - 1 ? c + 1 : -1, j > 0 ? c - nn : -1, j < nn - 1 ? c + nn : -1,
                                            k > 0 ? c - pl : -1, k < nn - 1 ? c + pl : -1};
                     int deg = 0;
-                    for (int a = 0; a < 6; a++)
-                        if (nb[a] >= 0) {
+                    for (int q = 0; q < 6; q++)
+                        if (nb[q] >= 0) {
                             deg++;
-                            ka[nb[a]] -= cf * ih2;
+                            ka[nk++] = {nb[q], -cf * ih2};
                         }
-                    ka[c] += deg * cf * ih2;
+                    ka[nk++] = {c, deg * cf * ih2};
                 }
-                for (const auto& kv : ka) {
-                    auto itn = node_map.find(kv.first);
-                    if (itn == node_map.end()) continue;
-                    for (const auto& oc : itn->second) brow[oc.first] += kv.second * oc.second;
+                for (int q = 0; q < nk; q++) {
+                    const auto it = std::lower_bound(unode.begin(), unode.end(), ka[q].first);
+                    if (it == unode.end() || *it != ka[q].first) continue;  // K a_r reaches a node no constraint row touches
+                    const size_t u = (size_t)(it - unode.begin());
+                    for (int y = ustart[u]; y < ustart[u + 1]; y++)
+                        bt.push_back({(uint64_t)r * (uint64_t)mp + (uint64_t)ents[y].row, ka[q].second * ents[y].coef});
                 }
-                for (const auto& kv : brow) {
-                    bcol.push_back(kv.first);
-                    bval.push_back(kv.second);
-                }
-                bptr[r + 1] = (int)bcol.size();
             }
+            compact(bt);
+            std::vector<int> bptr(m + 1, 0), bcol(bt.size());
+            std::vector<double> bval(bt.size());
+            for (size_t e = 0; e < bt.size(); e++) {
+                bptr[(size_t)(bt[e].first / (uint64_t)mp) + 1]++;
+                bcol[e] = (int)(bt[e].first % (uint64_t)mp);
+                bval[e] = bt[e].second;
+            }
+            for (int r = 0; r < m; r++) bptr[r + 1] += bptr[r];
             Bptr.upload(bptr, stream);
             Bcol.upload(bcol, stream);
             Bval.upload(bval, stream);
             have_B = true;
         }
-        std::unordered_map<uint64_t, double> gmap;
-        gmap.reserve((size_t)m * 32);
-        for (int r = 0; r < m; r++)
-            for (int e = 0; e < 8; e++)
-                for (const auto& oc : node_map[rows[r].nodes[e]]) gmap[(uint64_t)r * (uint64_t)mp + (uint64_t)oc.first] += rows[r].coeffs[e] * oc.second;
         Ginv.alloc((size_t)mp * mp);
         HIPCHK(hipMemsetAsync(Ginv.p, 0, (size_t)mp * mp * sizeof(double), stream));
-        // scatter the (few) non-zeros with 2D copies row by row would be slow; upload triplets and scatter
+        // upload the (few) non-zeros as triplets and scatter them into the dense matrix on the device
         std::vector<uint64_t> tidx;
         std::vector<double> tval;
-        tidx.reserve(gmap.size() + (mp - m));
-        tval.reserve(gmap.size() + (mp - m));
-        for (const auto& kv : gmap) {
+        tidx.reserve(gt.size() + (mp - m));
+        tval.reserve(gt.size() + (mp - m));
+        for (const Trip& kv : gt) {
             tidx.push_back(kv.first);
             tval.push_back(kv.second);
         }
@@ -693,6 +720,8 @@ struct Solver final : SolverBase {
         hipLaunchKernelGGL(scatter_triplets_kernel, dim3(grid_for(tidx.size(), 4096)), dim3(kBlock), 0, stream, (size_t)tidx.size(), d_tidx.p,
                            d_tval.p, Ginv.p);
         HIPCHK(hipGetLastError());
+        last_host_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
+        log("[shm] constraint set-up: host part %.2f ms (m=%d)", last_host_setup_ms, m);
         invert_G();
         upload_red_tables(stream);
         HIPCHK(hipStreamSynchronize(stream));  // d_tidx/d_tval and ptrs go out of scope
