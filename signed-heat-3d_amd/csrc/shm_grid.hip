@@ -576,8 +576,11 @@ struct Solver final : SolverBase {
     void build_constraints() {
         hipStream_t stream = stream2;  // everything below runs beside the Step-1 kernel of the main stream
         const auto th0 = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) { log("[shm]   setup %-28s %.2f ms", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count()); };
         build_rows();
+        lap("rows");
         build_shift_items(stream);
+        lap("shift items");
         const size_t plane = (size_t)n * n;
         for (Slab<T>& sl : slabs) {
             const int64_t lo = (int64_t)sl.k0 * (int64_t)plane, hi = (int64_t)sl.k1 * (int64_t)plane;
@@ -622,6 +625,7 @@ struct Solver final : SolverBase {
             sl.u.alloc((size_t)std::max(m, 1));
             sl.dv.alloc((size_t)7 * std::max(mp, 64));
         }
+        lap("per-slab lists");
         // ---- G = A A^T and B = A K A^T from the (node, row, coef) entries sorted by node: rows meet exactly at shared nodes.
         //      Sorted vectors instead of hash maps: the host part of the set-up is on the critical path of small / multi-GPU runs.
         struct Ent { int64_t node; int row; double coef; };
@@ -637,31 +641,66 @@ struct Solver final : SolverBase {
                 ustart.push_back((int)e);
             }
         ustart.push_back((int)ents.size());
-        typedef std::pair<uint64_t, double> Trip;
-        auto compact = [](std::vector<Trip>& t) {  // sort by key and add up duplicates
-            std::sort(t.begin(), t.end(), [](const Trip& x, const Trip& y) { return x.first < y.first; });
-            size_t w = 0;
-            for (size_t e = 0; e < t.size(); e++) {
-                if (w > 0 && t[w - 1].first == t[e].first) t[w - 1].second += t[e].second;
-                else t[w++] = t[e];
+        lap("sorted entries");
+        // row by row with a dense scatter-accumulate scratch (value + owner stamp per column): no sorting, no hashing; the
+        // column order inside a CSR row is irrelevant for the mat-vec
+        // node -> group through a small open-addressing table (binary searching 56 stencil nodes per row dominated the set-up)
+        size_t hbits = 4;
+        while (((size_t)1 << hbits) < 4 * unode.size() + 16) hbits++;
+        const size_t hmask = ((size_t)1 << hbits) - 1;
+        std::vector<int64_t> hkey((size_t)1 << hbits, -1);
+        std::vector<int> hval((size_t)1 << hbits, -1);
+        auto hslot = [&](int64_t node) { return (size_t)(((uint64_t)node * 0x9E3779B97F4A7C15ULL) >> (64 - hbits)) & hmask; };
+        for (size_t u = 0; u < unode.size(); u++) {
+            size_t h = hslot(unode[u]);
+            while (hkey[h] >= 0) h = (h + 1) & hmask;
+            hkey[h] = unode[u];
+            hval[h] = (int)u;
+        }
+        auto group_of = [&](int64_t node) -> int {
+            size_t h = hslot(node);
+            while (hkey[h] >= 0) {
+                if (hkey[h] == node) return hval[h];
+                h = (h + 1) & hmask;
             }
-            t.resize(w);
+            return -1;
         };
-        std::vector<Trip> gt;
-        gt.reserve((size_t)m * 48);
-        for (size_t u = 0; u < unode.size(); u++)
-            for (int x = ustart[u]; x < ustart[u + 1]; x++)
-                for (int y = ustart[u]; y < ustart[u + 1]; y++)
-                    gt.push_back({(uint64_t)ents[x].row * (uint64_t)mp + (uint64_t)ents[y].row, ents[x].coef * ents[y].coef});
-        compact(gt);
-        {   // B = A K A^T: K a_r is supported on the 8 cell corners of row r and their in-grid neighbours (<= 56 nodes)
-            std::vector<Trip> bt;
-            bt.reserve((size_t)m * 160);
+        std::vector<double> accv((size_t)m, 0.);
+        std::vector<int> stamp((size_t)m, -1), cols;
+        auto add = [&](int tag, int col, double v) {
+            if (stamp[(size_t)col] != tag) {
+                stamp[(size_t)col] = tag;
+                accv[(size_t)col] = v;
+                cols.push_back(col);
+            } else {
+                accv[(size_t)col] += v;
+            }
+        };
+        std::vector<uint64_t> tidx;
+        std::vector<double> tval;
+        tidx.reserve((size_t)m * 32 + (mp - m));
+        tval.reserve((size_t)m * 32 + (mp - m));
+        std::vector<int> bptr(m + 1, 0), bcol;
+        std::vector<double> bval;
+        bcol.reserve((size_t)m * 128);
+        bval.reserve((size_t)m * 128);
+        {
             const double ih2 = 1. / (cell * cell);
             const int64_t nn = n, pl = (int64_t)n * n;
-            std::pair<int64_t, double> ka[56];
             for (int r = 0; r < m; r++) {
-                int nk = 0;
+                int ug[8];
+                // G = A A^T: rows sharing a node with row r
+                cols.clear();
+                for (int e = 0; e < 8; e++) {
+                    ug[e] = group_of(rows[r].nodes[e]);
+                    for (int y = ustart[ug[e]]; y < ustart[ug[e] + 1]; y++) add(2 * r, ents[y].row, rows[r].coeffs[e] * ents[y].coef);
+                }
+                for (int c : cols) {
+                    tidx.push_back((uint64_t)r * (uint64_t)mp + (uint64_t)c);
+                    tval.push_back(accv[(size_t)c]);
+                }
+                // B = A K A^T: K a_r lives on the 8 corners and their in-grid neighbours
+                cols.clear();
                 for (int e = 0; e < 8; e++) {
                     const int64_t c = rows[r].nodes[e];
                     const double cf = rows[r].coeffs[e];
@@ -669,30 +708,22 @@ struct Solver final : SolverBase {
                     const int64_t nb[6] = {i > 0 ? c - 1 : -1, i < nn - 1 ? c + 1 : -1, j > 0 ? c - nn : -1, j < nn - 1 ? c + nn : -1,
                                            k > 0 ? c - pl : -1, k < nn - 1 ? c + pl : -1};
                     int deg = 0;
-                    for (int q = 0; q < 6; q++)
-                        if (nb[q] >= 0) {
-                            deg++;
-                            ka[nk++] = {nb[q], -cf * ih2};
-                        }
-                    ka[nk++] = {c, deg * cf * ih2};
+                    for (int q = 0; q < 6; q++) {
+                        if (nb[q] < 0) continue;
+                        deg++;
+                        const int ub = group_of(nb[q]);
+                        if (ub < 0) continue;  // K a_r reaches a node no constraint row touches
+                        for (int y = ustart[ub]; y < ustart[ub + 1]; y++) add(2 * r + 1, ents[y].row, -cf * ih2 * ents[y].coef);
+                    }
+                    for (int y = ustart[ug[e]]; y < ustart[ug[e] + 1]; y++) add(2 * r + 1, ents[y].row, deg * cf * ih2 * ents[y].coef);
                 }
-                for (int q = 0; q < nk; q++) {
-                    const auto it = std::lower_bound(unode.begin(), unode.end(), ka[q].first);
-                    if (it == unode.end() || *it != ka[q].first) continue;  // K a_r reaches a node no constraint row touches
-                    const size_t u = (size_t)(it - unode.begin());
-                    for (int y = ustart[u]; y < ustart[u + 1]; y++)
-                        bt.push_back({(uint64_t)r * (uint64_t)mp + (uint64_t)ents[y].row, ka[q].second * ents[y].coef});
+                for (int c : cols) {
+                    bcol.push_back(c);
+                    bval.push_back(accv[(size_t)c]);
                 }
+                bptr[r + 1] = (int)bcol.size();
             }
-            compact(bt);
-            std::vector<int> bptr(m + 1, 0), bcol(bt.size());
-            std::vector<double> bval(bt.size());
-            for (size_t e = 0; e < bt.size(); e++) {
-                bptr[(size_t)(bt[e].first / (uint64_t)mp) + 1]++;
-                bcol[e] = (int)(bt[e].first % (uint64_t)mp);
-                bval[e] = bt[e].second;
-            }
-            for (int r = 0; r < m; r++) bptr[r + 1] += bptr[r];
+            lap("G and B rows");
             Bptr.upload(bptr, stream);
             Bcol.upload(bcol, stream);
             Bval.upload(bval, stream);
@@ -700,15 +731,6 @@ struct Solver final : SolverBase {
         }
         Ginv.alloc((size_t)mp * mp);
         HIPCHK(hipMemsetAsync(Ginv.p, 0, (size_t)mp * mp * sizeof(double), stream));
-        // upload the (few) non-zeros as triplets and scatter them into the dense matrix on the device
-        std::vector<uint64_t> tidx;
-        std::vector<double> tval;
-        tidx.reserve(gt.size() + (mp - m));
-        tval.reserve(gt.size() + (mp - m));
-        for (const Trip& kv : gt) {
-            tidx.push_back(kv.first);
-            tval.push_back(kv.second);
-        }
         for (int a = m; a < mp; a++) {  // identity tail keeps the padded matrix SPD
             tidx.push_back((uint64_t)a * mp + a);
             tval.push_back(1.0);
@@ -720,6 +742,7 @@ struct Solver final : SolverBase {
         hipLaunchKernelGGL(scatter_triplets_kernel, dim3(grid_for(tidx.size(), 4096)), dim3(kBlock), 0, stream, (size_t)tidx.size(), d_tidx.p,
                            d_tval.p, Ginv.p);
         HIPCHK(hipGetLastError());
+        lap("uploads");
         last_host_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
         log("[shm] constraint set-up: host part %.2f ms (m=%d)", last_host_setup_ms, m);
         invert_G();
