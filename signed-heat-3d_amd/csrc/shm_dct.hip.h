@@ -94,7 +94,7 @@ template <typename TP, typename TIn, typename TOut, int MODE, bool DOT, int LOG2
 __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TIn* __restrict__ in, TOut* __restrict__ out,
                                                            const Cplx<TP>* __restrict__ tw_g, const Cplx<TP>* __restrict__ om_g,
                                                            const TP* __restrict__ lam_g, const TOut* __restrict__ dot_with,
-                                                           double* __restrict__ partials) {
+                                                           double* __restrict__ partials, const int* __restrict__ tile_list /* nullptr: all tiles */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int LC = dct_lc<LOG2N>(), kFftRow = LC + 1, kFftLC = LC;
     constexpr int n = 1 << LOG2N, L = 2 * LC, LOG2L = ilog2(L), total = n * L;
@@ -105,7 +105,8 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
     double* red = reinterpret_cast<double*>(tw_l + (dct_tw_in_lds<LOG2N>() ? n : 0));  // [8] block-reduction scratch
     const Cplx<TP>* tw = dct_tw_in_lds<LOG2N>() ? tw_l : tw_g;
     const int tid = threadIdx.x;
-    const int t = (int)xcd_remap(blockIdx.x, gridDim.x);  // neighbouring tiles (adjacent x chunks of the same rows) share an XCD's L2
+    const int lb = (int)xcd_remap(blockIdx.x, gridDim.x);  // neighbouring tiles (adjacent x chunks of the same rows) share an XCD's L2
+    const int t = tile_list ? tile_list[lb] : lb;          // sparse sweeps visit only the tiles that can hold non-zeros / needed outputs
     const long long base_in = (long long)(t % P.tiles_a) * P.in.a_stride + (long long)(t / P.tiles_a) * P.in.b_stride;
     const long long base_out = (long long)(t % P.tiles_a) * P.out.a_stride + (long long)(t / P.tiles_a) * P.out.b_stride;
     if (dct_tw_in_lds<LOG2N>())

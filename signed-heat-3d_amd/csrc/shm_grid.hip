@@ -182,6 +182,9 @@ struct Slab {
     DevArray<ShiftItem> shift_items;
     DevArray<double> dv;  // dual solver m-vectors: mu, r, p, z, t1, t2, g (7 x mp)
     DevArray<T> W1, W2;  // DCT work arrays (precision TP == T); W2 only with several slabs (packed transposes)
+    DevArray<T> S1, S2, S4;  // sparse-sweep buffers of the dual solver's per-iteration solve (single slab)
+    DevArray<int> act_x, act_y;  // active tiles of the x sweeps / y sweeps
+    int n_act_x = 0, n_act_y = 0;
     int n_touched = 0, n_shift = 0;
     GridParams gp{};
 };
@@ -203,6 +206,7 @@ struct Solver final : SolverBase {
     DevArray<T> d_src;          // [Spad][6] Morton-sorted, padded to whole clusters
     DevArray<float> d_src32;    // same in fp32 (far clusters of the fp64 path)
     DevArray<float> d_clusters; // [n_clusters][4] bounding spheres
+    DevArray<double> d_exptab;  // 2^(j/2048), j < 2048 (Step 1 fp64 exponential)
     std::vector<Slab<T>> slabs;
     int total_slabs = 1, first_slab = 0;
     bool have_problem = false, have_conv = false, have_div = false, have_phi = false, have_constraints = false;
@@ -389,6 +393,11 @@ struct Solver final : SolverBase {
             d_src.upload(packed, stream);
             d_src32.upload(packed32, stream);
             d_clusters.upload(cl, stream);
+            if (!d_exptab.p) {
+                std::vector<double> tab(2048);
+                for (int j = 0; j < 2048; j++) tab[(size_t)j] = std::exp2((double)j / 2048.0);
+                d_exptab.upload(tab, stream);
+            }
             HIPCHK(hipStreamSynchronize(stream));
         }
 
@@ -448,19 +457,30 @@ struct Solver final : SolverBase {
             for (int a = 0; a < 3; a++) P.bbox_min[a] = bbox_min[a];
             P.cell = cell;
             P.lambda = lambda;
+            P.cexp = -lambda * 2954.639443740597;  // 2048 / ln 2
             P.S = n_clusters * kConvCluster;
             P.n_clusters = n_clusters;
             P.far_gap = (float)conv_far_gap;
-            P.exact_offset = (lambda * 14.0 * cell > 30.0) ? 1 : 0;  // tile-diameter bound looser than e^-30: per-node offsets
             P.tiles_x = (n + kConvTile - 1) / kConvTile;
             P.tiles_y = P.tiles_x;
-            const int tiles_z = (P.kk_end - P.kk_begin + kConvTile - 1) / kConvTile;
-            constexpr int NPT = 2;
+            // nodes per lane (a z-column sharing dx^2 + dy^2): 4 when the grid still yields a full wave of workgroups, else 2;
+            // the fp32 kernel keeps 2 (its per-tile exponent offset wants compact tiles)
+            const int planes = P.kk_end - P.kk_begin;
+            const bool npt4 = sizeof(T) == 8 && (long long)P.tiles_x * P.tiles_y * ((planes + 15) / 16) >= conv_grid_cap;
+            const int tile_z = npt4 ? 16 : 8;
+            const double half_z = 0.5 * (tile_z - 1);
+            const double tile_diam = 2.0 * std::sqrt(2 * 3.5 * 3.5 + half_z * half_z) * cell;
+            P.exact_offset = (lambda * tile_diam > 30.0) ? 1 : 0;  // tile-diameter bound looser than e^-30: per-node offsets
+            const int tiles_z = (planes + tile_z - 1) / tile_z;
             P.n_tiles = P.tiles_x * P.tiles_y * tiles_z;
             // fewer workgroups than the chip has slots (4 per CU by LDS): the set-up stream's kernels find room beside Step 1
             const unsigned grid = (unsigned)std::min(P.n_tiles, conv_grid_cap);
-            hipLaunchKernelGGL((conv_normalize_kernel<T, NPT>), dim3(grid), dim3(kBlock), 0, stream, P, d_src.p, d_src32.p, d_clusters.p, sl.Y0.p, sl.Y1.p,
-                               sl.Y2.p);
+            if (npt4)
+                hipLaunchKernelGGL((conv_normalize_kernel<T, 4>), dim3(grid), dim3(kBlock), 0, stream, P, d_src.p, d_src32.p, d_clusters.p, d_exptab.p, sl.Y0.p,
+                                   sl.Y1.p, sl.Y2.p);
+            else
+                hipLaunchKernelGGL((conv_normalize_kernel<T, 2>), dim3(grid), dim3(kBlock), 0, stream, P, d_src.p, d_src32.p, d_clusters.p, d_exptab.p, sl.Y0.p,
+                                   sl.Y1.p, sl.Y2.p);
         }
         HIPCHK(hipGetLastError());
         have_conv = true;
@@ -724,6 +744,7 @@ struct Solver final : SolverBase {
                 bptr[r + 1] = (int)bcol.size();
             }
             lap("G and B rows");
+            if (total_slabs == 1 && precond_available()) build_active_tiles(unode);
             Bptr.upload(bptr, stream);
             Bcol.upload(bcol, stream);
             Bval.upload(bval, stream);
@@ -916,7 +937,7 @@ struct Solver final : SolverBase {
     }
 
     template <int MODE, typename TIn, typename TOut, bool DOT, int LOG2N, bool XPASS>
-    void launch_dct_n(const DctParams& P, int ntiles, const TIn* in, TOut* out, const TOut* dotw, double* partials) {
+    void launch_dct_n(const DctParams& P, int ntiles, const TIn* in, TOut* out, const TOut* dotw, double* partials, const int* tile_list) {
         auto kern = dct_lines_kernel<TP, TIn, TOut, MODE, DOT, LOG2N, XPASS>;
         static bool configured = false;  // per instantiation
         constexpr size_t lds = dct_lds_bytes<LOG2N>(sizeof(Cplx<TP>));
@@ -924,18 +945,18 @@ struct Solver final : SolverBase {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             configured = true;
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(kBlock), lds, stream, P, in, out, d_tw.p, d_om.p, d_lam.p, dotw, partials);
+        hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(kBlock), lds, stream, P, in, out, d_tw.p, d_om.p, d_lam.p, dotw, partials, tile_list);
     }
     template <int MODE, typename TIn, typename TOut, bool DOT, bool XPASS>
-    void launch_dct(const DctParams& P, int ntiles, const TIn* in, TOut* out, const TOut* dotw, double* partials) {
+    void launch_dct(const DctParams& P, int ntiles, const TIn* in, TOut* out, const TOut* dotw, double* partials, const int* tile_list = nullptr) {
         switch (log2n) {
-            case 4: launch_dct_n<MODE, TIn, TOut, DOT, 4, XPASS>(P, ntiles, in, out, dotw, partials); break;
-            case 5: launch_dct_n<MODE, TIn, TOut, DOT, 5, XPASS>(P, ntiles, in, out, dotw, partials); break;
-            case 6: launch_dct_n<MODE, TIn, TOut, DOT, 6, XPASS>(P, ntiles, in, out, dotw, partials); break;
-            case 7: launch_dct_n<MODE, TIn, TOut, DOT, 7, XPASS>(P, ntiles, in, out, dotw, partials); break;
-            case 8: launch_dct_n<MODE, TIn, TOut, DOT, 8, XPASS>(P, ntiles, in, out, dotw, partials); break;
-            case 9: launch_dct_n<MODE, TIn, TOut, DOT, 9, XPASS>(P, ntiles, in, out, dotw, partials); break;
-            case 10: launch_dct_n<MODE, TIn, TOut, DOT, 10, XPASS>(P, ntiles, in, out, dotw, partials); break;
+            case 4: launch_dct_n<MODE, TIn, TOut, DOT, 4, XPASS>(P, ntiles, in, out, dotw, partials, tile_list); break;
+            case 5: launch_dct_n<MODE, TIn, TOut, DOT, 5, XPASS>(P, ntiles, in, out, dotw, partials, tile_list); break;
+            case 6: launch_dct_n<MODE, TIn, TOut, DOT, 6, XPASS>(P, ntiles, in, out, dotw, partials, tile_list); break;
+            case 7: launch_dct_n<MODE, TIn, TOut, DOT, 7, XPASS>(P, ntiles, in, out, dotw, partials, tile_list); break;
+            case 8: launch_dct_n<MODE, TIn, TOut, DOT, 8, XPASS>(P, ntiles, in, out, dotw, partials, tile_list); break;
+            case 9: launch_dct_n<MODE, TIn, TOut, DOT, 9, XPASS>(P, ntiles, in, out, dotw, partials, tile_list); break;
+            case 10: launch_dct_n<MODE, TIn, TOut, DOT, 10, XPASS>(P, ntiles, in, out, dotw, partials, tile_list); break;
             default: throw Error(SHM_ERR_INVALID, "DCT preconditioner: unsupported grid size");
         }
     }
@@ -1121,6 +1142,78 @@ struct Solver final : SolverBase {
         }
     }
 
+    // K^+ applied to a vector that is non-zero only on the nodes the constraint rows touch, with the result needed only on those
+    // nodes (one iteration of the dual solver): the x sweeps visit only the 16-row tiles that contain touched nodes, the y sweeps only
+    // the z-planes that do; only the fused z sweep is dense.  S1 / S2 keep exact zeros outside the active tiles / planes (zeroed when
+    // the constraint set is built, written only inside it), so the skipped lines transform to the zeros they would produce.
+    void build_active_tiles(const std::vector<int64_t>& touched_nodes) {
+        Slab<T>& sl = slabs[0];
+        const int L = dct_lines_for(log2n_of(n));
+        const int64_t nn = n, pl = (int64_t)n * n;
+        std::vector<int> ax, planes;
+        for (int64_t g : touched_nodes) {
+            const int64_t k = g / pl, j = (g - k * pl) / nn;
+            ax.push_back((int)((k * nn + j) / L));
+            planes.push_back((int)k);
+        }
+        std::sort(ax.begin(), ax.end());
+        ax.erase(std::unique(ax.begin(), ax.end()), ax.end());
+        std::sort(planes.begin(), planes.end());
+        planes.erase(std::unique(planes.begin(), planes.end()), planes.end());
+        std::vector<int> ay;
+        const int tiles_a = n / L;
+        for (int z : planes)
+            for (int xc = 0; xc < tiles_a; xc++) ay.push_back(xc + z * tiles_a);
+        sl.n_act_x = (int)ax.size();
+        sl.n_act_y = (int)ay.size();
+        sl.act_x.upload(ax, stream2);
+        sl.act_y.upload(ay, stream2);
+        sl.S1.alloc(sl.nown);
+        sl.S2.alloc(sl.nown);
+        sl.S4.alloc(sl.nown);
+        sl.W1.alloc(sl.nown);
+        HIPCHK(hipMemsetAsync(sl.S1.p, 0, sl.nown * sizeof(T), stream2));
+        HIPCHK(hipMemsetAsync(sl.S2.p, 0, sl.nown * sizeof(T), stream2));
+        HIPCHK(hipStreamSynchronize(stream2));
+    }
+    static int log2n_of(int v) {
+        int l = 0;
+        while ((1 << l) < v) l++;
+        return l;
+    }
+    void launch_precond_sparse(int in_sel, int out_sel) {
+        Slab<T>& sl = slabs[0];
+        const long long nn = n, plane = (long long)n * n;
+        const int L = dct_lines_for(log2n);
+        const int tiles_all = (int)(plane * nn / L / nn);  // = n*n/L tiles per sweep
+        DctParams Q{};
+        Q.inv_n3_8 = 8.0 / ((double)n * n * n);
+        Q.ky0 = 0;
+        // x-fwd on the active tiles: in (ghost layout) -> S1
+        Q.tiles_a = tiles_all;
+        Q.in = plain_addr((long long)sl.plane, (long long)L * nn, 0, nn, 1);
+        Q.out = plain_addr(0, (long long)L * nn, 0, nn, 1);
+        launch_dct<DCT_FWD, T, TP, false, true>(Q, sl.n_act_x, arr(sl, in_sel), sl.S1.p, (const TP*)nullptr, nullptr, sl.act_x.p);
+        // y-fwd on the active planes: S1 -> S2
+        Q.tiles_a = n / L;
+        Q.in = plain_addr(0, L, plane, 1, nn);
+        Q.out = Q.in;
+        launch_dct<DCT_FWD, TP, TP, false, false>(Q, sl.n_act_y, sl.S1.p, sl.S2.p, (const TP*)nullptr, nullptr, sl.act_y.p);
+        // z-fused, dense: S2 -> W1
+        Q.in = plain_addr(0, L, nn, 1, plane);
+        Q.out = Q.in;
+        launch_dct<DCT_FUSED, TP, TP, false, false>(Q, tiles_all, sl.S2.p, sl.W1.p, (const TP*)nullptr, nullptr);
+        // y-inv on the active planes: W1 -> S4
+        Q.in = plain_addr(0, L, plane, 1, nn);
+        Q.out = Q.in;
+        launch_dct<DCT_INV, TP, TP, false, false>(Q, sl.n_act_y, sl.W1.p, sl.S4.p, (const TP*)nullptr, nullptr, sl.act_y.p);
+        // x-inv on the active tiles: S4 -> out (ghost layout)
+        Q.tiles_a = tiles_all;
+        Q.in = plain_addr(0, (long long)L * nn, 0, nn, 1);
+        Q.out = plain_addr((long long)sl.plane, (long long)L * nn, 0, nn, 1);
+        launch_dct<DCT_INV, TP, T, false, true>(Q, sl.n_act_x, sl.S4.p, arr(sl, out_sel), (const T*)nullptr, nullptr, sl.act_x.p);
+    }
+
     // ------------------------------------------------------------------------------------------
     // Dual solver (see the block comment above the dual_* kernels): CG on S = A K^+ A^T for the multipliers.
     void solve_dual(const shm_opts& o, shm_stats* st, Event& e_start, Event& e_conv, Event& e_div, Event& e_setup, Event& e_s2a, Event& e_s2b,
@@ -1164,8 +1257,10 @@ struct Solver final : SolverBase {
             HIPCHK(hipMemsetAsync(sl.p.p, 0, sl.ntot * sizeof(T), stream));  // w = A^T nu lives in p: zero outside the touched nodes
         }
         // ---- r = Pm(g - S mu), z, p
+        const bool sparse_ok = total_slabs == 1 && slabs[0].n_act_x > 0 && !getenv("SHM_DENSE_DCT");
         scatter(V_MU, ARR_P, 0);
-        launch_precond(false, ARR_P, ARR_Z);
+        if (sparse_ok) launch_precond_sparse(ARR_P, ARR_Z);
+        else launch_precond(false, ARR_P, ARR_Z);
         gather(ARR_Z);
         for (Slab<T>& sl : slabs)
             hipLaunchKernelGGL(dual_init_residual_kernel, dim3(1), dim3(kDualBlock), 0, stream, m, mv(sl, V_G), sl.red.p + 1, mv(sl, V_R), sl.sc.p);
@@ -1184,7 +1279,8 @@ struct Solver final : SolverBase {
                 const bool sample = st && nsamples < kMaxSamples;
                 scatter(V_P, ARR_P, 0);
                 if (sample) ev[3 * nsamples]->record(stream);
-                launch_precond(false, ARR_P, ARR_Z);
+                if (sparse_ok) launch_precond_sparse(ARR_P, ARR_Z);
+                else launch_precond(false, ARR_P, ARR_Z);
                 if (sample) ev[3 * nsamples + 1]->record(stream);
                 gather(ARR_Z);
                 for (Slab<T>& sl : slabs)

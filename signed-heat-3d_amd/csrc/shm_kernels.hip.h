@@ -55,42 +55,39 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
 // For T=float the exponent is offset per node by a lower bound d0 of every source distance so that
 // exp() cannot underflow to 0 for all sources (SURVEY trap #4); the factor cancels in X/|X|.
 // =================================================================================================
-constexpr int kSrcTile = 512;
+constexpr int kSrcTile = 256;
 
 // exp(-lambda r)/r evaluated without a division and without the library sqrt: y = rsqrt(r^2) (hardware seed +
 // two Goldschmidt steps), r = r^2 y, 1/r = y.  fp64 exp: range reduction by ln2 (two-term Cody-Waite) + degree-13
 // Taylor polynomial on |f| <= ln2/2 (truncation 4e-18) + ldexp; the argument is always <= 0 and > -745.
 template <typename T> struct YukawaMath;
 template <> struct YukawaMath<double> {
-    static __device__ __forceinline__ void rsqrt_and_sqrt(double x, double& rinv, double& r) {
+    // e^{-lambda r}/r from x = |d|^2, division-free.  25 VALU + 3 integer instructions per (node, source) pair.
+    //  - r and 1/r: v_rsq_f64 seed y0 (relative error 2^-24), then ONE third-order step: with t = x y0 ~ r and
+    //    e = 1 - x y0^2,  (1 - e)^(-1/2) = 1 + e/2 + 3e^2/8 + O(e^3)  (remainder 5e^3/16 < 1e-21), so r = t (1 + q), 1/r = y0 (1 + q).
+    //  - exp: u = r c with c = -lambda 2048/ln2 is the exponent in units of ln2/2048; k = round(u) by the 1.5*2^52 trick (the integer
+    //    lands in the low mantissa bits), f = fma(r, c, -k) is the remainder with ONE rounding (|f| <= 1/2), and
+    //    e^{-lambda r} = 2^(k >> 11) * T[k & 2047] * P3(f),  T[j] = 2^(j/2048) from a 16 KB LDS table (the LDS pipe is otherwise idle
+    //    in this kernel), P3 the degree-3 Taylor polynomial of 2^(f/2048) (truncation 3.4e-17).  The only error the reference's
+    //    std::exp(-lambda * r) does not share is the rounding of c, relative 1.1e-16 * lambda r in the result -- the same size as
+    //    the reference's own rounding of the product lambda * r.
+    static constexpr int kExpTabBits = 11;
+    static __device__ __forceinline__ double yukawa(double x, double c, const double* __restrict__ tab /* LDS: 2^(j/2048) */) {
         const double y0 = __builtin_amdgcn_rsq(x);
-        double g = x * y0, h = 0.5 * y0;
-        double e = fma(-g, h, 0.5);
-        g = fma(g, e, g);
-        h = fma(h, e, h);
-        e = fma(-g, h, 0.5);
-        g = fma(g, e, g);
-        h = fma(h, e, h);
-        r = g;
-        rinv = h + h;
-    }
-    // exp(x) for x <= 0: x = (64 k + j) ln2/64 + f, |f| <= ln2/128; exp(x) = 2^k * T[j] * P5(f) with T[j] = 2^(j/64) from a
-    // 512-byte LDS table (the LDS pipe is otherwise idle in this kernel) and a degree-5 Taylor polynomial (truncation 4e-17).
-    static __device__ __forceinline__ double exp_neg(double x, const double* __restrict__ tab /* LDS: 2^(j/64), j < 64 */) {
-        // round-to-nearest by the 1.5*2^52 trick: the integer lands in the low mantissa bits (no v_rndne / v_cvt)
-        const double tm = fma(x, 92.33248261689366, 6755399441055744.0);   // 64/ln2 ; 1.5 * 2^52
+        const double t = x * y0;
+        const double e = fma(-t, y0, 1.0);
+        const double q = fma(e, 0.375, 0.5) * e;
+        const double r = fma(t, q, t);
+        const double rinv = fma(y0, q, y0);
+        const double tm = fma(r, c, 6755399441055744.0);   // 1.5 * 2^52
         const double kf = tm - 6755399441055744.0;
         const int ki = (int)(unsigned)__double_as_longlong(tm);
-        double f = fma(kf, -0.010830424695086549, x);                // ln2/64, high part (20 trailing zero bits: kf*hi is exact)
-        f = fma(kf, -1.162596423439437e-12, f);                      // ln2/64, low part
-        const double t = tab[ki & 63];
-        double p = 8.3333333333333332e-03;                           // 1/120
-        p = fma(p, f, 4.1666666666666664e-02);
-        p = fma(p, f, 1.6666666666666666e-01);
-        p = fma(p, f, 0.5);
+        const double f = fma(r, c, -kf);
+        double p = 6.461528672932366e-12;                   // (ln2/2048)^3 / 6
+        p = fma(p, f, 5.727446245172041e-08);               // (ln2/2048)^2 / 2
+        p = fma(p, f, 3.384507717577858e-04);               // ln2/2048
         p = fma(p, f, 1.0);
-        p = fma(p, f, 1.0);
-        return __builtin_amdgcn_ldexp(t * p, ki >> 6);
+        return __builtin_amdgcn_ldexp(tab[ki & ((1 << kExpTabBits) - 1)] * p * rinv, ki >> kExpTabBits);   // r = 0 -> NaN (0 * inf)
     }
     // table-free variant (range reduction by ln2 + degree-13 polynomial): the tile epilogue and tests
     static __device__ __forceinline__ double exp_neg(double x) {
@@ -121,7 +118,6 @@ template <> struct YukawaMath<float> {
         rinv = y0;
     }
     static __device__ __forceinline__ float exp_neg(float x) { return __expf(x); }
-    static __device__ __forceinline__ float exp_neg(float x, const double*) { return __expf(x); }
 };
 template <typename T> __device__ __forceinline__ T t_sqrt(T x);
 template <> __device__ __forceinline__ double t_sqrt<double>(double x) { return sqrt(x); }
@@ -136,6 +132,7 @@ struct ConvParams {
     double bbox_min[3];
     double cell;
     double lambda;
+    double cexp;        // -lambda * 2048 / ln 2 (fp64 path: exponent in table units)
     int S;              // padded to whole clusters
     int n_clusters;
     float far_gap;      // fp64 path: a cluster is "far" when d_lo(tile, cluster) - r_hi(tile) > far_gap
@@ -160,46 +157,56 @@ constexpr int kConvChunk = kSrcTile / kConvCluster;  // clusters per LDS fill
 template <typename T, int NPT>
 __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, const T* __restrict__ src /* [S][6]: pos xyz, wn xyz */,
                                                                 const float* __restrict__ src32, const float* __restrict__ clusters,
+                                                                const double* __restrict__ exp_tab_g /* [2048]: 2^(j/2048) */,
                                                                 T* __restrict__ Y0, T* __restrict__ Y1, T* __restrict__ Y2) {
-    static_assert(NPT * kBlock == kConvTile * kConvTile * kConvTile, "tile = NPT nodes per lane");
+    // tile = 8 x 8 x (4 NPT) nodes; a lane owns the z-column (i, j, k0 + w + 4 e), e < NPT (w = its wave): the NPT nodes share
+    // dx^2 + dy^2 of every source
+    constexpr int kTileZ = (kBlock / 64) * NPT;
     constexpr bool kMixed = sizeof(T) == 8;
     __shared__ T tile[kSrcTile * 6];
     __shared__ float tile32[kMixed ? kSrcTile * 6 : 1];
     __shared__ float cls[kConvChunk * 4];
     __shared__ float red[kBlock / kWave];
-    __shared__ double exp_tab[64];
-    if (kMixed && threadIdx.x < 64) exp_tab[threadIdx.x] = exp2((double)threadIdx.x * 0.015625);  // correctly rounded 2^(j/64)
+    constexpr int kTab = kMixed ? (1 << YukawaMath<double>::kExpTabBits) : 1;
+    __shared__ double exp_tab[kTab];
+    if (kMixed)
+        for (int a = threadIdx.x; a < kTab; a += kBlock) exp_tab[a] = exp_tab_g[a];
     const int n = P.n;
     const size_t plane = (size_t)n * n;
     for (int bt = blockIdx.x; bt < P.n_tiles; bt += gridDim.x) {
     __syncthreads();  // LDS reuse between consecutive tiles of this workgroup
     const int tz = bt / (P.tiles_x * P.tiles_y), trem = bt - tz * (P.tiles_x * P.tiles_y);
     const int ty = trem / P.tiles_x, tx = trem - ty * P.tiles_x;
-    const int i0 = tx * kConvTile, j0 = ty * kConvTile, kk0 = P.kk_begin + tz * kConvTile;
+    const int i0 = tx * kConvTile, j0 = ty * kConvTile, kk0 = P.kk_begin + tz * kTileZ;
 
-    T px[NPT], py[NPT], pz[NPT], ax[NPT], ay[NPT], az[NPT];
-    float qx[NPT], qy[NPT], qz[NPT], fx[NPT], fy[NPT], fz[NPT];
+    T pz[NPT], ax[NPT], ay[NPT], az[NPT];
+    float qz[NPT], fx[NPT], fy[NPT], fz[NPT];
     bool live[NPT];
     size_t vidx[NPT];
+    const int li = i0 + (threadIdx.x & 7), lj = j0 + ((threadIdx.x >> 3) & 7);
+    const int ci = min(li, n - 1), cj = min(lj, n - 1);
+    // indicesToNodePosition: (i,j,k)*cellSize + bboxMin, evaluated in double like the reference
+    const double xd = ci * P.cell + P.bbox_min[0], yd = cj * P.cell + P.bbox_min[1];
+    const T px = (T)xd, py = (T)yd;
+    const float qx = (float)xd, qy = (float)yd;
 #pragma unroll
     for (int e = 0; e < NPT; e++) {
-        const int id = threadIdx.x + e * kBlock;
-        int i = i0 + (id & 7), j = j0 + ((id >> 3) & 7), kk = kk0 + (id >> 6);
-        live[e] = i < n && j < n && kk < P.kk_end;
-        i = min(i, n - 1); j = min(j, n - 1); kk = min(kk, P.kk_end - 1);
-        vidx[e] = (size_t)kk * plane + (size_t)j * n + i;
+        int kk = kk0 + (int)(threadIdx.x >> 6) + e * (kBlock / 64);
+        live[e] = li < n && lj < n && kk < P.kk_end;
+        kk = min(kk, P.kk_end - 1);
+        vidx[e] = (size_t)kk * plane + (size_t)cj * n + ci;
         const int k = P.k0 + kk - 1;
-        // indicesToNodePosition: (i,j,k)*cellSize + bboxMin, evaluated in double like the reference
-        const double x = i * P.cell + P.bbox_min[0], y = j * P.cell + P.bbox_min[1], z = k * P.cell + P.bbox_min[2];
-        px[e] = (T)x; py[e] = (T)y; pz[e] = (T)z;
-        qx[e] = (float)x; qy[e] = (float)y; qz[e] = (float)z;
+        const double z = k * P.cell + P.bbox_min[2];
+        pz[e] = (T)z;
+        qz[e] = (float)z;
         ax[e] = ay[e] = az[e] = (T)0;
         fx[e] = fy[e] = fz[e] = 0.f;
     }
     // tile centre / circumscribed radius, then the workgroup-wide minimum distance from the centre to the sources
+    constexpr double kHalfZ = 0.5 * (kTileZ - 1);
     const float cx = (float)((i0 + 3.5) * P.cell + P.bbox_min[0]), cy = (float)((j0 + 3.5) * P.cell + P.bbox_min[1]);
-    const float cz = (float)((P.k0 + kk0 - 1 + 3.5) * P.cell + P.bbox_min[2]);
-    const float rt = (float)(3.5 * 1.7320508075688772 * P.cell) * 1.000001f;
+    const float cz = (float)((P.k0 + kk0 - 1 + kHalfZ) * P.cell + P.bbox_min[2]);
+    const float rt = (float)(sqrt(3.5 * 3.5 * 2 + kHalfZ * kHalfZ) * P.cell) * 1.000001f;
     float dmin = 3.0e38f;
     for (int s = threadIdx.x; s < P.S; s += kBlock) {
         const float dx = cx - (float)src[(size_t)s * 6], dy = cy - (float)src[(size_t)s * 6 + 1], dz = cz - (float)src[(size_t)s * 6 + 2];
@@ -227,10 +234,12 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
             for (int a = threadIdx.x; a < cnt * 6; a += kBlock) tile[a] = src[(size_t)s0 * 6 + a];
             __syncthreads();
             for (int s = 0; s < cnt; s++) {
+                const float dx = qx - (float)tile[6 * s], dy = qy - (float)tile[6 * s + 1];
+                const float dxy2 = dx * dx + dy * dy;
 #pragma unroll
                 for (int e = 0; e < NPT; e++) {
-                    const float dx = qx[e] - (float)tile[6 * s], dy = qy[e] - (float)tile[6 * s + 1], dz = qz[e] - (float)tile[6 * s + 2];
-                    m2[e] = fminf(m2[e], dx * dx + dy * dy + dz * dz);
+                    const float dz = qz[e] - (float)tile[6 * s + 2];
+                    m2[e] = fminf(m2[e], dxy2 + dz * dz);
                 }
             }
         }
@@ -259,13 +268,15 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
             if (far) {
 #pragma unroll 2
                 for (int s = c * kConvCluster; s < (c + 1) * kConvCluster; s++) {
-                    const float sx = tile32[6 * s], sy = tile32[6 * s + 1], sz = tile32[6 * s + 2];
+                    const float sz = tile32[6 * s + 2];
                     const float wx = tile32[6 * s + 3], wy = tile32[6 * s + 4], wz = tile32[6 * s + 5];
+                    const float dx = qx - tile32[6 * s], dy = qy - tile32[6 * s + 1];
+                    const float dxy2 = dx * dx + dy * dy;
 #pragma unroll
                     for (int e = 0; e < NPT; e++) {
-                        const float dx = qx[e] - sx, dy = qy[e] - sy, dz = qz[e] - sz;
+                        const float dz = qz[e] - sz;
                         float r, rinv;
-                        YukawaMath<float>::rsqrt_and_sqrt(dx * dx + dy * dy + dz * dz, rinv, r);
+                        YukawaMath<float>::rsqrt_and_sqrt(dxy2 + dz * dz, rinv, r);
                         const float g = YukawaMath<float>::exp_neg(-lamf * (r - d0t)) * rinv;
                         fx[e] += wx * g; fy[e] += wy * g; fz[e] += wz * g;
                     }
@@ -273,14 +284,22 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
             } else {
 #pragma unroll 2
                 for (int s = c * kConvCluster; s < (c + 1) * kConvCluster; s++) {
-                    const T sx = tile[6 * s], sy = tile[6 * s + 1], sz = tile[6 * s + 2];
+                    const T sz = tile[6 * s + 2];
                     const T wx = tile[6 * s + 3], wy = tile[6 * s + 4], wz = tile[6 * s + 5];
+                    const T dx = px - tile[6 * s], dy = py - tile[6 * s + 1];
+                    const T dxy2 = dx * dx + dy * dy;
 #pragma unroll
                     for (int e = 0; e < NPT; e++) {
-                        const T dx = px[e] - sx, dy = py[e] - sy, dz = pz[e] - sz;
-                        T r, rinv;
-                        YukawaMath<T>::rsqrt_and_sqrt(dx * dx + dy * dy + dz * dz, rinv, r);
-                        const T g = YukawaMath<T>::exp_neg(-lam * (r - d0[e]), exp_tab) * rinv;   // r = 0 -> NaN, like exp(0)/0 = inf -> NaN after normalise
+                        const T dz = pz[e] - sz;
+                        const T d2 = dxy2 + dz * dz;
+                        T g;   // r = 0 -> NaN, like exp(0)/0 = inf -> NaN after normalise
+                        if constexpr (kMixed) {
+                            g = YukawaMath<double>::yukawa(d2, P.cexp, exp_tab);
+                        } else {
+                            float r, rinv;
+                            YukawaMath<float>::rsqrt_and_sqrt(d2, rinv, r);
+                            g = YukawaMath<float>::exp_neg(-lam * (r - d0[e])) * rinv;
+                        }
                         ax[e] += wx * g; ay[e] += wy * g; az[e] += wz * g;
                     }
                 }

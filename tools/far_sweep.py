@@ -5,7 +5,8 @@ shm = shm_import.load()
 from signed_heat_3d_amd.host_abi import HostSolver
 pre = HostSolver("data/bunny_small.obj").preprocess(hCoef=4.0)
 ref = None
-for fl in ("25", "20", "16", "12", "9"):
+print("lambda*cell", pre["lam"] * pre["cell"], "S", pre["S"])
+for fl in ("25", "16", "12", "9", "7", "5", "3"):
     os.environ["SHM_CONV_FAR_LOG"] = fl
     s = shm.GridSolver()
     s.set_problem(pre["pos"], pre["wnormal"], pre["area"], pre["lam"], pre["n"], pre["bbox_min"], pre["cell"])
