@@ -43,7 +43,9 @@ struct DctAddr {
     int seg_shift, seg_mask;
 };
 struct DctParams {
+    int ntiles;             // tiles of this sweep; the workgroups stride over them (persistent: a workgroup costs more to start than a tile to set up)
     int tiles_a;
+    int debug_skip;         // experiments only (SHM_DCT_SKIP): 1 = no FFT passes, 2 = no spectral step, 4 = no global loads, 8 = no global stores
     DctAddr in, out;
     // FUSED only: spectral coordinates of line l of tile t: kx = (t % tiles_a)*16 + l ; ky = ky0 + t / tiles_a
     int ky0;
@@ -70,7 +72,7 @@ __device__ __forceinline__ void dct_fft_pass(Cplx<TP>* buf, const Cplx<TP>* tw, 
 #pragma unroll
     for (int a = 0; a < IPT; a++) {
         const int w = tid + a * kBlock;
-        if (items % kBlock == 0 || w < items) pass_load<TP, LOG2N, R, NS, SIGN, LC>(buf, tw, w, v[a]);
+        if (items % kBlock == 0 || w < items) pass_load<TP, LOG2N, R, NS, SIGN, LC, true>(buf, tw, w, v[a]);
     }
     __syncthreads();
 #pragma unroll
@@ -90,11 +92,12 @@ __device__ __forceinline__ void dct_fft(Cplx<TP>* buf, const Cplx<TP>* tw, int t
 }
 
 // tw_g[t] = e^{-2 pi i t/n}, t<n ; om_g[k] = e^{-i pi k/(2n)}, k<n ; lam_g[k] = (2-2cos(pi k/n))/h^2
-template <typename TP, typename TIn, typename TOut, int MODE, bool DOT, int LOG2N, bool XPASS>
+template <typename TP, typename TIn, typename TOut, int MODE, bool DOT, int LOG2N, bool XPASS, bool SEG>
 __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TIn* __restrict__ in, TOut* __restrict__ out,
                                                            const Cplx<TP>* __restrict__ tw_g, const Cplx<TP>* __restrict__ om_g,
                                                            const TP* __restrict__ lam_g, const TOut* __restrict__ dot_with,
-                                                           double* __restrict__ partials, const int* __restrict__ tile_list /* nullptr: all tiles */) {
+                                                           double* __restrict__ partials, const int* __restrict__ tile_list /* nullptr: all tiles */,
+                                                           const unsigned* __restrict__ elem_mask /* nullptr: all elements; else bit k = element k is non-zero on input / needed on output */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int LC = dct_lc<LOG2N>(), kFftRow = LC + 1, kFftLC = LC;
     constexpr int n = 1 << LOG2N, L = 2 * LC, LOG2L = ilog2(L), total = n * L;
@@ -105,18 +108,43 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
     double* red = reinterpret_cast<double*>(tw_l + (dct_tw_in_lds<LOG2N>() ? n : 0));  // [8] block-reduction scratch
     const Cplx<TP>* tw = dct_tw_in_lds<LOG2N>() ? tw_l : tw_g;
     const int tid = threadIdx.x;
-    const int lb = (int)xcd_remap(blockIdx.x, gridDim.x);  // neighbouring tiles (adjacent x chunks of the same rows) share an XCD's L2
+    if (dct_tw_in_lds<LOG2N>())
+        for (int a = tid; a < n; a += kBlock) tw_l[a] = tw_g[a];
+    // concurrently running workgroups take neighbouring tiles (adjacent x chunks of the same rows share an XCD's L2)
+    for (int lb = (int)xcd_remap(blockIdx.x, gridDim.x); lb < P.ntiles; lb += (int)gridDim.x) {
+    __syncthreads();                                       // the previous tile's LDS reads are done (and the twiddle table is in place)
     const int t = tile_list ? tile_list[lb] : lb;          // sparse sweeps visit only the tiles that can hold non-zeros / needed outputs
     const long long base_in = (long long)(t % P.tiles_a) * P.in.a_stride + (long long)(t / P.tiles_a) * P.in.b_stride;
     const long long base_out = (long long)(t % P.tiles_a) * P.out.a_stride + (long long)(t / P.tiles_a) * P.out.b_stride;
-    if (dct_tw_in_lds<LOG2N>())
-        for (int a = tid; a < n; a += kBlock) tw_l[a] = tw_g[a];
 
     // element index of the a-th element this thread moves: idx = tid + a*256
     //   y/z sweeps: l = idx & (L-1) (consecutive lanes = consecutive lines = consecutive x), j = idx >> log2(L)
     //   x sweep   : j = idx & (n-1) (consecutive lanes = consecutive x),                  l = idx >> LOG2N
     auto line_of = [&](int idx) { return XPASS ? (idx >> LOG2N) : (idx & (L - 1)); };
     auto elem_of = [&](int idx) { return XPASS ? (idx & (n - 1)) : (idx >> LOG2L); };
+    // Plain layouts (SEG = false): the address of element a of this thread splits into a per-thread 32-bit offset (fixed) and a
+    // workgroup-uniform part that depends on a only -- scalar registers, no per-element vector address arithmetic:
+    //   y/z sweeps: l = tid % L, j = tid / L + a (256 / L)                  -> uniform part a (256 / L) elem_stride
+    //   x sweep, n >= 256: l = a / (n/256), j = tid + (a % (n/256)) 256     -> l line_stride + (a % (n/256)) 256 elem_stride
+    //   x sweep, n <  256: l = tid / n + a (256/n), j = tid % n             -> a (256/n) line_stride
+    auto thread_off = [&](const DctAddr& A) -> unsigned {
+        if (XPASS) return n >= kBlock ? (unsigned)(tid * A.elem_stride) : (unsigned)((tid >> LOG2N) * A.line_stride + (tid & (n - 1)) * A.elem_stride);
+        return (unsigned)((tid & (L - 1)) * A.line_stride + (tid >> LOG2L) * A.elem_stride);
+    };
+    auto uniform_off = [&](const DctAddr& A, int a) -> long long {
+        if (XPASS) {
+            constexpr int per = n >= kBlock ? n / kBlock : 1, lp = n >= kBlock ? 1 : kBlock / n;
+            return n >= kBlock ? (long long)(a / per) * A.line_stride + (long long)((a % per) * kBlock) * A.elem_stride : (long long)(a * lp) * A.line_stride;
+        }
+        return (long long)(a * (kBlock / L)) * A.elem_stride;
+    };
+    const unsigned toff_in = SEG ? 0u : thread_off(P.in), toff_out = SEG ? 0u : thread_off(P.out);
+    auto in_at = [&](const TIn* base, int a, int idx) -> const TIn* {
+        return SEG ? base + dct_addr(P.in, base_in, line_of(idx), elem_of(idx)) : (base + (P.in.off + base_in + uniform_off(P.in, a))) + toff_in;
+    };
+    auto out_at = [&](auto* base, int a, int idx) {
+        return SEG ? base + dct_addr(P.out, base_out, line_of(idx), elem_of(idx)) : (base + (P.out.off + base_out + uniform_off(P.out, a))) + toff_out;
+    };
 
     // ---------------- load: global -> registers (CH loads in flight) -> LDS ----------------
 #pragma unroll 1
@@ -125,8 +153,10 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
 #pragma unroll
         for (int a = 0; a < CH; a++) {
             const int idx = tid + (a0 + a) * kBlock;
-            if (total % kBlock == 0 || idx < total)
-                v[a] = (TP)in[dct_addr(P.in, base_in, line_of(idx), elem_of(idx))];
+            if (total % kBlock == 0 || idx < total) {
+                const int j = elem_of(idx);
+                v[a] = (!(P.debug_skip & 4) && (!elem_mask || ((elem_mask[j >> 5] >> (j & 31)) & 1u))) ? (TP)*in_at(in, a0 + a, idx) : (TP)0;
+            }
         }
 #pragma unroll
         for (int a = 0; a < CH; a++) {
@@ -141,7 +171,7 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
     }
     __syncthreads();
 
-    if (MODE == DCT_FWD || MODE == DCT_FUSED) dct_fft<TP, LOG2N, -1>(buf, tw, tid);
+    if ((MODE == DCT_FWD || MODE == DCT_FUSED) && !(P.debug_skip & 1)) dct_fft<TP, LOG2N, -1>(buf, tw, tid);
 
     if (MODE == DCT_FWD) {
         // ---------------- X[k] = Re(om_k V[k]) straight to global ----------------
@@ -154,15 +184,15 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
                     const int l = line_of(idx), k = elem_of(idx), c = l >> 1;
                     TP xa, xb;
                     dct_fwd_post<TP>(buf[k * kFftRow + c], buf[((n - k) & (n - 1)) * kFftRow + c], om_g[k], xa, xb);
-                    out[dct_addr(P.out, base_out, l, k)] = (TOut)((l & 1) ? xb : xa);
+                    *out_at(out, a0 + a, idx) = (TOut)((l & 1) ? xb : xa);
                 }
             }
         }
-        return;
+        continue;
     }
 
     // ---------------- spectral step on (k, n-k) pairs, k = 0..n/2 ----------------
-    {
+    if (!(P.debug_skip & 2)) {
         const int kx0 = (t % P.tiles_a) * L, ky = P.ky0 + t / P.tiles_a;
         constexpr int pairs = (n / 2 + 1) * kFftLC;
         for (int b = tid; b < pairs; b += kBlock) {
@@ -182,10 +212,17 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
                 const TP lk = lam_g[k], ln = lam_g[nk];
                 const TP szk = k == 0 ? (TP)0.5 : (TP)1;  // nk == 0 only together with k == 0
                 const TP da_k = lxy_a + lk, db_k = lxy_b + lk, da_n = lxy_a + ln, db_n = lxy_b + ln;
-                xa_k = da_k > (TP)0 ? xa_k * sa * szk / da_k : (TP)0;
-                xb_k = xb_k * sb * szk / db_k;
-                xa_n = da_n > (TP)0 ? xa_n * sa * szk / da_n : (TP)0;
-                xb_n = xb_n * sb * szk / db_n;
+                // 1/d by the hardware seed and two Newton steps (1-2 ulp; the IEEE division sequence is ~10x the instructions)
+                auto recip = [](TP d) {
+                    TP r = t_rcp<TP>(d);
+                    r = fma(fma(-d, r, (TP)1), r, r);
+                    r = fma(fma(-d, r, (TP)1), r, r);
+                    return r;
+                };
+                xa_k = da_k > (TP)0 ? xa_k * (sa * szk) * recip(da_k) : (TP)0;
+                xb_k = xb_k * (sb * szk) * recip(db_k);
+                xa_n = da_n > (TP)0 ? xa_n * (sa * szk) * recip(da_n) : (TP)0;
+                xb_n = xb_n * (sb * szk) * recip(db_n);
             } else {
                 const Cplx<TP> rk = buf[k * kFftRow + c], rn = buf[nk * kFftRow + c];
                 xa_k = rk.x; xb_k = rk.y; xa_n = rn.x; xb_n = rn.y;
@@ -196,7 +233,7 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
         __syncthreads();
     }
 
-    dct_fft<TP, LOG2N, +1>(buf, tw, tid);
+    if (!(P.debug_skip & 1)) dct_fft<TP, LOG2N, +1>(buf, tw, tid);
 
     // ---------------- store: x[j] = v[makhoul_slot(j)] ----------------
     double acc = 0.;
@@ -208,7 +245,7 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
             for (int a = 0; a < CH; a++) {
                 const int idx = tid + (a0 + a) * kBlock;
                 if (total % kBlock == 0 || idx < total)
-                    dv[a] = dot_with[dct_addr(P.out, base_out, line_of(idx), elem_of(idx))];
+                    dv[a] = *out_at(dot_with, a0 + a, idx);
             }
         }
 #pragma unroll
@@ -217,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
             if (total % kBlock == 0 || idx < total) {
                 const int l = line_of(idx), j = elem_of(idx);
                 const TP v = reinterpret_cast<const TP*>(&buf[makhoul_slot(j, n) * kFftRow + (l >> 1)])[l & 1];
-                out[dct_addr(P.out, base_out, l, j)] = (TOut)v;
+                if (!(P.debug_skip & 8) && (!elem_mask || ((elem_mask[j >> 5] >> (j & 31)) & 1u))) *out_at(out, a0 + a, idx) = (TOut)v;
                 if (DOT) acc += (double)v * (double)dv[a];
             }
         }
@@ -226,6 +263,7 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
         acc = block_sum(acc, red);
         if (tid == 0) partials[t] = acc;
     }
+    }  // tile loop
 }
 
 }  // namespace shm

@@ -67,7 +67,7 @@ template <> struct FftPlan<4> { static constexpr int npass = 1; static constexpr
 template <> struct FftPlan<5> { static constexpr int npass = 2; static constexpr int R0 = 8, R1 = 4, R2 = 1; };
 template <> struct FftPlan<6> { static constexpr int npass = 2; static constexpr int R0 = 8, R1 = 8, R2 = 1; };
 template <> struct FftPlan<7> { static constexpr int npass = 2; static constexpr int R0 = 16, R1 = 8, R2 = 1; };
-template <> struct FftPlan<8> { static constexpr int npass = 2; static constexpr int R0 = 16, R1 = 16, R2 = 1; };
+template <> struct FftPlan<8> { static constexpr int npass = 3; static constexpr int R0 = 8, R1 = 8, R2 = 4; };
 template <> struct FftPlan<9> { static constexpr int npass = 3; static constexpr int R0 = 8, R1 = 8, R2 = 8; };
 template <> struct FftPlan<10> { static constexpr int npass = 3; static constexpr int R0 = 16, R1 = 8, R2 = 8; };
 
@@ -78,7 +78,10 @@ template <int LOG2N, int R, int LC> struct PassGeom {
 };
 
 // Phase 1 of a pass (before the barrier): gather + twiddle + register DFT for work item w.
-template <typename TP, int LOG2N, int R, int NS, int SIGN, int LC>
+// POW = false: the R-1 inter-pass twiddles w^{r k n/(NS R)} are read from the table.  POW = true: only w^{k n/(NS R)} is read and
+// the other powers come from a multiplication tree of depth <= 4 (w2 = w1^2, w3 = w2 w1, w4 = w2^2, ...; a few ulp): one table access
+// per work item instead of R-1, for the lengths whose table lives in global memory.
+template <typename TP, int LOG2N, int R, int NS, int SIGN, int LC, bool POW = false>
 SHM_HD void pass_load(const Cplx<TP>* buf, const Cplx<TP>* tw /* [n]: e^{-2 pi i t/n} */, int w, Cplx<TP> (&v)[R]) {
     constexpr int n = 1 << LOG2N;
     const int c = w & (LC - 1), jj = w >> ilog2(LC);
@@ -86,11 +89,21 @@ SHM_HD void pass_load(const Cplx<TP>* buf, const Cplx<TP>* tw /* [n]: e^{-2 pi i
     for (int r = 0; r < R; r++) v[r] = buf[(jj + r * (n / R)) * (LC + 1) + c];
     if (NS > 1) {
         const int k = jj & (NS - 1);
+        if (POW) {
+            Cplx<TP> p[R];
+            p[1] = tw[k * (n / (NS * R))];
+            if (SIGN > 0) p[1] = cconj(p[1]);
 #pragma unroll
-        for (int r = 1; r < R; r++) {
-            Cplx<TP> t = tw[r * k * (n / (NS * R))];
-            if (SIGN > 0) t = cconj(t);
-            v[r] = cmul(v[r], t);
+            for (int r = 2; r < R; r++) p[r] = cmul(p[r / 2], p[r - r / 2]);
+#pragma unroll
+            for (int r = 1; r < R; r++) v[r] = cmul(v[r], p[r]);
+        } else {
+#pragma unroll
+            for (int r = 1; r < R; r++) {
+                Cplx<TP> t = tw[r * k * (n / (NS * R))];
+                if (SIGN > 0) t = cconj(t);
+                v[r] = cmul(v[r], t);
+            }
         }
     }
     RegDft<TP, R, SIGN>::run(v);

@@ -184,6 +184,7 @@ struct Slab {
     DevArray<T> W1, W2;  // DCT work arrays (precision TP == T); W2 only with several slabs (packed transposes)
     DevArray<T> S1, S2, S4;  // sparse-sweep buffers of the dual solver's per-iteration solve (single slab)
     DevArray<int> act_x, act_y;  // active tiles of the x sweeps / y sweeps
+    DevArray<unsigned> act_z;    // bit k: z-plane k holds touched nodes
     int n_act_x = 0, n_act_y = 0;
     int n_touched = 0, n_shift = 0;
     GridParams gp{};
@@ -203,6 +204,7 @@ struct Solver final : SolverBase {
     double area_sum = 0., conv_far_gap = 0., last_host_setup_ms = 0.;
     int n_clusters = 0;
     int conv_grid_cap = 1 << 30;
+    int num_cus = 256, dct_grid_x16 = 16;
     DevArray<T> d_src;          // [Spad][6] Morton-sorted, padded to whole clusters
     DevArray<float> d_src32;    // same in fp32 (far clusters of the fp64 path)
     DevArray<float> d_clusters; // [n_clusters][4] bounding spheres
@@ -214,6 +216,7 @@ struct Solver final : SolverBase {
     std::vector<Row> rows;
     int m = 0, mp = 0;
     DevArray<double> Ginv, gjP, gjR, gjC;
+    DevArray<float> Ginv32;  // single-precision copy for the dual solver's preconditioner
     DevArray<int> gjFlag;
     DevArray<double*> d_redptrs;
     // dual solver: B = A K A^T (CSR, replicated) and the m-vectors of its CG (per slab, replicated values)
@@ -245,6 +248,9 @@ struct Solver final : SolverBase {
             const char* e = getenv("SHM_CONV_SLOTS_PER_CU_X16");  // tuning knob: conv workgroups per CU, in 1/16ths (default 64 = 4, the LDS-limited residency: one persistent wave of workgroups)
             const int x16 = e ? atoi(e) : 64;
             conv_grid_cap = std::max(1, prop.multiProcessorCount * x16 / 16);
+            num_cus = prop.multiProcessorCount;
+            const char* d = getenv("SHM_DCT_GRID_X16");  // tuning knob: DCT workgroups per resident slot, in 1/16ths (16 = one persistent wave of workgroups)
+            dct_grid_x16 = d ? std::max(1, atoi(d)) : (1 << 20);
         }
         {   // the set-up stream outranks the main stream so that its short kernels are not starved by the Step-1 kernel
             int least = 0, greatest = 0;
@@ -785,6 +791,8 @@ struct Solver final : SolverBase {
             hipLaunchKernelGGL(gj_panels_kernel, dim3(nb), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjP.p, gjR.p, gjC.p);
             hipLaunchKernelGGL(gj_update_kernel, dim3(nb, nb), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjR.p, gjC.p);
         }
+        Ginv32.alloc((size_t)mp * mp);
+        hipLaunchKernelGGL((convert_kernel<double, float>), dim3(grid_for((size_t)mp * mp, 4096)), dim3(kBlock), 0, stream, (size_t)mp * mp, Ginv.p, Ginv32.p);
         HIPCHK(hipGetLastError());
         int flag = 0;
         HIPCHK(hipMemcpyAsync(&flag, gjFlag.p, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -896,7 +904,7 @@ struct Solver final : SolverBase {
         allreduce(0, 1 + m);
         for (Slab<T>& sl : slabs) {
             if (m > 0)
-                hipLaunchKernelGGL(ginv_matvec_kernel, dim3((m + 3) / 4), dim3(kBlock), 0, stream, m, mp, Ginv.p, sl.red.p + 1, sl.u.p);
+                hipLaunchKernelGGL(ginv_matvec_kernel<double>, dim3(m), dim3(kBlock), 0, stream, m, mp, Ginv.p, sl.red.p + 1, sl.u.p);
             hipLaunchKernelGGL((scatter_nodes_kernel<T>), dim3(1 + (sl.n_touched + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sl.n_touched,
                                sl.node_id.p, sl.node_ptr.p, sl.ent_row.p, sl.nent_coef.p, sl.u.p, sl.red.p + 1, m, sl.sc.p, save_rr,
                                on_z ? sl.z.p : sl.r.p);
@@ -937,26 +945,46 @@ struct Solver final : SolverBase {
     }
 
     template <int MODE, typename TIn, typename TOut, bool DOT, int LOG2N, bool XPASS>
-    void launch_dct_n(const DctParams& P, int ntiles, const TIn* in, TOut* out, const TOut* dotw, double* partials, const int* tile_list) {
-        auto kern = dct_lines_kernel<TP, TIn, TOut, MODE, DOT, LOG2N, XPASS>;
+    void launch_dct_n(const DctParams& P, int ntiles, const TIn* in, TOut* out, const TOut* dotw, double* partials, const int* tile_list, const unsigned* elem_mask) {
+        // segmented addressing (the packed all-to-all layout) occurs only in the y sweeps of a multi-slab transform
+        constexpr bool kCanSeg = !XPASS && MODE != DCT_FUSED && !DOT;
+        const bool seg = P.in.seg_shift < 30 || P.out.seg_shift < 30;
+        if (seg && !kCanSeg) throw Error(SHM_ERR_INVALID, "DCT: segmented layout in a sweep that does not support it");
+        if constexpr (kCanSeg) {
+            if (seg) {
+                launch_dct_k<MODE, TIn, TOut, DOT, LOG2N, XPASS, true>(P, ntiles, in, out, dotw, partials, tile_list, elem_mask);
+                return;
+            }
+        }
+        launch_dct_k<MODE, TIn, TOut, DOT, LOG2N, XPASS, false>(P, ntiles, in, out, dotw, partials, tile_list, elem_mask);
+    }
+    template <int MODE, typename TIn, typename TOut, bool DOT, int LOG2N, bool XPASS, bool SEG>
+    void launch_dct_k(const DctParams& P, int ntiles, const TIn* in, TOut* out, const TOut* dotw, double* partials, const int* tile_list, const unsigned* elem_mask) {
+        auto kern = dct_lines_kernel<TP, TIn, TOut, MODE, DOT, LOG2N, XPASS, SEG>;
         static bool configured = false;  // per instantiation
         constexpr size_t lds = dct_lds_bytes<LOG2N>(sizeof(Cplx<TP>));
         if (!configured) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             configured = true;
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(kBlock), lds, stream, P, in, out, d_tw.p, d_om.p, d_lam.p, dotw, partials, tile_list);
+        DctParams Q = P;
+        Q.ntiles = ntiles;
+        { static const int dbg = getenv("SHM_DCT_SKIP") ? atoi(getenv("SHM_DCT_SKIP")) : 0; Q.debug_skip = dbg; }
+        const int per_cu = std::max(1, (int)((size_t)(160 * 1024) / lds));
+        const int grid = (int)std::min<long long>(ntiles, std::max<long long>(1, (long long)dct_grid_x16 * num_cus * per_cu / 16));
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), lds, stream, Q, in, out, d_tw.p, d_om.p, d_lam.p, dotw, partials, tile_list, elem_mask);
     }
     template <int MODE, typename TIn, typename TOut, bool DOT, bool XPASS>
-    void launch_dct(const DctParams& P, int ntiles, const TIn* in, TOut* out, const TOut* dotw, double* partials, const int* tile_list = nullptr) {
+    void launch_dct(const DctParams& P, int ntiles, const TIn* in, TOut* out, const TOut* dotw, double* partials, const int* tile_list = nullptr,
+                    const unsigned* elem_mask = nullptr) {
         switch (log2n) {
-            case 4: launch_dct_n<MODE, TIn, TOut, DOT, 4, XPASS>(P, ntiles, in, out, dotw, partials, tile_list); break;
-            case 5: launch_dct_n<MODE, TIn, TOut, DOT, 5, XPASS>(P, ntiles, in, out, dotw, partials, tile_list); break;
-            case 6: launch_dct_n<MODE, TIn, TOut, DOT, 6, XPASS>(P, ntiles, in, out, dotw, partials, tile_list); break;
-            case 7: launch_dct_n<MODE, TIn, TOut, DOT, 7, XPASS>(P, ntiles, in, out, dotw, partials, tile_list); break;
-            case 8: launch_dct_n<MODE, TIn, TOut, DOT, 8, XPASS>(P, ntiles, in, out, dotw, partials, tile_list); break;
-            case 9: launch_dct_n<MODE, TIn, TOut, DOT, 9, XPASS>(P, ntiles, in, out, dotw, partials, tile_list); break;
-            case 10: launch_dct_n<MODE, TIn, TOut, DOT, 10, XPASS>(P, ntiles, in, out, dotw, partials, tile_list); break;
+            case 4: launch_dct_n<MODE, TIn, TOut, DOT, 4, XPASS>(P, ntiles, in, out, dotw, partials, tile_list, elem_mask); break;
+            case 5: launch_dct_n<MODE, TIn, TOut, DOT, 5, XPASS>(P, ntiles, in, out, dotw, partials, tile_list, elem_mask); break;
+            case 6: launch_dct_n<MODE, TIn, TOut, DOT, 6, XPASS>(P, ntiles, in, out, dotw, partials, tile_list, elem_mask); break;
+            case 7: launch_dct_n<MODE, TIn, TOut, DOT, 7, XPASS>(P, ntiles, in, out, dotw, partials, tile_list, elem_mask); break;
+            case 8: launch_dct_n<MODE, TIn, TOut, DOT, 8, XPASS>(P, ntiles, in, out, dotw, partials, tile_list, elem_mask); break;
+            case 9: launch_dct_n<MODE, TIn, TOut, DOT, 9, XPASS>(P, ntiles, in, out, dotw, partials, tile_list, elem_mask); break;
+            case 10: launch_dct_n<MODE, TIn, TOut, DOT, 10, XPASS>(P, ntiles, in, out, dotw, partials, tile_list, elem_mask); break;
             default: throw Error(SHM_ERR_INVALID, "DCT preconditioner: unsupported grid size");
         }
     }
@@ -1164,6 +1192,9 @@ struct Solver final : SolverBase {
         const int tiles_a = n / L;
         for (int z : planes)
             for (int xc = 0; xc < tiles_a; xc++) ay.push_back(xc + z * tiles_a);
+        std::vector<unsigned> zm((size_t)(n + 31) / 32, 0u);
+        for (int z : planes) zm[(size_t)z >> 5] |= 1u << (z & 31);
+        sl.act_z.upload(zm, stream2);
         sl.n_act_x = (int)ax.size();
         sl.n_act_y = (int)ay.size();
         sl.act_x.upload(ax, stream2);
@@ -1173,7 +1204,6 @@ struct Solver final : SolverBase {
         sl.S4.alloc(sl.nown);
         sl.W1.alloc(sl.nown);
         HIPCHK(hipMemsetAsync(sl.S1.p, 0, sl.nown * sizeof(T), stream2));
-        HIPCHK(hipMemsetAsync(sl.S2.p, 0, sl.nown * sizeof(T), stream2));
         HIPCHK(hipStreamSynchronize(stream2));
     }
     static int log2n_of(int v) {
@@ -1199,10 +1229,10 @@ struct Solver final : SolverBase {
         Q.in = plain_addr(0, L, plane, 1, nn);
         Q.out = Q.in;
         launch_dct<DCT_FWD, TP, TP, false, false>(Q, sl.n_act_y, sl.S1.p, sl.S2.p, (const TP*)nullptr, nullptr, sl.act_y.p);
-        // z-fused, dense: S2 -> W1
+        // z-fused over all lines, but only the active planes are read (the others hold zeros) and written (the others are not needed): S2 -> W1
         Q.in = plain_addr(0, L, nn, 1, plane);
         Q.out = Q.in;
-        launch_dct<DCT_FUSED, TP, TP, false, false>(Q, tiles_all, sl.S2.p, sl.W1.p, (const TP*)nullptr, nullptr);
+        launch_dct<DCT_FUSED, TP, TP, false, false>(Q, tiles_all, sl.S2.p, sl.W1.p, (const TP*)nullptr, nullptr, nullptr, sl.act_z.p);
         // y-inv on the active planes: W1 -> S4
         Q.in = plain_addr(0, L, plane, 1, nn);
         Q.out = Q.in;
@@ -1236,9 +1266,9 @@ struct Solver final : SolverBase {
         };
         auto precondition = [&](int init) {  // z = Pm(G^-1 B G^-1 r); p = z (+ beta p)
             for (Slab<T>& sl : slabs) {
-                hipLaunchKernelGGL(ginv_matvec_kernel, dim3((m + 3) / 4), dim3(kBlock), 0, stream, m, mp, Ginv.p, mv(sl, V_R), mv(sl, V_T1));
+                hipLaunchKernelGGL(ginv_matvec_kernel<float>, dim3(m), dim3(kBlock), 0, stream, m, mp, Ginv32.p, mv(sl, V_R), mv(sl, V_T1));
                 hipLaunchKernelGGL(csr_matvec_kernel, dim3((m + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, m, Bptr.p, Bcol.p, Bval.p, mv(sl, V_T1), mv(sl, V_T2));
-                hipLaunchKernelGGL(ginv_matvec_kernel, dim3((m + 3) / 4), dim3(kBlock), 0, stream, m, mp, Ginv.p, mv(sl, V_T2), mv(sl, V_Z));
+                hipLaunchKernelGGL(ginv_matvec_kernel<float>, dim3(m), dim3(kBlock), 0, stream, m, mp, Ginv32.p, mv(sl, V_T2), mv(sl, V_Z));
                 hipLaunchKernelGGL(dual_direction_kernel, dim3(1), dim3(kDualBlock), 0, stream, m, init, mv(sl, V_R), mv(sl, V_Z), mv(sl, V_P), sl.sc.p);
             }
         };
@@ -1296,7 +1326,9 @@ struct Solver final : SolverBase {
             HIPCHK(hipStreamSynchronize(stream));
             rr0 = h_pinned[SC_RR0];
             rr = h_pinned[SC_RR];
-            if (!std::isfinite(rr) || !std::isfinite(rr0) || !std::isfinite(h_pinned[SC_RZ])) breakdown = true;
+            static const int force_iters = getenv("SHM_DUAL_FORCE_ITERS") ? atoi(getenv("SHM_DUAL_FORCE_ITERS")) : 0;  // timing experiments only
+            if (force_iters > 0) converged = it >= force_iters;
+            else if (!std::isfinite(rr) || !std::isfinite(rr0) || !std::isfinite(h_pinned[SC_RZ])) breakdown = true;
             else if (rr <= o.tol * o.tol * rr0) converged = true;
             log("[shm] dual it=%d rel_res=%.3e", it, std::sqrt(std::fabs(rr / rr0)));
         }

@@ -119,6 +119,9 @@ template <> struct YukawaMath<float> {
     }
     static __device__ __forceinline__ float exp_neg(float x) { return __expf(x); }
 };
+template <typename T> __device__ __forceinline__ T t_rcp(T x);
+template <> __device__ __forceinline__ double t_rcp<double>(double x) { return __builtin_amdgcn_rcp(x); }
+template <> __device__ __forceinline__ float t_rcp<float>(float x) { return __builtin_amdgcn_rcpf(x); }
 template <typename T> __device__ __forceinline__ T t_sqrt(T x);
 template <> __device__ __forceinline__ double t_sqrt<double>(double x) { return sqrt(x); }
 template <> __device__ __forceinline__ float t_sqrt<float>(float x) { return sqrtf(x); }
@@ -652,17 +655,52 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(int m, const int* _
     red[1 + row] = s;
 }
 
-// u = Ginv * w  (Ginv = (A A^T)^-1, dense, row-major, leading dimension ld); one wave per row.
-__global__ __launch_bounds__(kBlock) void ginv_matvec_kernel(int m, int ld, const double* __restrict__ Ginv, const double* __restrict__ w,
+// u = Ginv * w  (Ginv = (A A^T)^-1, dense, row-major, leading dimension ld, a multiple of 4).  One workgroup per row, four
+// consecutive columns per lane and load (16 or 32 bytes); rows up to 4096 columns are fetched with every load of the row in flight
+// at once (the kernel is pure latency otherwise: a row is only 11-23 KB).  TM = float: the dual solver's preconditioner reads a
+// single-precision copy (any fixed symmetric positive definite operator will do there); products and sums stay in double.
+template <typename TM>
+__global__ __launch_bounds__(kBlock) void ginv_matvec_kernel(int m, int ld, const TM* __restrict__ Ginv, const double* __restrict__ w,
                                                              double* __restrict__ u) {
-    const int row = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= m) return;
-    const double* g = Ginv + (size_t)row * ld;
+    __shared__ double lds[8];
+    const int row = blockIdx.x;
+    const TM* g = Ginv + (size_t)row * ld;
+    auto load4 = [&](int c, TM (&gv)[4]) {
+        if (sizeof(TM) == 4) *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(g + c);
+        else {
+            *reinterpret_cast<double2*>(gv) = *reinterpret_cast<const double2*>(g + c);
+            *reinterpret_cast<double2*>(gv + 2) = *reinterpret_cast<const double2*>(g + c + 2);
+        }
+    };
+    auto dot4 = [&](int c, const TM (&gv)[4]) {
+        double s = (double)gv[0] * w[c];
+        if (c + 1 < m) s += (double)gv[1] * w[c + 1];
+        if (c + 2 < m) s += (double)gv[2] * w[c + 2];
+        if (c + 3 < m) s += (double)gv[3] * w[c + 3];
+        return s;
+    };
     double s = 0.;
-    for (int c = lane; c < m; c += kWave) s += g[c] * w[c];
-    s = wave_sum(s);
-    if (lane == 0) u[row] = s;
+    if (m <= 4 * kBlock * 4) {
+        TM gv[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            const int c = (threadIdx.x + a * kBlock) * 4;
+            if (c < m) load4(c, gv[a]);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            const int c = (threadIdx.x + a * kBlock) * 4;
+            if (c < m) s += dot4(c, gv[a]);
+        }
+    } else {
+        for (int c = threadIdx.x * 4; c < m; c += kBlock * 4) {
+            TM gv[4];
+            load4(c, gv);
+            s += dot4(c, gv);
+        }
+    }
+    s = block_sum(s, lds);
+    if (threadIdx.x == 0) u[row] = s;
 }
 
 // v[node] -= sum_e coef * u[row]  (node-major lists: no atomics, deterministic); block 0 also

@@ -13,6 +13,9 @@ typedef Cplx<double> C;
 #ifndef TEST_LC
 #define TEST_LC 8
 #endif
+#ifndef TEST_POW
+#define TEST_POW false   // true: inter-pass twiddles from the power tree (what the device uses for n >= 512)
+#endif
 constexpr int kFftLC = TEST_LC, kFftRow = TEST_LC + 1;
 
 template <int LOG2N, int R, int NS, int SIGN> static void run_pass(std::vector<C>& buf, const std::vector<C>& tw) {
@@ -20,7 +23,7 @@ template <int LOG2N, int R, int NS, int SIGN> static void run_pass(std::vector<C
     std::vector<C> regs((size_t)items * R);
     for (int w = 0; w < items; w++) {  // "before the barrier"
         C v[R];
-        pass_load<double, LOG2N, R, NS, SIGN, kFftLC>(buf.data(), tw.data(), w, v);
+        pass_load<double, LOG2N, R, NS, SIGN, kFftLC, TEST_POW>(buf.data(), tw.data(), w, v);
         for (int r = 0; r < R; r++) regs[(size_t)w * R + r] = v[r];
     }
     for (int w = 0; w < items; w++) {  // "after the barrier"

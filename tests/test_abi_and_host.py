@@ -121,6 +121,7 @@ def test_fft_core_on_host(tmp_path):
     host against naive O(n^2) transforms for every supported length."""
     import subprocess
     exe = str(tmp_path / "test_fft_core")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "native", "test_fft_core.cpp"), "-o", exe])
-    out = subprocess.run([exe], capture_output=True, text=True)
-    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout
+    for flags in ([], ["-DTEST_POW=true"], ["-DTEST_LC=4", "-DTEST_POW=true"]):
+        subprocess.check_call(["g++", "-O2", "-std=c++17"] + flags + [os.path.join(ROOT, "tests", "native", "test_fft_core.cpp"), "-o", exe])
+        out = subprocess.run([exe], capture_output=True, text=True)
+        assert out.returncode == 0 and out.stdout.strip().endswith("OK"), (flags, out.stdout)
