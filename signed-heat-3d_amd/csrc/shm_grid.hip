@@ -1373,7 +1373,13 @@ struct Solver final : SolverBase {
             st->kernel_samples = nsamples;
             st->preconditioner = SHM_PRECOND_DCT;
             st->solver = SHM_SOLVER_DUAL;
-            st->bytes_per_iter = (double)N * (3.0 * sizeof(T) + 8.0 * sizeof(TP)) - (double)N * sizeof(T);  // five DCT sweeps, no r.z read
+            if (sparse_ok) {  // bytes the five sparse sweeps actually move: active x tiles, active planes (y sweeps and the masked z sweep)
+                const double L = dct_lines_for(log2n), tile_bytes = L * n * sizeof(TP);
+                const double planes_active = (double)slabs[0].n_act_y / (n / L);
+                st->bytes_per_iter = 4.0 * slabs[0].n_act_x * tile_bytes + 4.0 * slabs[0].n_act_y * tile_bytes + 2.0 * planes_active * n * n * sizeof(TP);
+            } else {
+                st->bytes_per_iter = (double)N * (3.0 * sizeof(T) + 8.0 * sizeof(TP)) - (double)N * sizeof(T);  // five dense DCT sweeps, no r.z read
+            }
         }
         if (breakdown) throw Error(SHM_ERR_BREAKDOWN, fmt("dual CG broke down at iteration %d (rr=%g, rr0=%g)", it, rr, rr0));
         if (!converged) throw Error(SHM_ERR_NOCONV, fmt("dual CG: max_iters=%d reached, rel. residual %.3e > tol %.1e", o.max_iters,
