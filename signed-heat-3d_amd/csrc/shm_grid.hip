@@ -469,10 +469,9 @@ struct Solver final : SolverBase {
             P.far_gap = (float)conv_far_gap;
             P.tiles_x = (n + kConvTile - 1) / kConvTile;
             P.tiles_y = P.tiles_x;
-            // nodes per lane (a z-column sharing dx^2 + dy^2): 4 when the grid still yields a full wave of workgroups, else 2;
-            // the fp32 kernel keeps 2 (its per-tile exponent offset wants compact tiles)
+            // nodes per lane (a z-column sharing dx^2 + dy^2): 4 when the grid still yields a full wave of workgroups, else 2
             const int planes = P.kk_end - P.kk_begin;
-            const bool npt4 = sizeof(T) == 8 && (long long)P.tiles_x * P.tiles_y * ((planes + 15) / 16) >= conv_grid_cap;
+            const bool npt4 = (long long)P.tiles_x * P.tiles_y * ((planes + 15) / 16) >= conv_grid_cap;
             const int tile_z = npt4 ? 16 : 8;
             const double half_z = 0.5 * (tile_z - 1);
             const double tile_diam = 2.0 * std::sqrt(2 * 3.5 * 3.5 + half_z * half_z) * cell;

@@ -143,6 +143,7 @@ struct ConvParams {
     int n_tiles;        // total tiles; workgroups stride over them (fewer workgroups than slots leave room for the set-up stream)
 };
 
+typedef float float2v __attribute__((ext_vector_type(2)));
 constexpr int kConvTile = 8;      // 8x8x8 nodes per workgroup, 2 per lane
 constexpr int kConvCluster = 64;  // sources per cluster (Morton-sorted on the host)
 constexpr int kConvChunk = kSrcTile / kConvCluster;  // clusters per LDS fill
@@ -249,8 +250,11 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
 #pragma unroll
         for (int e = 0; e < NPT; e++) d0[e] = (T)(sqrtf(m2[e]) * 0.99999f);
     }
-    const T lam = (T)P.lambda;
     const float lamf = (float)P.lambda;
+    const float cexp32 = (float)(-P.lambda * 1.4426950408889634);   // fp32 path: exponent in powers of two
+    float coff[NPT];
+#pragma unroll
+    for (int e = 0; e < NPT; e++) coff[e] = (float)(P.lambda * 1.4426950408889634 * (double)d0[e]);
     for (int c0 = 0; c0 < P.n_clusters; c0 += kConvChunk) {
         const int ncl = min(kConvChunk, P.n_clusters - c0);
         const int cnt = ncl * kConvCluster;
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
                         fx[e] += wx * g; fy[e] += wy * g; fz[e] += wz * g;
                     }
                 }
-            } else {
+            } else if constexpr (kMixed) {
 #pragma unroll 2
                 for (int s = c * kConvCluster; s < (c + 1) * kConvCluster; s++) {
                     const T sz = tile[6 * s + 2];
@@ -294,16 +298,34 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
 #pragma unroll
                     for (int e = 0; e < NPT; e++) {
                         const T dz = pz[e] - sz;
-                        const T d2 = dxy2 + dz * dz;
-                        T g;   // r = 0 -> NaN, like exp(0)/0 = inf -> NaN after normalise
-                        if constexpr (kMixed) {
-                            g = YukawaMath<double>::yukawa(d2, P.cexp, exp_tab);
-                        } else {
-                            float r, rinv;
-                            YukawaMath<float>::rsqrt_and_sqrt(d2, rinv, r);
-                            g = YukawaMath<float>::exp_neg(-lam * (r - d0[e])) * rinv;
-                        }
+                        const T g = YukawaMath<double>::yukawa(dxy2 + dz * dz, P.cexp, exp_tab);   // r = 0 -> NaN, like exp(0)/0 = inf -> NaN after normalise
                         ax[e] += wx * g; ay[e] += wy * g; az[e] += wz * g;
+                    }
+                }
+            } else {
+                // fp32: the lane's nodes two at a time in packed registers (v_pk_add/mul/fma_f32: two values per issue slot); per pair
+                // of nodes and source: 8 packed + 2 v_rsq_f32 + 2 v_exp_f32.  exp(-lambda (r - d0)) = 2^(r c + c0), c = -lambda log2(e).
+                static_assert(NPT % 2 == 0, "packed fp32 path handles the lane's nodes in pairs");
+#pragma unroll 2
+                for (int s = c * kConvCluster; s < (c + 1) * kConvCluster; s++) {
+                    const float sz = tile[6 * s + 2];
+                    const float wx = tile[6 * s + 3], wy = tile[6 * s + 4], wz = tile[6 * s + 5];
+                    const float dx = px - tile[6 * s], dy = py - tile[6 * s + 1];
+                    const float dxy2 = dx * dx + dy * dy;
+#pragma unroll
+                    for (int e = 0; e < NPT; e += 2) {
+                        const float2v z2 = {pz[e], pz[e + 1]}, c02 = {coff[e], coff[e + 1]};
+                        const float2v dz = z2 - sz;
+                        const float2v d2 = __builtin_elementwise_fma(dz, dz, float2v{dxy2, dxy2});
+                        const float2v rinv = {__builtin_amdgcn_rsqf(d2.x), __builtin_amdgcn_rsqf(d2.y)};   // r = 0 -> inf -> NaN below
+                        const float2v r = d2 * rinv;
+                        const float2v arg = __builtin_elementwise_fma(r, float2v{cexp32, cexp32}, c02);
+                        const float2v ex = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+                        const float2v g = ex * rinv;
+                        float2v a;
+                        a = __builtin_elementwise_fma(float2v{wx, wx}, g, float2v{ax[e], ax[e + 1]}); ax[e] = a.x; ax[e + 1] = a.y;
+                        a = __builtin_elementwise_fma(float2v{wy, wy}, g, float2v{ay[e], ay[e + 1]}); ay[e] = a.x; ay[e + 1] = a.y;
+                        a = __builtin_elementwise_fma(float2v{wz, wz}, g, float2v{az[e], az[e + 1]}); az[e] = a.x; az[e + 1] = a.y;
                     }
                 }
             }
