@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--tol", type=float, default=0.0, help="projected-CG relative residual tolerance (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precond", default="auto", choices=["auto", "none", "dct"])
-    ap.add_argument("--solver", default="auto", choices=["auto", "primal", "dual"])
+    ap.add_argument("--solver", default="auto", choices=["auto", "primal", "dual", "dual_slabs"])
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the bootstrap/timing collectives (gloo + SHM_RCCL_LIB + SHM_BENCH_ONE_DEVICE=1 lets "
                          "several ranks share one GPU in tests)")
@@ -192,7 +192,8 @@ def main():
         # per-kernel algorithmic bytes of the decomposition launched; per rank = per launch
         n_local = N / world
         has_pre = int(avg["preconditioner"]) == 2
-        is_dual = int(avg["solver"]) == 2
+        is_dual = int(avg["solver"]) in (2, 3)
+        gathered = world > 1 and int(avg["solver"]) == 2   # every rank solved the whole grid after gathering D^T Y
         TP = T  # the preconditioner sweeps run in the solve precision
         # name: (algorithmic bytes per launch, avg ms per launch, launches per CG iteration)
         kernels = {
@@ -205,7 +206,7 @@ def main():
         if is_dual:
             # the dual solver has no N-sized CG sweeps (its vectors are m-dimensional); on one GPU its five sweeps per iteration are
             # sparse (active x tiles, active z-planes, masked z I/O) and the library reports the bytes they actually move
-            kernels = {"dct_lines_kernel": (avg["bytes_per_iter"] / world / 5.0, avg["ms_precond_avg"] / 5.0, 5)}
+            kernels = {"dct_lines_kernel": (avg["bytes_per_iter"] / (1 if gathered else world) / 5.0, avg["ms_precond_avg"] / 5.0, 5)}
         kinfo = {k: {"algorithmic_bytes_per_launch": b, "avg_ms_per_launch": ms, "launches_per_iter": cnt,
                      "achieved_GBps": (b / (ms * 1e-3) / 1e9 if ms > 0 else None)}
                  for k, (b, ms, cnt) in kernels.items()}
@@ -226,12 +227,15 @@ def main():
             "config": {"workload": args.workload, "grid": "%d^3" % n, "sources": int(pre["S"]), "constraint_rows": int(avg["m"]),
                        "tol": args.tol if args.tol > 0 else (1e-8 if precision == 64 else 1e-5), "cg_iters": int(avg["iters"]),
                        "rel_residual": avg["rel_residual"], "partition": "z-slabs x%d" % world,
-                       "solver": "dual: CG on the Schur complement A K^+ A^T, K^+ = DCT fast Poisson solve" if is_dual else "primal: projected stencil CG",
+                       "solver": ("dual: CG on the Schur complement A K^+ A^T, K^+ = DCT fast Poisson solve"
+                                  + ("; Steps 1-2 on z-slabs, D^T Y gathered over RCCL, whole-grid solve on every rank" if gathered else
+                                     "; z-slab DCT with two all-to-alls per application" if int(avg["solver"]) == 3 else "")) if is_dual
+                       else "primal: projected stencil CG",
                        "preconditioner": ("G^-1 (A K A^T) G^-1" if is_dual else "dct (exact fast Poisson, sandwiched P M^-1 P)") if has_pre else "none"},
             "phases_ms": {k: avg[k] for k in ("ms_conv", "ms_div", "ms_setup", "ms_wait_setup", "ms_pcg", "ms_shift", "ms_total")},
-            "pcg": {"ms_per_iter": avg["ms_pcg"] / max(1.0, avg["iters"]), "algorithmic_bytes_per_iter": avg["bytes_per_iter"] / world,
-                    "achieved_GBps": avg["bytes_per_iter"] / world / (avg["ms_pcg"] / max(1.0, avg["iters"]) * 1e-3) / 1e9,
-                    "frac_of_hbm_peak": avg["bytes_per_iter"] / world / (avg["ms_pcg"] / max(1.0, avg["iters"]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "pcg": {"ms_per_iter": avg["ms_pcg"] / max(1.0, avg["iters"]), "algorithmic_bytes_per_iter": avg["bytes_per_iter"] / (1 if gathered else world),
+                    "achieved_GBps": avg["bytes_per_iter"] / (1 if gathered else world) / (avg["ms_pcg"] / max(1.0, avg["iters"]) * 1e-3) / 1e9,
+                    "frac_of_hbm_peak": avg["bytes_per_iter"] / (1 if gathered else world) / (avg["ms_pcg"] / max(1.0, avg["iters"]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "ms_project_avg": avg["ms_project_avg"]},
             "kernels": kinfo,
             # Step 1+2 is compute-bound on the vector ALU: 18 nominal flop per (node, source) pair against the

@@ -80,15 +80,20 @@ typedef struct {
     int32_t max_iters;        /* <=0 -> default 20*n */
     int32_t check_every;      /* residual is inspected on the host every this many iterations; <=0 -> 32 (4 with the preconditioner) */
     int32_t preconditioner;   /* SHM_PRECOND_AUTO | _NONE | _DCT  (primal solver only) */
-    int32_t solver;           /* SHM_SOLVER_AUTO | _PRIMAL | _DUAL */
+    int32_t solver;           /* SHM_SOLVER_AUTO | _PRIMAL | _DUAL | _DUAL_SLABS */
 } shm_opts;
 
 /* How the KKT system of signed_heat_grid_solver.cpp:101-107 is solved.
  * PRIMAL: projected (optionally DCT-preconditioned) CG on the N grid unknowns -- the matrix-free 7-point-stencil PCG.
  * DUAL:   CG on the m x m Schur complement S = A K^+ A^T (K^+ = DCT fast Poisson solve) for the multipliers, preconditioned by
  *         (A A^T)^-1 (A K A^T) (A A^T)^-1; needs the DCT (n = 2^k).  Same solution, ~2x fewer and ~2x cheaper iterations.
- * AUTO:   DUAL when the DCT is available, else PRIMAL. */
-enum { SHM_SOLVER_AUTO = 0, SHM_SOLVER_PRIMAL = 1, SHM_SOLVER_DUAL = 2 };
+ * AUTO:   DUAL when the DCT is available, else PRIMAL.
+ * With several processes (world > 1) Steps 1-2 and the divergence always run on the rank's z-slab.  DUAL / AUTO then gather the
+ * right-hand side D^T Y (one N-vector, grouped ncclSend/ncclRecv) and every rank runs the single-GPU dual solve on the whole grid
+ * (its iteration is m-dimensional and latency-bound: slicing it buys nothing, exchanging its transposes costs more than it saves);
+ * DUAL_SLABS keeps the solve distributed as well (z-slab DCT with two all-to-alls per application), PRIMAL is the z-slab stencil
+ * CG with halo exchange.  phi comes back per rank for its own planes in every case. */
+enum { SHM_SOLVER_AUTO = 0, SHM_SOLVER_PRIMAL = 1, SHM_SOLVER_DUAL = 2, SHM_SOLVER_DUAL_SLABS = 3 };
 
 /* Preconditioner of the projected CG.  DCT = exact fast Poisson solve (3-D DCT-II diagonalises the reference's
  * Neumann Laplacian, signed_heat_grid_solver.cpp:278-334) sandwiched between constraint projections; needs n = 2^k,
@@ -117,7 +122,7 @@ typedef struct {
     double ms_precond_avg;    /* z = M^-1 r: five DCT sweeps (0 without preconditioner)   10NT(+1NT for r.z) */
     int32_t kernel_samples;   /* how many iterations were sampled for the averages above */
     int32_t preconditioner;   /* SHM_PRECOND_NONE or SHM_PRECOND_DCT: what actually ran */
-    int32_t solver;           /* SHM_SOLVER_PRIMAL or SHM_SOLVER_DUAL: what actually ran */
+    int32_t solver;           /* SHM_SOLVER_PRIMAL, SHM_SOLVER_DUAL or SHM_SOLVER_DUAL_SLABS: what actually ran */
     double bytes_per_iter;    /* algorithmic HBM bytes per CG iteration of the decomposition launched */
 } shm_stats;
 

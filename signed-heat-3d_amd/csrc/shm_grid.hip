@@ -232,8 +232,11 @@ struct Solver final : SolverBase {
     double* h_pinned = nullptr;
     Rccl::comm_t comm = nullptr;
     int vec = 1;  // vector width usable for this n
+    // world > 1: the whole-grid solver every rank runs after the right-hand side has been gathered (see solve_gathered)
+    std::unique_ptr<Solver<T>> full;
+    bool solve_only = false;  // this instance is such a whole-grid solver: it never runs Steps 1-2, so it owns no Y arrays
 
-    explicit Solver(const shm_config& c) : cfg(c) {
+    explicit Solver(const shm_config& c, bool solve_only_ = false) : cfg(c), solve_only(solve_only_) {
         int ndev = 0;
         hipError_t e = hipGetDeviceCount(&ndev);
         if (e != hipSuccess || ndev <= 0)
@@ -426,10 +429,12 @@ struct Solver final : SolverBase {
             sl.nown = sl.plane * sl.nzl;
             sl.ntot = sl.plane * (sl.nzl + 2);
             if (sl.ntot >= ((size_t)1 << 32)) throw Error(SHM_ERR_INVALID, "slab too large for 32-bit local node indices; use more slabs");
-            for (DevArray<T>* a : {&sl.Y0, &sl.Y1, &sl.Y2, &sl.r, &sl.x, &sl.p, &sl.q}) a->alloc(sl.ntot);
+            if (!solve_only)
+                for (DevArray<T>* a : {&sl.Y0, &sl.Y1, &sl.Y2}) a->alloc(sl.ntot);
+            for (DevArray<T>* a : {&sl.r, &sl.x, &sl.p, &sl.q}) a->alloc(sl.ntot);
             // ghosts of p are read only where a neighbour exists, but zero everything once for hygiene
             HIPCHK(hipMemsetAsync(sl.p.p, 0, sl.ntot * sizeof(T), stream));
-            HIPCHK(hipMemsetAsync(sl.Y2.p, 0, sl.ntot * sizeof(T), stream));
+            if (!solve_only) HIPCHK(hipMemsetAsync(sl.Y2.p, 0, sl.ntot * sizeof(T), stream));
             sl.partials.alloc(std::max<size_t>(kMaxPartials, (size_t)n * n / 8 + 8));
             sl.pq.alloc(1);
             sl.sc.alloc(SC_COUNT);
@@ -444,6 +449,19 @@ struct Solver final : SolverBase {
         precond_ready = false;
         have_problem = true;
         have_conv = have_div = have_phi = have_constraints = false;
+        if (cfg.world > 1 && !solve_only && n >= 16 && n <= 1024 && (n & (n - 1)) == 0) {
+            if (!full) {
+                shm_config c = cfg;
+                c.world = 1;
+                c.rank = 0;
+                c.local_slabs = 1;
+                c.rccl_unique_id = nullptr;
+                full.reset(new Solver<T>(c, true));
+            }
+            full->set_problem(src, g);
+        } else {
+            full.reset();
+        }
         log("[shm] problem set: n=%d N=%zu S=%lld slabs=%d(local %d) vec=%d", n, N, (long long)S, total_slabs, cfg.local_slabs, vec);
     }
 
@@ -1371,7 +1389,7 @@ struct Solver final : SolverBase {
             st->ms_project_avg = nsamples ? a_rest / nsamples : 0.;  // gather, m-vector algebra, 2 G^-1 mat-vecs, B mat-vec
             st->kernel_samples = nsamples;
             st->preconditioner = SHM_PRECOND_DCT;
-            st->solver = SHM_SOLVER_DUAL;
+            st->solver = total_slabs > 1 ? SHM_SOLVER_DUAL_SLABS : SHM_SOLVER_DUAL;
             if (sparse_ok) {  // bytes the five sparse sweeps actually move: active x tiles, active planes (y sweeps and the masked z sweep)
                 const double L = dct_lines_for(log2n), tile_bytes = L * n * sizeof(TP);
                 const double planes_active = (double)slabs[0].n_act_y / (n / L);
@@ -1383,6 +1401,58 @@ struct Solver final : SolverBase {
         if (breakdown) throw Error(SHM_ERR_BREAKDOWN, fmt("dual CG broke down at iteration %d (rr=%g, rr0=%g)", it, rr, rr0));
         if (!converged) throw Error(SHM_ERR_NOCONV, fmt("dual CG: max_iters=%d reached, rel. residual %.3e > tol %.1e", o.max_iters,
                                                           std::sqrt(std::fabs(rr / rr0)), o.tol));
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // Several processes, dual solver: Steps 1-2 and the divergence ran on this rank's z-slabs (the bulk of the work, perfectly
+    // parallel); the right-hand side b = D^T Y is gathered from all ranks (one N-vector in all, grouped ncclSend/ncclRecv over
+    // xGMI) and every rank runs the single-GPU dual solve on the whole grid, whose constraint set-up overlapped Step 1 as usual.
+    // Each rank keeps phi for its own planes.  (The dual iteration works on m-vectors and a handful of sparse transforms; it is
+    // latency-bound on one GPU already, and its distributed form -- SHM_SOLVER_DUAL_SLABS -- pays two all-to-alls per iteration.)
+    void solve_gathered(const shm_opts& o, shm_stats* st, Event& e_start, Event& e_conv, Event& e_div, std::chrono::steady_clock::time_point wall0) {
+        Solver<T>& F = *full;
+        Slab<T>& fs = F.slabs[0];
+        Event c_s2a, c_s2b, e_gather, f_start, f_setup;
+        c_s2a.record(F.stream2);
+        F.build_constraints();  // on the whole-grid solver's set-up stream: overlaps this rank's Step-1 kernel
+        c_s2b.record(F.stream2);
+        F.setup_precond();
+        const size_t plane = (size_t)n * n;
+        for (Slab<T>& sl : slabs)
+            HIPCHK(hipMemcpyAsync(fs.r.p + (size_t)(sl.k0 + 1) * plane, sl.r.p + plane, sl.nown * sizeof(T), hipMemcpyDeviceToDevice, stream));
+        if (comm) {
+            Rccl& R = Rccl::get();
+            const int dt = sizeof(T) == 8 ? Rccl::kFloat64 : Rccl::kFloat32;
+            R.chk(R.GroupStart(), "ncclGroupStart");
+            for (int peer = 0; peer < cfg.world; peer++) {
+                if (peer == cfg.rank) continue;
+                for (Slab<T>& sl : slabs) R.chk(R.Send(sl.r.p + plane, sl.nown, dt, peer, comm, stream), "ncclSend(gather b)");
+                for (int b = 0; b < cfg.local_slabs; b++) {  // the peer sends its slabs in this order
+                    int32_t k0, k1;
+                    shm_plan_slab(n, total_slabs, peer * cfg.local_slabs + b, &k0, &k1);
+                    R.chk(R.Recv(fs.r.p + (size_t)(k0 + 1) * plane, (size_t)(k1 - k0) * plane, dt, peer, comm, stream), "ncclRecv(gather b)");
+                }
+            }
+            R.chk(R.GroupEnd(), "ncclGroupEnd");
+        }
+        e_gather.record(stream);
+        HIPCHK(hipStreamWaitEvent(F.stream, e_gather.e, 0));
+        f_start.record(F.stream);
+        f_setup.record(F.stream);
+        F.have_div = true;
+        shm_stats cst;
+        F.solve_dual(o, &cst, f_start, f_start, f_start, f_setup, c_s2a, c_s2b, wall0);  // synchronises F.stream; phi = F.q
+        for (Slab<T>& sl : slabs)
+            HIPCHK(hipMemcpyAsync(sl.q.p + plane, fs.q.p + (size_t)(sl.k0 + 1) * plane, sl.nown * sizeof(T), hipMemcpyDeviceToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        have_phi = true;
+        if (st) {
+            *st = cst;
+            st->ms_conv = elapsed(e_start, e_conv);
+            st->ms_div = elapsed(e_conv, e_div);
+            st->ms_wait_setup = elapsed(e_div, e_gather);  // here: the gather of b (the set-up was waited for on the host before it)
+            st->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+        }
     }
 
     // ------------------------------------------------------------------------------------------
@@ -1414,11 +1484,15 @@ struct Solver final : SolverBase {
             solve_fast(o, st, e_start, e_conv, e_div, wall0);
             return;
         }
+        if (full && (o.solver == SHM_SOLVER_AUTO || o.solver == SHM_SOLVER_DUAL) && o.preconditioner != SHM_PRECOND_NONE) {
+            solve_gathered(o, st, e_start, e_conv, e_div, wall0);
+            return;
+        }
         e_s2a.record(stream2);
         build_constraints();  // on stream2: overlaps the Step-1 kernel; returns once (A A^T)^-1 is ready
         e_s2b.record(stream2);
         bool dual = false;
-        if (o.solver == SHM_SOLVER_DUAL) {
+        if (o.solver == SHM_SOLVER_DUAL || o.solver == SHM_SOLVER_DUAL_SLABS) {
             if (!precond_available()) throw Error(SHM_ERR_INVALID, "the dual solver needs the DCT: n = 2^k in [16,1024] and a power-of-two number of z-slabs dividing n");
             dual = true;
         } else if (o.solver == SHM_SOLVER_AUTO) {

@@ -172,7 +172,7 @@ class GridSolver:
 
     PRECOND = {"auto": 0, "none": 1, "dct": 2}
 
-    SOLVER = {"auto": 0, "primal": 1, "dual": 2}
+    SOLVER = {"auto": 0, "primal": 1, "dual": 2, "dual_slabs": 3}
 
     def solve(self, tol=0.0, max_iters=0, check_every=0, scrub=True, fast=False, allow_noconv=False, precond="auto", solver="auto"):
         o = _Opts(int(fast), int(scrub), float(tol), int(max_iters), int(check_every), self.PRECOND[precond], self.SOLVER[solver])

@@ -17,8 +17,9 @@ def main():
     s = shm.GridSolver(device=0, rank=rank, world=world, rccl_unique_id=bytes.fromhex(uid_hex))
     s.set_problem(d["pos"], d["wnormal"], d["area"], float(d["lam"]), int(d["n"]), d["bbox_min"], float(d["cell"]))
     kw = {"primal-plain": dict(solver="primal", precond="none"), "primal-dct": dict(solver="primal", precond="dct"),
-          "dual": dict(solver="dual"), "fast": dict(fast=True)}[mode]
+          "dual": dict(solver="dual"), "dual-slabs": dict(solver="dual_slabs"), "fast": dict(fast=True)}[mode]
     st = s.solve(tol=1e-10, **kw)
+    assert st.solver == {"dual": 2, "dual-slabs": 3}.get(mode, st.solver)
     phi, (k0, k1) = s.get_phi()
     np.save(os.path.join(out_dir, "phi_%d.npy" % rank), phi)
     np.save(os.path.join(out_dir, "meta_%d.npy" % rank), np.array([k0, k1, st.iters, st.shift]))

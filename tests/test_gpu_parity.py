@@ -510,10 +510,11 @@ def test_preconditioner_1024_property(shm):
 
 
 # ---- several PROCESSES (ranks) on one GPU through a shared-memory double of librccl --------------------------------------
-@pytest.mark.parametrize("world,mode", [(2, "dual"), (4, "dual"), (2, "primal-plain"), (2, "primal-dct"), (4, "fast")])
+@pytest.mark.parametrize("world,mode", [(2, "dual"), (4, "dual"), (2, "dual-slabs"), (4, "dual-slabs"), (2, "primal-plain"), (2, "primal-dct"), (4, "fast")])
 def test_multiprocess_ranks_on_one_gpu(shm, tmp_path, world, mode):
-    """The real multi-rank code path (rank-major z-slabs, halo send/recv, all-reduces, the all-to-all transposes of the distributed
-    DCT, the slab-chained fast integration) with one process per rank.  RCCL refuses two ranks on one device, so its nine entry
+    """The real multi-rank code path (rank-major z-slabs, halo send/recv, all-reduces, the gather of D^T Y in front of the whole-grid
+    dual solve ("dual"), the all-to-all transposes of the distributed DCT ("dual-slabs", "primal-dct"), the slab-chained fast
+    integration) with one process per rank.  RCCL refuses two ranks on one device, so its nine entry
     points are replaced by tests/native/rccl_mock.c (SHM_RCCL_LIB) -- everything above the transport is the product code."""
     import os
     import subprocess
