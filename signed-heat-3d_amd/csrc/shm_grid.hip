@@ -214,6 +214,7 @@ struct Solver final : SolverBase {
     bool have_problem = false, have_conv = false, have_div = false, have_phi = false, have_constraints = false;
     // constraints (replicated)
     std::vector<Row> rows;
+    std::vector<std::vector<ShiftItem>> shift_host;
     int m = 0, mp = 0;
     DevArray<double> Ginv, gjP, gjR, gjC;
     DevArray<float> Ginv32;  // single-precision copy for the dual solver's preconditioner
@@ -576,8 +577,11 @@ struct Solver final : SolverBase {
     // plane evaluates it, so the slabs sum to the reference's nested lerp.
     void build_shift_items(hipStream_t stream) {
         const size_t plane = (size_t)n * n;
-        for (Slab<T>& sl : slabs) {
-            std::vector<ShiftItem> items;
+        shift_host.resize(slabs.size());  // host copies outlive the asynchronous uploads
+        for (size_t si = 0; si < slabs.size(); si++) {
+            Slab<T>& sl = slabs[si];
+            std::vector<ShiftItem>& items = shift_host[si];
+            items.clear();
             for (int64_t s = 0; s < S; s++) {
                 const double* b = &h_pos[3 * s];
                 const int i = (int)std::floor((b[0] - bbox_min[0]) / cell);
@@ -615,60 +619,16 @@ struct Solver final : SolverBase {
         upload_red_tables(stream);
     }
 
-    // Per-slab CSR pieces, shift items, and G = A A^T (sparse triplets -> dense on device -> inverted).
+    // Per-slab CSR pieces, shift items, G = A A^T (sparse triplets -> dense on device -> inverted) and B = A K A^T.
+    // Order: everything the inversion needs first (rows, G), then the Gauss-Jordan kernels are enqueued, and the rest of the host
+    // work (per-slab lists, B, active-tile lists) runs while the GPU inverts; uploads come last (a pageable copy waits for the stream).
     void build_constraints() {
         hipStream_t stream = stream2;  // everything below runs beside the Step-1 kernel of the main stream
         const auto th0 = std::chrono::steady_clock::now();
         auto lap = [&](const char* what) { log("[shm]   setup %-28s %.2f ms", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count()); };
         build_rows();
         lap("rows");
-        build_shift_items(stream);
-        lap("shift items");
         const size_t plane = (size_t)n * n;
-        for (Slab<T>& sl : slabs) {
-            const int64_t lo = (int64_t)sl.k0 * (int64_t)plane, hi = (int64_t)sl.k1 * (int64_t)plane;
-            const int64_t shiftoff = (int64_t)plane - lo;  // global node -> local ghost-layout index
-            std::vector<int> row_ptr(m + 1, 0);
-            std::vector<uint32_t> ent_node;
-            std::vector<double> ent_coef;
-            std::vector<std::pair<uint32_t, std::pair<int, double>>> by_node;
-            for (int r = 0; r < m; r++) {
-                for (int e = 0; e < 8; e++) {
-                    const int64_t g = rows[r].nodes[e];
-                    if (g < lo || g >= hi) continue;
-                    const uint32_t l = (uint32_t)(g + shiftoff);
-                    ent_node.push_back(l);
-                    ent_coef.push_back(rows[r].coeffs[e]);
-                    by_node.push_back({l, {r, rows[r].coeffs[e]}});
-                }
-                row_ptr[r + 1] = (int)ent_node.size();
-            }
-            std::stable_sort(by_node.begin(), by_node.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
-            std::vector<uint32_t> node_id;
-            std::vector<int> node_ptr, ent_row;
-            std::vector<double> nent_coef;
-            for (size_t a = 0; a < by_node.size(); a++) {
-                if (a == 0 || by_node[a].first != by_node[a - 1].first) {
-                    node_id.push_back(by_node[a].first);
-                    node_ptr.push_back((int)a);
-                }
-                ent_row.push_back(by_node[a].second.first);
-                nent_coef.push_back(by_node[a].second.second);
-            }
-            node_ptr.push_back((int)by_node.size());
-            sl.n_touched = (int)node_id.size();
-            sl.row_ptr.upload(row_ptr, stream);
-            sl.ent_node.upload(ent_node, stream);
-            sl.ent_coef.upload(ent_coef, stream);
-            sl.node_id.upload(node_id, stream);
-            sl.node_ptr.upload(node_ptr, stream);
-            sl.ent_row.upload(ent_row, stream);
-            sl.nent_coef.upload(nent_coef, stream);
-            sl.red.alloc((size_t)m + 1);
-            sl.u.alloc((size_t)std::max(m, 1));
-            sl.dv.alloc((size_t)7 * std::max(mp, 64));
-        }
-        lap("per-slab lists");
         // ---- G = A A^T and B = A K A^T from the (node, row, coef) entries sorted by node: rows meet exactly at shared nodes.
         //      Sorted vectors instead of hash maps: the host part of the set-up is on the critical path of small / multi-GPU runs.
         struct Ent { int64_t node; int row; double coef; };
@@ -723,6 +683,37 @@ struct Solver final : SolverBase {
         std::vector<double> tval;
         tidx.reserve((size_t)m * 32 + (mp - m));
         tval.reserve((size_t)m * 32 + (mp - m));
+        std::vector<int> ugs((size_t)8 * m);
+        for (int r = 0; r < m; r++) {  // G = A A^T: rows sharing a node with row r
+            cols.clear();
+            for (int e = 0; e < 8; e++) {
+                const int ug = group_of(rows[r].nodes[e]);
+                ugs[(size_t)8 * r + e] = ug;
+                for (int y = ustart[ug]; y < ustart[ug + 1]; y++) add(2 * r, ents[y].row, rows[r].coeffs[e] * ents[y].coef);
+            }
+            for (int c : cols) {
+                tidx.push_back((uint64_t)r * (uint64_t)mp + (uint64_t)c);
+                tval.push_back(accv[(size_t)c]);
+            }
+        }
+        for (int a = m; a < mp; a++) {  // identity tail keeps the padded matrix SPD
+            tidx.push_back((uint64_t)a * mp + a);
+            tval.push_back(1.0);
+        }
+        lap("G rows");
+        Ginv.alloc((size_t)mp * mp);
+        HIPCHK(hipMemsetAsync(Ginv.p, 0, (size_t)mp * mp * sizeof(double), stream));
+        DevArray<uint64_t> d_tidx;  // alive until the final synchronisation below
+        DevArray<double> d_tval;
+        d_tidx.upload(tidx, stream);
+        d_tval.upload(tval, stream);
+        hipLaunchKernelGGL(scatter_triplets_kernel, dim3(grid_for(tidx.size(), 4096)), dim3(kBlock), 0, stream, (size_t)tidx.size(), d_tidx.p,
+                           d_tval.p, Ginv.p);
+        HIPCHK(hipGetLastError());
+        enqueue_invert_G();
+        lap("G uploaded, inversion enqueued");
+
+        // ---- host work that the inversion does not need, while the GPU inverts
         std::vector<int> bptr(m + 1, 0), bcol;
         std::vector<double> bval;
         bcol.reserve((size_t)m * 128);
@@ -730,19 +721,7 @@ struct Solver final : SolverBase {
         {
             const double ih2 = 1. / (cell * cell);
             const int64_t nn = n, pl = (int64_t)n * n;
-            for (int r = 0; r < m; r++) {
-                int ug[8];
-                // G = A A^T: rows sharing a node with row r
-                cols.clear();
-                for (int e = 0; e < 8; e++) {
-                    ug[e] = group_of(rows[r].nodes[e]);
-                    for (int y = ustart[ug[e]]; y < ustart[ug[e] + 1]; y++) add(2 * r, ents[y].row, rows[r].coeffs[e] * ents[y].coef);
-                }
-                for (int c : cols) {
-                    tidx.push_back((uint64_t)r * (uint64_t)mp + (uint64_t)c);
-                    tval.push_back(accv[(size_t)c]);
-                }
-                // B = A K A^T: K a_r lives on the 8 corners and their in-grid neighbours
+            for (int r = 0; r < m; r++) {  // B = A K A^T: K a_r lives on the 8 corners and their in-grid neighbours
                 cols.clear();
                 for (int e = 0; e < 8; e++) {
                     const int64_t c = rows[r].nodes[e];
@@ -758,7 +737,8 @@ struct Solver final : SolverBase {
                         if (ub < 0) continue;  // K a_r reaches a node no constraint row touches
                         for (int y = ustart[ub]; y < ustart[ub + 1]; y++) add(2 * r + 1, ents[y].row, -cf * ih2 * ents[y].coef);
                     }
-                    for (int y = ustart[ug[e]]; y < ustart[ug[e] + 1]; y++) add(2 * r + 1, ents[y].row, deg * cf * ih2 * ents[y].coef);
+                    const int ug = ugs[(size_t)8 * r + e];
+                    for (int y = ustart[ug]; y < ustart[ug + 1]; y++) add(2 * r + 1, ents[y].row, deg * cf * ih2 * ents[y].coef);
                 }
                 for (int c : cols) {
                     bcol.push_back(c);
@@ -766,51 +746,92 @@ struct Solver final : SolverBase {
                 }
                 bptr[r + 1] = (int)bcol.size();
             }
-            lap("G and B rows");
-            if (total_slabs == 1 && precond_available()) build_active_tiles(unode);
-            Bptr.upload(bptr, stream);
-            Bcol.upload(bcol, stream);
-            Bval.upload(bval, stream);
-            have_B = true;
         }
-        Ginv.alloc((size_t)mp * mp);
-        HIPCHK(hipMemsetAsync(Ginv.p, 0, (size_t)mp * mp * sizeof(double), stream));
-        for (int a = m; a < mp; a++) {  // identity tail keeps the padded matrix SPD
-            tidx.push_back((uint64_t)a * mp + a);
-            tval.push_back(1.0);
+        lap("B rows");
+        struct SlabLists {
+            std::vector<int> row_ptr, node_ptr, ent_row;
+            std::vector<uint32_t> ent_node, node_id;
+            std::vector<double> ent_coef, nent_coef;
+        };
+        std::vector<SlabLists> lists(slabs.size());
+        for (size_t si = 0; si < slabs.size(); si++) {
+            Slab<T>& sl = slabs[si];
+            SlabLists& L = lists[si];
+            const int64_t lo = (int64_t)sl.k0 * (int64_t)plane, hi = (int64_t)sl.k1 * (int64_t)plane;
+            const int64_t shiftoff = (int64_t)plane - lo;  // global node -> local ghost-layout index
+            L.row_ptr.assign(m + 1, 0);
+            std::vector<std::pair<uint32_t, std::pair<int, double>>> by_node;
+            for (int r = 0; r < m; r++) {
+                for (int e = 0; e < 8; e++) {
+                    const int64_t g = rows[r].nodes[e];
+                    if (g < lo || g >= hi) continue;
+                    const uint32_t l = (uint32_t)(g + shiftoff);
+                    L.ent_node.push_back(l);
+                    L.ent_coef.push_back(rows[r].coeffs[e]);
+                    by_node.push_back({l, {r, rows[r].coeffs[e]}});
+                }
+                L.row_ptr[r + 1] = (int)L.ent_node.size();
+            }
+            std::stable_sort(by_node.begin(), by_node.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+            for (size_t a = 0; a < by_node.size(); a++) {
+                if (a == 0 || by_node[a].first != by_node[a - 1].first) {
+                    L.node_id.push_back(by_node[a].first);
+                    L.node_ptr.push_back((int)a);
+                }
+                L.ent_row.push_back(by_node[a].second.first);
+                L.nent_coef.push_back(by_node[a].second.second);
+            }
+            L.node_ptr.push_back((int)by_node.size());
+            sl.n_touched = (int)L.node_id.size();
         }
-        DevArray<uint64_t> d_tidx;
-        DevArray<double> d_tval;
-        d_tidx.upload(tidx, stream);
-        d_tval.upload(tval, stream);
-        hipLaunchKernelGGL(scatter_triplets_kernel, dim3(grid_for(tidx.size(), 4096)), dim3(kBlock), 0, stream, (size_t)tidx.size(), d_tidx.p,
-                           d_tval.p, Ginv.p);
-        HIPCHK(hipGetLastError());
-        lap("uploads");
+        lap("per-slab lists");
+        // ---- uploads (queued behind the inversion on the set-up stream)
+        build_shift_items(stream);
+        for (size_t si = 0; si < slabs.size(); si++) {
+            Slab<T>& sl = slabs[si];
+            SlabLists& L = lists[si];
+            sl.row_ptr.upload(L.row_ptr, stream);
+            sl.ent_node.upload(L.ent_node, stream);
+            sl.ent_coef.upload(L.ent_coef, stream);
+            sl.node_id.upload(L.node_id, stream);
+            sl.node_ptr.upload(L.node_ptr, stream);
+            sl.ent_row.upload(L.ent_row, stream);
+            sl.nent_coef.upload(L.nent_coef, stream);
+            sl.red.alloc((size_t)m + 1);
+            sl.u.alloc((size_t)std::max(m, 1));
+            sl.dv.alloc((size_t)7 * std::max(mp, 64));
+        }
+        if (total_slabs == 1 && precond_available()) build_active_tiles(unode);
+        Bptr.upload(bptr, stream);
+        Bcol.upload(bcol, stream);
+        Bval.upload(bval, stream);
+        have_B = true;
+        upload_red_tables(stream);
         last_host_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
         log("[shm] constraint set-up: host part %.2f ms (m=%d)", last_host_setup_ms, m);
-        invert_G();
-        upload_red_tables(stream);
-        HIPCHK(hipStreamSynchronize(stream));  // d_tidx/d_tval and ptrs go out of scope
+        finish_invert_G();  // synchronises the set-up stream (d_tidx/d_tval go out of scope after it)
         have_constraints = true;
     }
 
-    void invert_G() {
+    void enqueue_invert_G() {
         hipStream_t stream = stream2;
         const int nb = mp / kGJ;
         gjP.alloc(kGJ * kGJ);
         gjR.alloc((size_t)kGJ * mp);
         gjC.alloc((size_t)mp * kGJ);
         gjFlag.alloc(1);
+        Ginv32.alloc((size_t)mp * mp);
         HIPCHK(hipMemsetAsync(gjFlag.p, 0, sizeof(int), stream));
         for (int kb = 0; kb < nb; kb++) {
             hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjP.p, gjFlag.p);
             hipLaunchKernelGGL(gj_panels_kernel, dim3(nb), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjP.p, gjR.p, gjC.p);
             hipLaunchKernelGGL(gj_update_kernel, dim3(nb, nb), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjR.p, gjC.p);
         }
-        Ginv32.alloc((size_t)mp * mp);
         hipLaunchKernelGGL((convert_kernel<double, float>), dim3(grid_for((size_t)mp * mp, 4096)), dim3(kBlock), 0, stream, (size_t)mp * mp, Ginv.p, Ginv32.p);
         HIPCHK(hipGetLastError());
+    }
+    void finish_invert_G() {
+        hipStream_t stream = stream2;
         int flag = 0;
         HIPCHK(hipMemcpyAsync(&flag, gjFlag.p, sizeof(int), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
