@@ -825,8 +825,9 @@ struct Solver final : SolverBase {
         for (int kb = 0; kb < nb; kb++) {
             hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjP.p, gjFlag.p);
             hipLaunchKernelGGL(gj_panels_kernel, dim3(nb), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjP.p, gjR.p, gjC.p);
-            hipLaunchKernelGGL(gj_update_kernel, dim3(nb, nb), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjR.p, gjC.p);
+            hipLaunchKernelGGL(gj_update_kernel, dim3((unsigned)((size_t)nb * (nb + 1) / 2)), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjR.p, gjC.p);
         }
+        if (nb > 1) hipLaunchKernelGGL(gj_mirror_kernel, dim3((unsigned)((size_t)nb * (nb - 1) / 2)), dim3(kBlock), 0, stream, Ginv.p, mp);
         hipLaunchKernelGGL((convert_kernel<double, float>), dim3(grid_for((size_t)mp * mp, 4096)), dim3(kBlock), 0, stream, (size_t)mp * mp, Ginv.p, Ginv32.p);
         HIPCHK(hipGetLastError());
     }

@@ -1009,10 +1009,14 @@ __global__ __launch_bounds__(kBlock) void convert_kernel(size_t count, const TS*
 // identity tail) by blocked Gauss-Jordan without pivoting (Schur complements of an SPD matrix stay
 // SPD).  Setup-time only; replaces the reference's sparse LU of the KKT matrix (:101-107) together
 // with the projected CG.  Per 64-wide pivot block kb:
-//   1. P = inv(G[kb,kb])                                   (one workgroup, LDS)
+//   1. P = inv(G[kb,kb])                                   (one workgroup, registers + LDS)
 //   2. R = P * G[kb,:]  (row panel),  C = G[:,kb] (saved column panel)
-//   3. G[i,j] -= C[i] * R[j]   for i,j outside kb           (rank-64 update, LDS-tiled)
+//   3. G[i,j] -= C[i] * R[j]   for i,j outside kb           (rank-64 update on the matrix cores)
 //   4. G[kb,:] = R ; G[:,kb] = -C * P ; G[kb,kb] = P
+// Symmetry halves the work: between a processed block p and an unprocessed block u the running matrix satisfies
+// M[p,u] = -M[u,p]^T, and M is symmetric inside the processed and inside the unprocessed set, so only the block-lower
+// triangle (i >= j) is kept up to date; the panels are rebuilt from it with the right transposes and signs, the update
+// visits nb(nb+1)/2 tiles, and one mirror pass at the end fills the upper triangle of the inverse.
 // =================================================================================================
 constexpr int kGJ = 64;
 
@@ -1074,27 +1078,32 @@ __global__ __launch_bounds__(kBlock) void gj_pivot_kernel(double* __restrict__ G
         for (int b = 0; b < 4; b++) Pout[(ty * 4 + a) * kGJ + tx * 4 + b] = r[a][b];
 }
 
-// step 2: R[:, jb] = P * G[kb, jb] and C[ib, :] = G[ib, kb] for every block index != kb.
-// grid.x = number of 64-blocks; block b handles column block jb=b of the row panel and row block ib=b
-// of the column panel.
+// step 2: R[:, b] = P * G[kb, b] and C[b, :] = G[b, kb] for every block index b, from the block-lower triangle:
+//   X = stored block (b >= kb ? G[b,kb] : G[kb,b]);   b > kb: G[kb,b] = X^T, G[b,kb] = X;   b < kb: G[kb,b] = X, G[b,kb] = -X^T.
 __global__ __launch_bounds__(kBlock) void gj_panels_kernel(const double* __restrict__ G, int ld, int kb, const double* __restrict__ P,
                                                            double* __restrict__ R /* [64][ld] */, double* __restrict__ C /* [ld][64] */) {
     __shared__ double p[kGJ][kGJ + 1];
-    __shared__ double g[kGJ][kGJ + 1];
+    __shared__ double x[kGJ][kGJ + 1];
     const int b = blockIdx.x;
     const size_t o = (size_t)kb * kGJ, ob = (size_t)b * kGJ;
+    const bool below = b >= kb;
     for (int t = threadIdx.x; t < kGJ * kGJ; t += kBlock) {
         const int i = t / kGJ, j = t % kGJ;
         p[i][j] = P[t];
-        g[i][j] = G[(o + i) * ld + ob + j];                 // row panel block
-        C[(ob + i) * kGJ + j] = G[(ob + i) * ld + o + j];   // column panel block (copy)
+        x[i][j] = below ? G[(ob + i) * ld + o + j] : G[(o + i) * ld + ob + j];
     }
     __syncthreads();
     for (int t = threadIdx.x; t < kGJ * kGJ; t += kBlock) {
         const int i = t / kGJ, j = t % kGJ;
+        C[(ob + i) * kGJ + j] = below ? x[i][j] : -x[j][i];
         double s = 0.;
+        if (b > kb) {
 #pragma unroll 8
-        for (int k = 0; k < kGJ; k++) s += p[i][k] * g[k][j];
+            for (int k = 0; k < kGJ; k++) s += p[i][k] * x[j][k];
+        } else {
+#pragma unroll 8
+            for (int k = 0; k < kGJ; k++) s += p[i][k] * x[k][j];
+        }
         R[(size_t)i * ld + ob + j] = (b == kb) ? p[i][j] : s;  // the pivot block column of R carries P: G[:,kb] = -C P, G[kb,kb] = P
     }
 }
@@ -1111,7 +1120,13 @@ __global__ __launch_bounds__(kBlock) void gj_update_kernel(double* __restrict__ 
                                                            const double* __restrict__ C) {
     __shared__ double cs[kGJ][kGJK + 1];  // C chunk  [i][k]
     __shared__ double rs[kGJK][kGJ + 1];  // R chunk  [k][j]
-    const size_t oi = (size_t)blockIdx.y * kGJ, oj = (size_t)blockIdx.x * kGJ;
+    // tile t of the block-lower triangle: bi = floor((sqrt(8t+1)-1)/2), bj = t - bi(bi+1)/2
+    const unsigned t = blockIdx.x;
+    int bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((unsigned)bi * (unsigned)(bi + 1) / 2 > t) bi--;
+    while ((unsigned)(bi + 1) * (unsigned)(bi + 2) / 2 <= t) bi++;
+    const int bj = (int)(t - (unsigned)bi * (unsigned)(bi + 1) / 2);
+    const size_t oi = (size_t)bi * kGJ, oj = (size_t)bj * kGJ;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wr = w >> 1, wc = w & 1;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -1142,7 +1157,7 @@ __global__ __launch_bounds__(kBlock) void gj_update_kernel(double* __restrict__ 
                 for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
     }
-    const bool prow = (int)blockIdx.y == kb, pcol = (int)blockIdx.x == kb;
+    const bool prow = bi == kb, pcol = bj == kb;
     const size_t o = (size_t)kb * kGJ;
 #pragma unroll
     for (int a = 0; a < 2; a++)
@@ -1159,6 +1174,26 @@ __global__ __launch_bounds__(kBlock) void gj_update_kernel(double* __restrict__ 
             }
 }
 
+// after the last pivot block: G[bj, bi] = G[bi, bj]^T for bi > bj (the inverse is symmetric; only its block-lower triangle was kept)
+__global__ __launch_bounds__(kBlock) void gj_mirror_kernel(double* __restrict__ G, int ld) {
+    __shared__ double x[kGJ][kGJ + 1];
+    const unsigned t = blockIdx.x;   // strictly lower tile: bi >= 1, bj < bi
+    int bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((unsigned)bi * (unsigned)(bi + 1) / 2 > t) bi--;
+    while ((unsigned)(bi + 1) * (unsigned)(bi + 2) / 2 <= t) bi++;
+    const int bj = (int)(t - (unsigned)bi * (unsigned)(bi + 1) / 2);
+    bi += 1;
+    const size_t oi = (size_t)bi * kGJ, oj = (size_t)bj * kGJ;
+    for (int e = threadIdx.x; e < kGJ * kGJ; e += kBlock) {
+        const int i = e / kGJ, j = e % kGJ;
+        x[i][j] = G[(oi + i) * ld + oj + j];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < kGJ * kGJ; e += kBlock) {
+        const int i = e / kGJ, j = e % kGJ;
+        G[(oj + i) * ld + oi + j] = x[j][i];
+    }
+}
 
 // =================================================================================================
 // Isosurface of the grid phi (headless replacement of the demo's Polyscope marching cubes, src/main.cpp:116-128,167-191):
