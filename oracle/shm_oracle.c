@@ -316,6 +316,23 @@ int shmo_constrained_solve(int n_, double cell, const double* b, int m, const in
     for (size_t i = 0; i < N; i++) p[i] = -r[i];
     double rho = dot(N, r, r), rho0 = rho;
     int it = 0;
+    if (!(rho0 == rho0) || rho0 > 1.7e308) {
+        /* non-finite right-hand side (|X|^2 underflowed far from a finely sampled point cloud -> Y = +-inf, and the point overload has
+         * no scrub, :180): the reference's sparse LU (:101-107) propagates it -- the KKT matrix is irreducible, so every entry of the
+         * solution becomes NaN.  Report that instead of leaving the CG loop through a false NaN comparison with x = 0. */
+        for (size_t i = 0; i < N; i++) phi[i] = NAN;
+        if (stats) {
+            stats[0] = 0;
+            stats[1] = NAN;
+            stats[2] = NAN;
+        }
+        free(x);
+        free(r);
+        free(p);
+        free(q);
+        projector_free(&P);
+        return 2;
+    }
     while (it < maxit && rho > tol * tol * rho0) {
         shmo_laplacian_apply(n_, cell, p, q); /* q = L p ; K = -L */
         double pq = -dot(N, p, q);

@@ -258,6 +258,43 @@ def test_matches_c_oracle_128(shm, oracle_c, n, slabs):
     assert np.abs(phi - ref).max() < 1e-7
 
 
+ALL_DATA = ["bunny_small.obj", "polygon-bear.obj", "rocker.obj", "chair.obj", "knot.obj", "bunny.pc", "rocker.pc", "chair.pc", "knot.pc", "SprayBottle.pc"]
+
+
+@pytest.mark.parametrize("fname", ALL_DATA)
+def test_every_data_file_matches_c_oracle_32(shm, oracle_c, fname):
+    """Every input the reference ships (closed, open, non-manifold and polygonal meshes; point clouds), pre-processed by the C++
+    host mirror, through the default HIP path at 32^3 against the C oracle on the same inputs (mesh overload: with the divYt scrub;
+    point overload: without).  Where the reference's own arithmetic breaks down (|X|^2 underflows far from a finely sampled point
+    cloud -> 0/0 -> NaN right-hand side, no scrub in the point overload) the oracle's phi is non-finite and the HIP path must report
+    SHM_ERR_BREAKDOWN instead of returning numbers."""
+    import os
+    from conftest import ROOT
+    from signed_heat_3d_amd.host_abi import HostSolver
+    pre = HostSolver(os.path.join(ROOT, "data", fname)).preprocess(hCoef=1.0)
+    n, S = pre["n"], pre["S"]
+    assert n == 32
+    scrub = not fname.endswith(".pc")
+    ref = np.zeros(n ** 3)
+    st = np.zeros(5)
+    oracle_c.shmo_set_threads(min(32, os.cpu_count() or 1))
+    rc = oracle_c.shmo_compute_distance(n, c_(pre["bbox_min"]), pre["cell"], S, c_(pre["pos"]).reshape(-1), c_(pre["wnormal"]).reshape(-1),
+                                        c_(pre["area"]), pre["lam"], int(scrub), 0, 1e-12, 100000, ref, st)
+    oracle_c.shmo_set_threads(min(8, os.cpu_count() or 1))
+    s = shm.GridSolver()
+    s.set_problem(pre["pos"], pre["wnormal"], pre["area"], pre["lam"], n, pre["bbox_min"], pre["cell"])
+    if rc != 0 or not np.isfinite(ref).all():
+        with pytest.raises(shm.ShmError) as e:
+            s.solve(tol=1e-10, scrub=scrub)
+        assert "BREAKDOWN" in str(e.value)
+        return
+    stg = s.solve(tol=1e-10, scrub=scrub)
+    assert stg.solver == 2
+    phi, _ = s.get_phi()
+    assert np.isfinite(phi).all()
+    assert np.abs(phi - ref).max() < 1e-7 * max(1.0, np.abs(ref).max())
+
+
 def test_errors_are_reported(shm):
     d = load_golden("bunny_small_n16")
     s = shm.GridSolver()

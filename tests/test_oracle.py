@@ -180,6 +180,30 @@ def test_projected_cg_equals_lu(bunny):
     assert np.abs(phi_plain - d["phi"]).max() > 0.1
 
 
+def test_non_finite_rhs_poisons_the_solution_like_the_lu(bunny, oracle_c):
+    """A non-finite entry of D^T Y (point overload: no scrub, :180) makes the reference's LU solve return NaN; the C oracle reports
+    that (rc 2, NaN phi) instead of leaving its CG loop through a false NaN comparison, and the HIP path raises SHM_ERR_BREAKDOWN
+    (tests/test_gpu_parity.py::test_every_data_file_matches_c_oracle_32[SprayBottle.pc])."""
+    V, F = bunny
+    g = o.grid_setup(V, 2.0, 0.0)
+    src = o.mesh_sources(V, F)
+    d = load_golden("bunny_small_n16")
+    b = d["b"].copy()
+    b[1234] = np.inf
+    A = o.constraint_matrix(g, src.pos)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        phi_lu, _ = o.solve_kkt_lu(g, b, A)
+    assert not np.isfinite(phi_lu).any()     # SuperLU, like Eigen::SparseLU, has no NaN guard: the whole vector is lost
+    nodes = np.ascontiguousarray(d["c_nodes"], dtype=np.int64).reshape(-1)
+    coeffs = np.ascontiguousarray(d["c_coeffs"], dtype=np.float64).reshape(-1)
+    phi = np.zeros(g.N)
+    st = np.zeros(3)
+    rc = oracle_c.shmo_constrained_solve(g.n, g.cell, b, len(nodes) // 8, nodes, coeffs, 1e-12, 1000, phi, st)
+    assert rc == 2 and np.isnan(phi).all()
+
+
 def test_sphere_known_answer(oracle_c):
     """Point samples on a unit sphere with outward normals: SHM -> phi ~ |x|-1 (sign, zero set, monotone in radius)."""
     # Fibonacci sphere
