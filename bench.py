@@ -259,7 +259,11 @@ def main():
         if avg["ms_conv"] >= avg["ms_pcg"]:
             out["roofline"] = {"kernel": "conv_normalize_kernel", "bound": "valu", "achieved": s1["achieved_TFLOPs_nominal_18_per_pair"],
                                "peak": s1["peak_TFLOPs_vector"], "unit": "TFLOP/s", "frac": s1["frac"], "traffic": None,
-                               "issue_slots_per_pair": 26.8 if precision == 64 else None,
+                               # wave-instruction issue: slots per pair (ISA count of the inner loop, weighted by the measured issue cost of
+                               # each opcode, tools/valu_probe.hip) x pairs/s / 64 lanes, against 256 CUs x 4 SIMDs x one slot per 4 cycles at
+                               # the 2.4 GHz peak clock (the part sustains ~2.0 GHz under this fp64 load, where the same figure is ~0.98)
+                               "issue_slots_per_pair": 26.8 if precision == 64 else 9.1,
+                               "valu_issue_utilisation_at_peak_clock": (26.8 if precision == 64 else 9.1) * s1["pairs_per_s"] / 64.0 / (1024 * 2.4e9 / 4.0),
                                "note": "one launch per step, duration = phases_ms.ms_conv (HIP events on the solver's stream); achieved = 18 nominal "
                                        "flop x pairs / duration (SURVEY 8(d)); the fp64 loop issues 26.8 VALU slots per pair (20 fp64 ops, "
                                        "v_rsq_f64 = 2.7 slots, 3 integer, shared dx/dy terms) = ~97% of the issue capacity at the 2.0 GHz the part "

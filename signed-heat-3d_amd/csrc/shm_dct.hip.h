@@ -23,6 +23,12 @@
 
 namespace shm {
 
+#ifdef SHM_EXPERIMENT_KNOBS
+#define SHM_DCT_DBG(P, bit) ((P).debug_skip & (bit))
+#else
+#define SHM_DCT_DBG(P, bit) 0
+#endif
+
 enum DctMode : int { DCT_FWD = 0, DCT_INV = 1, DCT_FUSED = 2 };
 // complex lines per tile: 8 (16 real lines = one 128-byte row per element row); 4 at n = 1024, where an fp64 tile of 8 would take
 // 147 KB of LDS (one workgroup per CU).  (Measured at n = 512: 4 instead of 8 lines doubles the residency but halves the access
@@ -45,7 +51,8 @@ struct DctAddr {
 struct DctParams {
     int ntiles;             // tiles of this sweep; the workgroups stride over them (persistent: a workgroup costs more to start than a tile to set up)
     int tiles_a;
-    int debug_skip;         // experiments only (SHM_DCT_SKIP): 1 = no FFT passes, 2 = no spectral step, 4 = no global loads, 8 = no global stores
+    int debug_skip;         // builds with -DSHM_EXPERIMENT_KNOBS only (env SHM_DCT_SKIP, timing experiments): 1 = no FFT passes, 2 = no spectral step,
+                            // 4 = no global loads, 8 = no global stores; always 0 otherwise
     DctAddr in, out;
     // FUSED only: spectral coordinates of line l of tile t: kx = (t % tiles_a)*16 + l ; ky = ky0 + t / tiles_a
     int ky0;
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
             const int idx = tid + (a0 + a) * kBlock;
             if (total % kBlock == 0 || idx < total) {
                 const int j = elem_of(idx);
-                v[a] = (!(P.debug_skip & 4) && (!elem_mask || ((elem_mask[j >> 5] >> (j & 31)) & 1u))) ? (TP)*in_at(in, a0 + a, idx) : (TP)0;
+                v[a] = (!SHM_DCT_DBG(P, 4) && (!elem_mask || ((elem_mask[j >> 5] >> (j & 31)) & 1u))) ? (TP)*in_at(in, a0 + a, idx) : (TP)0;
             }
         }
 #pragma unroll
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
     }
     __syncthreads();
 
-    if ((MODE == DCT_FWD || MODE == DCT_FUSED) && !(P.debug_skip & 1)) dct_fft<TP, LOG2N, -1>(buf, tw, tid);
+    if ((MODE == DCT_FWD || MODE == DCT_FUSED) && !SHM_DCT_DBG(P, 1)) dct_fft<TP, LOG2N, -1>(buf, tw, tid);
 
     if (MODE == DCT_FWD) {
         // ---------------- X[k] = Re(om_k V[k]) straight to global ----------------
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
     }
 
     // ---------------- spectral step on (k, n-k) pairs, k = 0..n/2 ----------------
-    if (!(P.debug_skip & 2)) {
+    if (!SHM_DCT_DBG(P, 2)) {
         const int kx0 = (t % P.tiles_a) * L, ky = P.ky0 + t / P.tiles_a;
         constexpr int pairs = (n / 2 + 1) * kFftLC;
         for (int b = tid; b < pairs; b += kBlock) {
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
         __syncthreads();
     }
 
-    if (!(P.debug_skip & 1)) dct_fft<TP, LOG2N, +1>(buf, tw, tid);
+    if (!SHM_DCT_DBG(P, 1)) dct_fft<TP, LOG2N, +1>(buf, tw, tid);
 
     // ---------------- store: x[j] = v[makhoul_slot(j)] ----------------
     double acc = 0.;
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
             if (total % kBlock == 0 || idx < total) {
                 const int l = line_of(idx), j = elem_of(idx);
                 const TP v = reinterpret_cast<const TP*>(&buf[makhoul_slot(j, n) * kFftRow + (l >> 1)])[l & 1];
-                if (!(P.debug_skip & 8) && (!elem_mask || ((elem_mask[j >> 5] >> (j & 31)) & 1u))) *out_at(out, a0 + a, idx) = (TOut)v;
+                if (!SHM_DCT_DBG(P, 8) && (!elem_mask || ((elem_mask[j >> 5] >> (j & 31)) & 1u))) *out_at(out, a0 + a, idx) = (TOut)v;
                 if (DOT) acc += (double)v * (double)dv[a];
             }
         }

@@ -1008,7 +1008,11 @@ struct Solver final : SolverBase {
         }
         DctParams Q = P;
         Q.ntiles = ntiles;
+#ifdef SHM_EXPERIMENT_KNOBS
         { static const int dbg = getenv("SHM_DCT_SKIP") ? atoi(getenv("SHM_DCT_SKIP")) : 0; Q.debug_skip = dbg; }
+#else
+        Q.debug_skip = 0;
+#endif
         const int per_cu = std::max(1, (int)((size_t)(160 * 1024) / lds));
         const int grid = (int)std::min<long long>(ntiles, std::max<long long>(1, (long long)dct_grid_x16 * num_cus * per_cu / 16));
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), lds, stream, Q, in, out, d_tw.p, d_om.p, d_lam.p, dotw, partials, tile_list, elem_mask);
@@ -1365,7 +1369,11 @@ struct Solver final : SolverBase {
             HIPCHK(hipStreamSynchronize(stream));
             rr0 = h_pinned[SC_RR0];
             rr = h_pinned[SC_RR];
+#ifdef SHM_EXPERIMENT_KNOBS
             static const int force_iters = getenv("SHM_DUAL_FORCE_ITERS") ? atoi(getenv("SHM_DUAL_FORCE_ITERS")) : 0;  // timing experiments only
+#else
+            const int force_iters = 0;
+#endif
             if (force_iters > 0) converged = it >= force_iters;
             else if (!std::isfinite(rr) || !std::isfinite(rr0) || !std::isfinite(h_pinned[SC_RZ])) breakdown = true;
             else if (rr <= o.tol * o.tol * rr0) converged = true;
