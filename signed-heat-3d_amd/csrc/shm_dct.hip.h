@@ -21,9 +21,37 @@
 #include "shm_fft_core.h"
 #include "shm_kernels.hip.h"
 
+// build-time variants (defaults = the measured best; tools/dct_variants.sh rebuilds the others for A/B runs)
+#ifndef SHM_DCT_HOIST
+#define SHM_DCT_HOIST 0        // 1: spectral-step constants of a thread fetched once into registers
+#endif
+#ifndef SHM_DCT_WAVES_HINT
+#define SHM_DCT_WAVES_HINT 9   // smallest log2(n) at which the register allocator is held to the occupancy the LDS footprint allows
+#endif                         // (n = 512: 268 registers without it = one tile per CU instead of two, 2.18 vs 1.62 ms per dual iteration)
+#ifndef SHM_DCT_WAVES_F32
+#define SHM_DCT_WAVES_F32 2     // the same for fp32 tiles (half the LDS, about two thirds of the registers)
+#endif
+#ifndef SHM_DCT_SPECTRAL_ORIG
+#define SHM_DCT_SPECTRAL_ORIG 0
+#endif
+#ifndef SHM_DCT_RUNTIME_GATE
+#define SHM_DCT_RUNTIME_GATE 1   // the phases of a tile (load, FFT, spectral step, store) sit behind run-time conditions on DctParams::debug_skip
+#endif                         // (always 0 in product builds).  Opaque to the compiler, they stop it from hoisting one phase's loads across the
+                               // previous phase, which costs ~60 registers and with them a tile of occupancy at n = 512 (fp32: 1.82 vs 2.18 ms
+                               // per dual iteration at 512^3; fp64 the same without the occupancy hint below)
+#ifndef SHM_DCT_LC8
+#define SHM_DCT_LC8 4          // complex lines per tile at n = 256 (4: 0.224 ms per dual iteration, 8: 0.234)
+#endif
+#ifndef SHM_DCT_TW_LDS_MAX
+#define SHM_DCT_TW_LDS_MAX 8   // largest log2(n) whose twiddle table is copied to LDS
+#endif
+#ifndef SHM_DCT_POW_ALWAYS
+#define SHM_DCT_POW_ALWAYS 1   // 1: inter-pass twiddles from one table read + multiplication tree at every n (else only when the table is global)
+#endif
+
 namespace shm {
 
-#ifdef SHM_EXPERIMENT_KNOBS
+#if defined(SHM_EXPERIMENT_KNOBS) || SHM_DCT_RUNTIME_GATE
 #define SHM_DCT_DBG(P, bit) ((P).debug_skip & (bit))
 #else
 #define SHM_DCT_DBG(P, bit) 0
@@ -33,8 +61,8 @@ enum DctMode : int { DCT_FWD = 0, DCT_INV = 1, DCT_FUSED = 2 };
 // complex lines per tile: 8 (16 real lines = one 128-byte row per element row); 4 at n = 1024, where an fp64 tile of 8 would take
 // 147 KB of LDS (one workgroup per CU).  (Measured at n = 512: 4 instead of 8 lines doubles the residency but halves the access
 // granularity to 64 bytes -- no net change, so 512 keeps the full 128-byte rows.)
-template <int LOG2N> constexpr int dct_lc() { return LOG2N >= 10 ? 4 : 8; }
-constexpr int dct_lines_for(int log2n) { return log2n >= 10 ? 8 : 16; }
+template <int LOG2N> constexpr int dct_lc() { return LOG2N >= 10 ? 4 : (LOG2N == 8 ? SHM_DCT_LC8 : 8); }
+constexpr int dct_lines_for(int log2n) { return log2n >= 10 ? 8 : (log2n == 8 ? 2 * SHM_DCT_LC8 : 16); }
 
 // Address of element k of line l of tile t:
 //   off + (t % tiles_a) a_stride + (t / tiles_a) b_stride + l line_stride + (k >> seg_shift) seg_stride + (k & seg_mask) elem_stride
@@ -51,8 +79,8 @@ struct DctAddr {
 struct DctParams {
     int ntiles;             // tiles of this sweep; the workgroups stride over them (persistent: a workgroup costs more to start than a tile to set up)
     int tiles_a;
-    int debug_skip;         // builds with -DSHM_EXPERIMENT_KNOBS only (env SHM_DCT_SKIP, timing experiments): 1 = no FFT passes, 2 = no spectral step,
-                            // 4 = no global loads, 8 = no global stores; always 0 otherwise
+    int debug_skip;         // always 0 in product builds (see SHM_DCT_RUNTIME_GATE); -DSHM_EXPERIMENT_KNOBS builds take it from env SHM_DCT_SKIP for
+                            // timing experiments: 1 = no FFT passes, 2 = no spectral step, 4 = no global loads, 8 = no global stores
     DctAddr in, out;
     // FUSED only: spectral coordinates of line l of tile t: kx = (t % tiles_a)*16 + l ; ky = ky0 + t / tiles_a
     int ky0;
@@ -64,7 +92,7 @@ __device__ __forceinline__ long long dct_addr(const DctAddr& A, long long base, 
 
 // Twiddles live in LDS up to n = 256; from n = 512 on they are read from global memory (L1/L2 resident, 8-16 KB) so that
 // two fp64 tiles (73.8 KB each at n = 512) fit in one CU's 160 KB and the load/FFT/store phases of two blocks overlap.
-template <int LOG2N> constexpr bool dct_tw_in_lds() { return LOG2N <= 8; }
+template <int LOG2N> constexpr bool dct_tw_in_lds() { return LOG2N <= SHM_DCT_TW_LDS_MAX; }
 template <int LOG2N> constexpr size_t dct_lds_bytes(size_t cplx_size) {
     return ((size_t)(1 << LOG2N) * (dct_lc<LOG2N>() + 1) + (dct_tw_in_lds<LOG2N>() ? (size_t)(1 << LOG2N) : 0)) * cplx_size + 64;
 }
@@ -79,7 +107,7 @@ __device__ __forceinline__ void dct_fft_pass(Cplx<TP>* buf, const Cplx<TP>* tw, 
 #pragma unroll
     for (int a = 0; a < IPT; a++) {
         const int w = tid + a * kBlock;
-        if (items % kBlock == 0 || w < items) pass_load<TP, LOG2N, R, NS, SIGN, LC, true>(buf, tw, w, v[a]);
+        if (items % kBlock == 0 || w < items) pass_load<TP, LOG2N, R, NS, SIGN, LC, SHM_DCT_POW_ALWAYS || !dct_tw_in_lds<LOG2N>()>(buf, tw, w, v[a]);
     }
     __syncthreads();
 #pragma unroll
@@ -99,8 +127,16 @@ __device__ __forceinline__ void dct_fft(Cplx<TP>* buf, const Cplx<TP>* tw, int t
 }
 
 // tw_g[t] = e^{-2 pi i t/n}, t<n ; om_g[k] = e^{-i pi k/(2n)}, k<n ; lam_g[k] = (2-2cos(pi k/n))/h^2
+// Occupancy the register allocator is held to for the long transforms: two waves per SIMD (= two tiles per CU) when the LDS footprint
+// allows them.  Without it the n = 512 fp64 kernels land just above 256 registers, i.e. one tile per CU; asking for more than two
+// (fp32 tiles are half the size) makes the allocator spill.
+template <int LOG2N, int CPLX_BYTES> constexpr int dct_waves_per_simd() {
+    constexpr int by_lds = (int)((size_t)(160 * 1024) / dct_lds_bytes<LOG2N>(CPLX_BYTES));
+    constexpr int want = CPLX_BYTES == 8 ? SHM_DCT_WAVES_F32 : 2;
+    return by_lds >= want ? want : (by_lds >= 1 ? by_lds : 1);
+}
 template <typename TP, typename TIn, typename TOut, int MODE, bool DOT, int LOG2N, bool XPASS, bool SEG>
-__global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TIn* __restrict__ in, TOut* __restrict__ out,
+__global__ __launch_bounds__(kBlock, (LOG2N >= SHM_DCT_WAVES_HINT ? dct_waves_per_simd<LOG2N, (int)sizeof(Cplx<TP>)>() : 1)) void dct_lines_kernel(DctParams P, const TIn* __restrict__ in, TOut* __restrict__ out,
                                                            const Cplx<TP>* __restrict__ tw_g, const Cplx<TP>* __restrict__ om_g,
                                                            const TP* __restrict__ lam_g, const TOut* __restrict__ dot_with,
                                                            double* __restrict__ partials, const int* __restrict__ tile_list /* nullptr: all tiles */,
@@ -117,6 +153,21 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
     const int tid = threadIdx.x;
     if (dct_tw_in_lds<LOG2N>())
         for (int a = tid; a < n; a += kBlock) tw_l[a] = tw_g[a];
+    // spectral-step constants of this thread (tile independent), fetched up front so that their latency hides behind the tile's loads
+    constexpr int kSpStep = kBlock / kFftLC;                          // k distance between a thread's consecutive pairs
+    constexpr int kSpIters = (n / 2 + 1 + kSpStep - 1) / kSpStep;
+    Cplx<TP> sp_om[(MODE == DCT_FWD || !SHM_DCT_HOIST) ? 1 : kSpIters];
+    TP sp_lam[(MODE == DCT_FUSED && SHM_DCT_HOIST) ? kSpIters : 1];
+    TP sp_lam_n = (TP)0;
+    if (MODE != DCT_FWD && SHM_DCT_HOIST) {
+#pragma unroll
+        for (int i = 0; i < kSpIters; i++) {
+            const int k = min((tid >> ilog2(kFftLC)) + i * kSpStep, n / 2);
+            sp_om[i] = om_g[k];
+            if (MODE == DCT_FUSED) sp_lam[i] = lam_g[k];
+        }
+    }
+    if (MODE == DCT_FUSED) sp_lam_n = (TP)2 * lam_g[n / 2];   // lam_n = 4/h^2 = 2 lam_{n/2}
     // concurrently running workgroups take neighbouring tiles (adjacent x chunks of the same rows share an XCD's L2)
     for (int lb = (int)xcd_remap(blockIdx.x, gridDim.x); lb < P.ntiles; lb += (int)gridDim.x) {
     __syncthreads();                                       // the previous tile's LDS reads are done (and the twiddle table is in place)
@@ -198,6 +249,7 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
         continue;
     }
 
+#if SHM_DCT_SPECTRAL_ORIG
     // ---------------- spectral step on (k, n-k) pairs, k = 0..n/2 ----------------
     if (!SHM_DCT_DBG(P, 2)) {
         const int kx0 = (t % P.tiles_a) * L, ky = P.ky0 + t / P.tiles_a;
@@ -240,6 +292,61 @@ __global__ __launch_bounds__(kBlock) void dct_lines_kernel(DctParams P, const TI
         __syncthreads();
     }
 
+#else
+    // ---------------- spectral step on (k, n-k) pairs, k = 0..n/2 ----------------
+    // A thread's pairs sit at k = tid / LC + i * (256 / LC): its om_k and lam_k were fetched before the tile's loads (sp_om, sp_lam);
+    // the partners follow from om_{n-k} = -i conj(om_k) and lam_{n-k} = lam_n - lam_k (n - k >= n/2: no cancellation).
+    if (!SHM_DCT_DBG(P, 2)) {
+        const int kx0 = (t % P.tiles_a) * L, ky = P.ky0 + t / P.tiles_a;
+        const int c = tid & (kFftLC - 1);
+        const int kxa = kx0 + 2 * c, kxb = kxa + 1;
+        TP lxy_a = (TP)0, lxy_b = (TP)0, sa = (TP)0, sb = (TP)0;
+        if (MODE == DCT_FUSED) {
+            // D(kx,ky,kz) = sx sy sz / (lam_x + lam_y + lam_z), s_0 = 1/n, s_k = 2/n ; zero mode -> 0
+            const TP lky = lam_g[ky];
+            lxy_a = lam_g[kxa] + lky;
+            lxy_b = lam_g[kxb] + lky;
+            const TP sy = ky == 0 ? (TP)0.5 : (TP)1;
+            sa = (kxa == 0 ? (TP)0.5 : (TP)1) * sy * (TP)P.inv_n3_8;
+            sb = sy * (TP)P.inv_n3_8;  // kxb >= 1
+        }
+#pragma unroll 1   // fully unrolled, the table reads cost > 100 registers at n = 512 and with them half the occupancy
+        for (int i = 0; i < kSpIters; i++) {
+            const int k = (tid >> ilog2(kFftLC)) + i * kSpStep;
+            if (k > n / 2) break;
+            const int nk = (n - k) & (n - 1);
+            const Cplx<TP> omk = SHM_DCT_HOIST ? sp_om[SHM_DCT_HOIST ? i : 0] : om_g[k];
+            const Cplx<TP> omn = k == 0 ? omk : Cplx<TP>{-omk.y, -omk.x};
+            TP xa_k, xb_k, xa_n, xb_n;
+            if (MODE == DCT_FUSED) {
+                const Cplx<TP> zk = buf[k * kFftRow + c], znk = buf[nk * kFftRow + c];
+                dct_fwd_post<TP>(zk, znk, omk, xa_k, xb_k);
+                dct_fwd_post<TP>(znk, zk, omn, xa_n, xb_n);
+                const TP lk = SHM_DCT_HOIST ? sp_lam[SHM_DCT_HOIST ? i : 0] : lam_g[k], ln = k == 0 ? lk : sp_lam_n - lk;
+                const TP szk = k == 0 ? (TP)0.5 : (TP)1;  // nk == 0 only together with k == 0
+                const TP da_k = lxy_a + lk, db_k = lxy_b + lk, da_n = lxy_a + ln, db_n = lxy_b + ln;
+                // 1/d by the hardware seed and two Newton steps (1-2 ulp; the IEEE division sequence is ~10x the instructions)
+                auto recip = [](TP d) {
+                    TP r = t_rcp<TP>(d);
+                    r = fma(fma(-d, r, (TP)1), r, r);
+                    r = fma(fma(-d, r, (TP)1), r, r);
+                    return r;
+                };
+                xa_k = da_k > (TP)0 ? xa_k * (sa * szk) * recip(da_k) : (TP)0;
+                xb_k = xb_k * (sb * szk) * recip(db_k);
+                xa_n = da_n > (TP)0 ? xa_n * (sa * szk) * recip(da_n) : (TP)0;
+                xb_n = xb_n * (sb * szk) * recip(db_n);
+            } else {
+                const Cplx<TP> rk = buf[k * kFftRow + c], rn = buf[nk * kFftRow + c];
+                xa_k = rk.x; xb_k = rk.y; xa_n = rn.x; xb_n = rn.y;
+            }
+            buf[k * kFftRow + c] = dct_inv_pre<TP>(k, xa_k, xa_n, xb_k, xb_n, omk);
+            if (nk != k) buf[nk * kFftRow + c] = dct_inv_pre<TP>(nk, xa_n, xa_k, xb_n, xb_k, omn);
+        }
+        __syncthreads();
+    }
+
+#endif
     if (!SHM_DCT_DBG(P, 1)) dct_fft<TP, LOG2N, +1>(buf, tw, tid);
 
     // ---------------- store: x[j] = v[makhoul_slot(j)] ----------------

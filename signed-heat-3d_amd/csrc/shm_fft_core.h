@@ -67,7 +67,14 @@ template <> struct FftPlan<4> { static constexpr int npass = 1; static constexpr
 template <> struct FftPlan<5> { static constexpr int npass = 2; static constexpr int R0 = 8, R1 = 4, R2 = 1; };
 template <> struct FftPlan<6> { static constexpr int npass = 2; static constexpr int R0 = 8, R1 = 8, R2 = 1; };
 template <> struct FftPlan<7> { static constexpr int npass = 2; static constexpr int R0 = 16, R1 = 8, R2 = 1; };
+#ifndef SHM_FFT_PLAN8_BALANCED
+#define SHM_FFT_PLAN8_BALANCED 1   // n = 256 as 8*8*4 (all four waves carry butterflies) instead of 16*16 (two of four)
+#endif
+#if SHM_FFT_PLAN8_BALANCED
 template <> struct FftPlan<8> { static constexpr int npass = 3; static constexpr int R0 = 8, R1 = 8, R2 = 4; };
+#else
+template <> struct FftPlan<8> { static constexpr int npass = 2; static constexpr int R0 = 16, R1 = 16, R2 = 1; };
+#endif
 template <> struct FftPlan<9> { static constexpr int npass = 3; static constexpr int R0 = 8, R1 = 8, R2 = 8; };
 template <> struct FftPlan<10> { static constexpr int npass = 3; static constexpr int R0 = 16, R1 = 8, R2 = 8; };
 

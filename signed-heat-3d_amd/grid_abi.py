@@ -60,7 +60,8 @@ class ShmStats(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libshm_grid.so")
+    """In-tree library; SHM_GRID_LIB selects another build of it (tools/dct_variants.sh A/B runs)."""
+    return os.environ.get("SHM_GRID_LIB") or os.path.join(_HERE, "lib", "libshm_grid.so")
 
 
 _LIB = None
