@@ -39,6 +39,9 @@
 #endif                         // (always 0 in product builds).  Opaque to the compiler, they stop it from hoisting one phase's loads across the
                                // previous phase, which costs ~60 registers and with them a tile of occupancy at n = 512 (fp32: 1.82 vs 2.18 ms
                                // per dual iteration at 512^3; fp64 the same without the occupancy hint below)
+#ifndef SHM_DCT_WAVES_256
+#define SHM_DCT_WAVES_256 0     // > 0: occupancy asked of the register allocator for n <= 256 as well
+#endif
 #ifndef SHM_DCT_LC8
 #define SHM_DCT_LC8 4          // complex lines per tile at n = 256 (4: 0.224 ms per dual iteration, 8: 0.234)
 #endif
@@ -132,11 +135,11 @@ __device__ __forceinline__ void dct_fft(Cplx<TP>* buf, const Cplx<TP>* tw, int t
 // (fp32 tiles are half the size) makes the allocator spill.
 template <int LOG2N, int CPLX_BYTES> constexpr int dct_waves_per_simd() {
     constexpr int by_lds = (int)((size_t)(160 * 1024) / dct_lds_bytes<LOG2N>(CPLX_BYTES));
-    constexpr int want = CPLX_BYTES == 8 ? SHM_DCT_WAVES_F32 : 2;
+    constexpr int want = LOG2N <= 8 ? (SHM_DCT_WAVES_256 > 0 ? SHM_DCT_WAVES_256 : 1) : (CPLX_BYTES == 8 ? SHM_DCT_WAVES_F32 : 2);
     return by_lds >= want ? want : (by_lds >= 1 ? by_lds : 1);
 }
 template <typename TP, typename TIn, typename TOut, int MODE, bool DOT, int LOG2N, bool XPASS, bool SEG>
-__global__ __launch_bounds__(kBlock, (LOG2N >= SHM_DCT_WAVES_HINT ? dct_waves_per_simd<LOG2N, (int)sizeof(Cplx<TP>)>() : 1)) void dct_lines_kernel(DctParams P, const TIn* __restrict__ in, TOut* __restrict__ out,
+__global__ __launch_bounds__(kBlock, ((LOG2N >= SHM_DCT_WAVES_HINT || SHM_DCT_WAVES_256 > 0) ? dct_waves_per_simd<LOG2N, (int)sizeof(Cplx<TP>)>() : 1)) void dct_lines_kernel(DctParams P, const TIn* __restrict__ in, TOut* __restrict__ out,
                                                            const Cplx<TP>* __restrict__ tw_g, const Cplx<TP>* __restrict__ om_g,
                                                            const TP* __restrict__ lam_g, const TOut* __restrict__ dot_with,
                                                            double* __restrict__ partials, const int* __restrict__ tile_list /* nullptr: all tiles */,
