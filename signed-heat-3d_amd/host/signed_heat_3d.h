@@ -36,8 +36,9 @@ double meanEdgeLength(const VertexPositionGeometry& geometry);                  
 void setFaceVectorAreas(const VertexPositionGeometry& geometry, std::vector<double>& areas, std::vector<Vector3>& normals);  // :62-89
 Vector3 barycenter(const VertexPositionGeometry& geometry, size_t f);            // signed_heat_grid_solver.cpp:498-503
 
-// Headless replacement of geometry-central's tufted-triangulation dual areas / edge length:
-// k-nearest-neighbour disk estimate.  Parity with geometry-central is unpinned; both are solver INPUTS.
-void estimatePointAreas(PointPositionNormalGeometry& pointGeom, int k = 8);
+// Headless replacement of geometry-central's tufted-triangulation dual areas / edge length: k nearest
+// neighbours, tangent-plane local Delaunay triangulations, union of the local triangles (geometry-central's construction without
+// the intrinsic flips).  Parity with geometry-central is unpinned; both quantities are solver INPUTS.
+void estimatePointAreas(PointPositionNormalGeometry& pointGeom, int k = 30);
 
 }  // namespace shm_host

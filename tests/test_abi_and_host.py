@@ -2,6 +2,7 @@
 fails loudly without a device, and the C++ host mirror's pre-processing reproduces the oracle's golden values."""
 import ctypes
 import os
+import sys
 import re
 
 import numpy as np
@@ -100,11 +101,31 @@ def test_host_mirror_point_cloud(shm):
     r = h.preprocess(hCoef=0.0)
     assert np.abs(r["pos"] - d["pos"]).max() < 1e-14 and np.abs(r["wnormal"] - d["wnormal"]).max() < 1e-14
     assert abs(r["lam"] - float(d["lam"])) < 1e-12 and np.abs(r["bbox_min"] - d["bbox_min"]).max() < 1e-14
-    # headless estimator: plausibility only (mesh dual areas sum 9.4887, h 0.095)
-    h2 = HostSolver(os.path.join(ROOT, "data", "bunny.pc"))
-    r2 = h2.preprocess()
-    assert 0.5 * 9.4887 < r2["area"].sum() < 1.5 * 9.4887
-    assert 0.6 * 0.095 < r2["h"] < 1.4 * 0.095
+
+
+def test_point_cloud_estimator_against_the_matching_meshes(shm):
+    """Headless estimator of the per-point dual areas and h (tangent-plane local Delaunay triangulations).
+    bunny.pc and rocker.pc are exactly the (stripped) vertices of bunny_small.obj / rocker.obj, so the meshes' barycentric dual areas
+    and mean edge lengths are the anchor: total area, h and the per-point correlation."""
+    from signed_heat_3d_amd.host_abi import HostSolver
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import shm_oracle as o
+    from scipy.spatial import cKDTree
+    for pc, obj, tol_sum, tol_h, min_corr in (("bunny.pc", "bunny_small.obj", 0.02, 0.05, 0.75), ("rocker.pc", "rocker.obj", 0.03, 0.01, 0.70)):
+        V, F = o.read_obj(os.path.join(ROOT, "data", obj))
+        dual = np.zeros(len(V))
+        for f in F:
+            p = V[list(f)]
+            a = 0.5 * np.linalg.norm(np.cross(p[1] - p[0], p[2] - p[0]))
+            dual[list(f)] += a / 3.0
+        r = HostSolver(os.path.join(ROOT, "data", pc)).preprocess()
+        dist, idx = cKDTree(V).query(r["pos"])
+        assert dist.max() < 1e-4
+        ref = dual[idx]
+        assert abs(r["area"].sum() - dual.sum()) < tol_sum * dual.sum(), (pc, r["area"].sum(), dual.sum())
+        assert abs(r["h"] - o.mean_edge_length(V, F)) < tol_h * o.mean_edge_length(V, F), (pc, r["h"])
+        assert np.corrcoef(r["area"], ref)[0, 1] > min_corr
+        assert (r["area"] > 0).all()
 
 
 def test_cli_reports_missing_device_or_runs():
