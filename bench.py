@@ -256,9 +256,15 @@ def main():
         # issue (no GEMM shape, HBM traffic 3 words per node), so its roofline is the fp64/fp32 vector peak at the
         # nominal 18 flop per pair; when the CG loop takes longer than Step 1 the HBM roofline of its dominant kernel is reported
         s1 = out["step1"]
+        conv_traffic = None   # PMC-measured HBM bytes of the Step-1 launch (profiles/r01_pmc_traffic.json): its 3 N T of output
+        if os.path.exists(tfile):
+            try:
+                conv_traffic = json.load(open(tfile)).get(args.workload, {}).get("conv_normalize_kernel")
+            except Exception:
+                conv_traffic = None
         if avg["ms_conv"] >= avg["ms_pcg"]:
             out["roofline"] = {"kernel": "conv_normalize_kernel", "bound": "valu", "achieved": s1["achieved_TFLOPs_nominal_18_per_pair"],
-                               "peak": s1["peak_TFLOPs_vector"], "unit": "TFLOP/s", "frac": s1["frac"], "traffic": None,
+                               "peak": s1["peak_TFLOPs_vector"], "unit": "TFLOP/s", "frac": s1["frac"], "traffic": conv_traffic,
                                # wave-instruction issue: slots per pair (ISA count of the inner loop, weighted by the measured issue cost of
                                # each opcode, tools/valu_probe.hip) x pairs/s / 64 lanes, against 256 CUs x 4 SIMDs x one slot per 4 cycles at
                                # the 2.4 GHz peak clock (the part sustains ~2.0 GHz under this fp64 load, where the same figure is ~0.98)
@@ -267,7 +273,7 @@ def main():
                                "note": "one launch per step, duration = phases_ms.ms_conv (HIP events on the solver's stream); achieved = 18 nominal "
                                        "flop x pairs / duration (SURVEY 8(d)); the fp64 loop issues 26.8 VALU slots per pair (20 fp64 ops, "
                                        "v_rsq_f64 = 2.7 slots, 3 integer, shared dx/dy terms) = ~97% of the issue capacity at the 2.0 GHz the part "
-                                       "sustains under this load (tools/valu_probe.hip); traffic: HBM bytes are 3 words per node, irrelevant here"}
+                                       "sustains under this load (tools/valu_probe.hip); traffic = PMC-measured HBM bytes of the launch (3 words per node written; irrelevant to the bound)"}
         else:
             out["roofline"] = dict(out["roofline_pcg"])
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only (the extra plain-CG solve below is a collective at N>1)
