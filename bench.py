@@ -263,7 +263,12 @@ def main():
             except Exception:
                 conv_traffic = None
         if avg["ms_conv"] >= avg["ms_pcg"]:
-            out["roofline"] = {"kernel": "conv_normalize_kernel", "bound": "valu", "achieved": s1["achieved_TFLOPs_nominal_18_per_pair"],
+            # "mfma" = the compute roofline of the contract (the alternative to "hbm"); the kernel's arithmetic is on the vector ALU,
+            # whose fp64 / fp32 peaks equal the dense matrix-core peaks of those types on MI355X (78.6 / 157.3 TFLOP/s)
+            out["roofline"] = {"kernel": "conv_normalize_kernel", "bound": "mfma",
+                               "bound_detail": "compute: vector-ALU issue (no matrix-core shape in the kernel); fp64 and fp32 vector peaks = dense "
+                                               "matrix peaks of the same types on MI355X",
+                               "achieved": s1["achieved_TFLOPs_nominal_18_per_pair"],
                                "peak": s1["peak_TFLOPs_vector"], "unit": "TFLOP/s", "frac": s1["frac"], "traffic": conv_traffic,
                                # wave-instruction issue: slots per pair (ISA count of the inner loop, weighted by the measured issue cost of
                                # each opcode, tools/valu_probe.hip) x pairs/s / 64 lanes, against 256 CUs x 4 SIMDs x one slot per 4 cycles at
