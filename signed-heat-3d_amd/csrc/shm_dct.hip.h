@@ -127,6 +127,7 @@ __device__ __forceinline__ void dct_fft(Cplx<TP>* buf, const Cplx<TP>* tw, int t
     dct_fft_pass<TP, LOG2N, P::R0, 1, SIGN>(buf, tw, tid);
     if constexpr (P::npass > 1) dct_fft_pass<TP, LOG2N, P::R1, P::R0, SIGN>(buf, tw, tid);
     if constexpr (P::npass > 2) dct_fft_pass<TP, LOG2N, P::R2, P::R0 * P::R1, SIGN>(buf, tw, tid);
+    if constexpr (P::npass > 3) dct_fft_pass<TP, LOG2N, P::R3, P::R0 * P::R1 * P::R2, SIGN>(buf, tw, tid);
 }
 
 // tw_g[t] = e^{-2 pi i t/n}, t<n ; om_g[k] = e^{-i pi k/(2n)}, k<n ; lam_g[k] = (2-2cos(pi k/n))/h^2

@@ -63,20 +63,24 @@ template <typename TP, int SIGN> struct RegDft<TP, 1, SIGN> {
 
 // Radix plan per transform length: R[p] for p = 0..npass-1.
 template <int LOG2N> struct FftPlan;
-template <> struct FftPlan<4> { static constexpr int npass = 1; static constexpr int R0 = 16, R1 = 1, R2 = 1; };
-template <> struct FftPlan<5> { static constexpr int npass = 2; static constexpr int R0 = 8, R1 = 4, R2 = 1; };
-template <> struct FftPlan<6> { static constexpr int npass = 2; static constexpr int R0 = 8, R1 = 8, R2 = 1; };
-template <> struct FftPlan<7> { static constexpr int npass = 2; static constexpr int R0 = 16, R1 = 8, R2 = 1; };
+template <> struct FftPlan<4> { static constexpr int npass = 1; static constexpr int R0 = 16, R1 = 1, R2 = 1, R3 = 1; };
+template <> struct FftPlan<5> { static constexpr int npass = 2; static constexpr int R0 = 8, R1 = 4, R2 = 1, R3 = 1; };
+template <> struct FftPlan<6> { static constexpr int npass = 2; static constexpr int R0 = 8, R1 = 8, R2 = 1, R3 = 1; };
+template <> struct FftPlan<7> { static constexpr int npass = 2; static constexpr int R0 = 16, R1 = 8, R2 = 1, R3 = 1; };
 #ifndef SHM_FFT_PLAN8_BALANCED
 #define SHM_FFT_PLAN8_BALANCED 1   // n = 256 as 8*8*4 (all four waves carry butterflies) instead of 16*16 (two of four)
 #endif
-#if SHM_FFT_PLAN8_BALANCED
-template <> struct FftPlan<8> { static constexpr int npass = 3; static constexpr int R0 = 8, R1 = 8, R2 = 4; };
+#if SHM_FFT_PLAN8_BALANCED == 2
+template <> struct FftPlan<8> { static constexpr int npass = 4; static constexpr int R0 = 4, R1 = 4, R2 = 4, R3 = 4; };
+#elif SHM_FFT_PLAN8_BALANCED == 3
+template <> struct FftPlan<8> { static constexpr int npass = 3; static constexpr int R0 = 4, R1 = 8, R2 = 8, R3 = 1; };
+#elif SHM_FFT_PLAN8_BALANCED
+template <> struct FftPlan<8> { static constexpr int npass = 3; static constexpr int R0 = 8, R1 = 8, R2 = 4, R3 = 1; };
 #else
-template <> struct FftPlan<8> { static constexpr int npass = 2; static constexpr int R0 = 16, R1 = 16, R2 = 1; };
+template <> struct FftPlan<8> { static constexpr int npass = 2; static constexpr int R0 = 16, R1 = 16, R2 = 1, R3 = 1; };
 #endif
-template <> struct FftPlan<9> { static constexpr int npass = 3; static constexpr int R0 = 8, R1 = 8, R2 = 8; };
-template <> struct FftPlan<10> { static constexpr int npass = 3; static constexpr int R0 = 16, R1 = 8, R2 = 8; };
+template <> struct FftPlan<9> { static constexpr int npass = 3; static constexpr int R0 = 8, R1 = 8, R2 = 8, R3 = 1; };
+template <> struct FftPlan<10> { static constexpr int npass = 3; static constexpr int R0 = 16, R1 = 8, R2 = 8, R3 = 1; };
 
 // Work items of one pass: (n/R) butterflies x LC lines; item w -> line c = w % LC, butterfly jj = w / LC.
 template <int LOG2N, int R, int LC> struct PassGeom {

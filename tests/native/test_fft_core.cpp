@@ -38,6 +38,7 @@ template <int LOG2N, int SIGN> static void fft_tile(std::vector<C>& buf, const s
     run_pass<LOG2N, P::R0, 1, SIGN>(buf, tw);
     if (P::npass > 1) run_pass<LOG2N, P::R1, P::R0, SIGN>(buf, tw);
     if (P::npass > 2) run_pass<LOG2N, P::R2, P::R0 * P::R1, SIGN>(buf, tw);
+    if (P::npass > 3) run_pass<LOG2N, P::R3, P::R0 * P::R1 * P::R2, SIGN>(buf, tw);
 }
 
 template <int LOG2N> static double test_n() {
