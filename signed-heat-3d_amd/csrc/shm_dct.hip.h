@@ -42,6 +42,9 @@
 #ifndef SHM_DCT_WAVES_256
 #define SHM_DCT_WAVES_256 0     // > 0: occupancy asked of the register allocator for n <= 256 as well
 #endif
+#ifndef SHM_DCT_WAVE_FFT
+#define SHM_DCT_WAVE_FFT 0x100  // bit log2(n): FFT passes of that length are wave-local (a wave owns whole lines: no workgroup barriers).
+#endif                         // Measured: n = 256 4 % faster per dual iteration (dense sweeps +8 %), n = 512 14 % slower -> 256 only
 #ifndef SHM_DCT_LC8
 #define SHM_DCT_LC8 4          // complex lines per tile at n = 256 (4: 0.224 ms per dual iteration, 8: 0.234)
 #endif
@@ -128,6 +131,55 @@ __device__ __forceinline__ void dct_fft(Cplx<TP>* buf, const Cplx<TP>* tw, int t
     if constexpr (P::npass > 1) dct_fft_pass<TP, LOG2N, P::R1, P::R0, SIGN>(buf, tw, tid);
     if constexpr (P::npass > 2) dct_fft_pass<TP, LOG2N, P::R2, P::R0 * P::R1, SIGN>(buf, tw, tid);
     if constexpr (P::npass > 3) dct_fft_pass<TP, LOG2N, P::R3, P::R0 * P::R1 * P::R2, SIGN>(buf, tw, tid);
+}
+
+// ---- wave-local variant (n >= 256).  Every wave owns LC/4 complete lines of the tile: the butterflies of a line read and write only
+// that line, the LDS executes one wave's instructions in order, and all reads of a pass are issued before its writes -- so a pass
+// needs no workgroup barrier at all (only a compiler fence), the four waves drift apart and hide each other's LDS latency, and a
+// tile is left with the two barriers around its global load / store phases.  Radix-4 passes keep all 64 lanes busy (n/4 >= 64).
+template <int LOG2N> struct FftPlanWave;
+template <> struct FftPlanWave<8> { static constexpr int npass = 4; static constexpr int R0 = 4, R1 = 4, R2 = 4, R3 = 4; };
+#ifndef SHM_DCT_WAVE_PLAN9
+#define SHM_DCT_WAVE_PLAN9 0
+#endif
+#if SHM_DCT_WAVE_PLAN9
+template <> struct FftPlanWave<9> { static constexpr int npass = 3; static constexpr int R0 = 8, R1 = 8, R2 = 8, R3 = 1; };
+#else
+template <> struct FftPlanWave<9> { static constexpr int npass = 4; static constexpr int R0 = 8, R1 = 4, R2 = 4, R3 = 4; };
+#endif
+template <> struct FftPlanWave<10> { static constexpr int npass = 4; static constexpr int R0 = 16, R1 = 4, R2 = 4, R3 = 4; };
+template <int LOG2N> constexpr bool dct_wave_fft() { return ((SHM_DCT_WAVE_FFT >> LOG2N) & 1) && LOG2N >= 8 && LOG2N <= 10; }
+
+template <typename TP, int LOG2N, int R, int NS, int SIGN>
+__device__ __forceinline__ void dct_fft_pass_wave(Cplx<TP>* buf, const Cplx<TP>* tw, int tid) {
+    constexpr int LC = dct_lc<LOG2N>(), n = 1 << LOG2N;
+    constexpr int B = n / R;                      // butterflies per line
+    constexpr int LW = LC / (kBlock / kWave);     // lines per wave
+    constexpr int IPL = (B + kWave - 1) / kWave;  // butterflies per lane and line
+    static_assert(LW >= 1 && B % kWave == 0, "wave-local FFT: whole lines per wave, full waves of butterflies");
+    const int wave = tid >> 6, lane = tid & 63;
+    Cplx<TP> v[LW * IPL][R];
+#pragma unroll
+    for (int a = 0; a < LW * IPL; a++) {
+        const int c = wave + (kBlock / kWave) * (a / IPL), jj = lane + kWave * (a % IPL);
+        pass_load<TP, LOG2N, R, NS, SIGN, LC, SHM_DCT_POW_ALWAYS || !dct_tw_in_lds<LOG2N>()>(buf, tw, jj * LC + c, v[a]);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int a = 0; a < LW * IPL; a++) {
+        const int c = wave + (kBlock / kWave) * (a / IPL), jj = lane + kWave * (a % IPL);
+        pass_store<TP, LOG2N, R, NS, LC>(buf, jj * LC + c, v[a]);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <typename TP, int LOG2N, int SIGN>
+__device__ __forceinline__ void dct_fft_wave(Cplx<TP>* buf, const Cplx<TP>* tw, int tid) {
+    typedef FftPlanWave<LOG2N> P;
+    dct_fft_pass_wave<TP, LOG2N, P::R0, 1, SIGN>(buf, tw, tid);
+    dct_fft_pass_wave<TP, LOG2N, P::R1, P::R0, SIGN>(buf, tw, tid);
+    dct_fft_pass_wave<TP, LOG2N, P::R2, P::R0 * P::R1, SIGN>(buf, tw, tid);
+    if constexpr (P::npass > 3) dct_fft_pass_wave<TP, LOG2N, P::R3, P::R0 * P::R1 * P::R2, SIGN>(buf, tw, tid);
 }
 
 // tw_g[t] = e^{-2 pi i t/n}, t<n ; om_g[k] = e^{-i pi k/(2n)}, k<n ; lam_g[k] = (2-2cos(pi k/n))/h^2
@@ -233,7 +285,12 @@ __global__ __launch_bounds__(kBlock, ((LOG2N >= SHM_DCT_WAVES_HINT || SHM_DCT_WA
     }
     __syncthreads();
 
-    if ((MODE == DCT_FWD || MODE == DCT_FUSED) && !SHM_DCT_DBG(P, 1)) dct_fft<TP, LOG2N, -1>(buf, tw, tid);
+    constexpr bool kWaveFft = dct_wave_fft<LOG2N>();
+    if ((MODE == DCT_FWD || MODE == DCT_FUSED) && !SHM_DCT_DBG(P, 1)) {
+        if constexpr (kWaveFft) dct_fft_wave<TP, LOG2N, -1>(buf, tw, tid);
+        else dct_fft<TP, LOG2N, -1>(buf, tw, tid);
+    }
+    if (kWaveFft && MODE == DCT_FWD) __syncthreads();   // the output phase below reads lines other waves transformed
 
     if (MODE == DCT_FWD) {
         // ---------------- X[k] = Re(om_k V[k]) straight to global ----------------
@@ -302,7 +359,11 @@ __global__ __launch_bounds__(kBlock, ((LOG2N >= SHM_DCT_WAVES_HINT || SHM_DCT_WA
     // the partners follow from om_{n-k} = -i conj(om_k) and lam_{n-k} = lam_n - lam_k (n - k >= n/2: no cancellation).
     if (!SHM_DCT_DBG(P, 2)) {
         const int kx0 = (t % P.tiles_a) * L, ky = P.ky0 + t / P.tiles_a;
-        const int c = tid & (kFftLC - 1);
+        // wave-local FFTs: a wave post-processes its own lines (kSpLines of them, pairs k = lane + 64 i), no barrier on either side
+        constexpr int kSpLines = kWaveFft ? kFftLC / (kBlock / kWave) : 1;
+#pragma unroll
+        for (int cl = 0; cl < kSpLines; cl++) {
+        const int c = kWaveFft ? (tid >> 6) + (kBlock / kWave) * cl : (tid & (kFftLC - 1));
         const int kxa = kx0 + 2 * c, kxb = kxa + 1;
         TP lxy_a = (TP)0, lxy_b = (TP)0, sa = (TP)0, sb = (TP)0;
         if (MODE == DCT_FUSED) {
@@ -315,8 +376,8 @@ __global__ __launch_bounds__(kBlock, ((LOG2N >= SHM_DCT_WAVES_HINT || SHM_DCT_WA
             sb = sy * (TP)P.inv_n3_8;  // kxb >= 1
         }
 #pragma unroll 1   // fully unrolled, the table reads cost > 100 registers at n = 512 and with them half the occupancy
-        for (int i = 0; i < kSpIters; i++) {
-            const int k = (tid >> ilog2(kFftLC)) + i * kSpStep;
+        for (int i = 0; i < (kWaveFft ? (n / 2 + kWave) / kWave : kSpIters); i++) {
+            const int k = kWaveFft ? (tid & 63) + i * kWave : (tid >> ilog2(kFftLC)) + i * kSpStep;
             if (k > n / 2) break;
             const int nk = (n - k) & (n - 1);
             const Cplx<TP> omk = SHM_DCT_HOIST ? sp_om[SHM_DCT_HOIST ? i : 0] : om_g[k];
@@ -347,11 +408,16 @@ __global__ __launch_bounds__(kBlock, ((LOG2N >= SHM_DCT_WAVES_HINT || SHM_DCT_WA
             buf[k * kFftRow + c] = dct_inv_pre<TP>(k, xa_k, xa_n, xb_k, xb_n, omk);
             if (nk != k) buf[nk * kFftRow + c] = dct_inv_pre<TP>(nk, xa_n, xa_k, xb_n, xb_k, omn);
         }
-        __syncthreads();
+        }  // lines of this wave
+        if (!kWaveFft) __syncthreads();
     }
 
 #endif
-    if (!SHM_DCT_DBG(P, 1)) dct_fft<TP, LOG2N, +1>(buf, tw, tid);
+    if (!SHM_DCT_DBG(P, 1)) {
+        if constexpr (kWaveFft) dct_fft_wave<TP, LOG2N, +1>(buf, tw, tid);
+        else dct_fft<TP, LOG2N, +1>(buf, tw, tid);
+    }
+    if (kWaveFft) __syncthreads();   // the store phase reads lines other waves transformed
 
     // ---------------- store: x[j] = v[makhoul_slot(j)] ----------------
     double acc = 0.;
