@@ -45,6 +45,9 @@
 #ifndef SHM_DCT_WAVE_FFT
 #define SHM_DCT_WAVE_FFT 0x100  // bit log2(n): FFT passes of that length are wave-local (a wave owns whole lines: no workgroup barriers).
 #endif                         // Measured: n = 256 4 % faster per dual iteration (dense sweeps +8 %), n = 512 14 % slower -> 256 only
+#ifndef SHM_DCT_LC9
+#define SHM_DCT_LC9 8          // complex lines per tile at n = 512
+#endif
 #ifndef SHM_DCT_LC8
 #define SHM_DCT_LC8 4          // complex lines per tile at n = 256 (4: 0.224 ms per dual iteration, 8: 0.234)
 #endif
@@ -67,8 +70,8 @@ enum DctMode : int { DCT_FWD = 0, DCT_INV = 1, DCT_FUSED = 2 };
 // complex lines per tile: 8 (16 real lines = one 128-byte row per element row); 4 at n = 1024, where an fp64 tile of 8 would take
 // 147 KB of LDS (one workgroup per CU).  (Measured at n = 512: 4 instead of 8 lines doubles the residency but halves the access
 // granularity to 64 bytes -- no net change, so 512 keeps the full 128-byte rows.)
-template <int LOG2N> constexpr int dct_lc() { return LOG2N >= 10 ? 4 : (LOG2N == 8 ? SHM_DCT_LC8 : 8); }
-constexpr int dct_lines_for(int log2n) { return log2n >= 10 ? 8 : (log2n == 8 ? 2 * SHM_DCT_LC8 : 16); }
+template <int LOG2N> constexpr int dct_lc() { return LOG2N >= 10 ? 4 : (LOG2N == 8 ? SHM_DCT_LC8 : (LOG2N == 9 ? SHM_DCT_LC9 : 8)); }
+constexpr int dct_lines_for(int log2n) { return log2n >= 10 ? 8 : (log2n == 8 ? 2 * SHM_DCT_LC8 : (log2n == 9 ? 2 * SHM_DCT_LC9 : 16)); }
 
 // Address of element k of line l of tile t:
 //   off + (t % tiles_a) a_stride + (t / tiles_a) b_stride + l line_stride + (k >> seg_shift) seg_stride + (k & seg_mask) elem_stride
