@@ -476,8 +476,8 @@ struct Solver final : SolverBase {
         for (Slab<T>& sl : slabs) {
             ConvParams P;
             P.n = n;
-            P.kk_begin = (sl.k0 > 0) ? 0 : 1;                  // low ghost plane exists globally?
-            P.kk_end = (sl.k1 < n) ? sl.nzl + 2 : sl.nzl + 1;  // high ghost plane exists globally?
+            P.kk_begin = 1;  // owned planes only: the ghost planes of Y are exchanged (exchange_Y_halos), not recomputed -- a ghost plane
+            P.kk_end = sl.nzl + 1;  // would cost a whole 16-plane tile layer of Step 1 (41 % extra on 8 GPUs at 256^3)
             P.k0 = sl.k0;
             for (int a = 0; a < 3; a++) P.bbox_min[a] = bbox_min[a];
             P.cell = cell;
@@ -507,7 +507,14 @@ struct Solver final : SolverBase {
                                    sl.Y1.p, sl.Y2.p);
         }
         HIPCHK(hipGetLastError());
+        exchange_Y_halos();
         have_conv = true;
+    }
+    // ghost planes of Y0, Y1, Y2 from the neighbouring slabs (device copies / ncclSend+ncclRecv): the divergence reads Y2 one plane
+    // below (and above, at the global top), the fast integration reads all three one plane below
+    void exchange_Y_halos() {
+        if (total_slabs <= 1) return;
+        for (int sel : {ARR_Y0, ARR_Y1, ARR_Y2}) halo_exchange(sel);
     }
 
     void launch_div(int scrub) {
@@ -1071,13 +1078,16 @@ struct Solver final : SolverBase {
     // z' = M^-1 r on every slab (no projection).  dot: also leave the partial sums of r.z' in sl.partials; returns
     // their count per slab.  One slab: x-fwd, y-fwd, z-fused, y-inv, x-inv in place on W1.  P slabs: the y sweeps write /
     // read the packed layout [dest slab][z_local][y_local][x] and two all-to-alls turn z-slabs into y-pencils and back.
-    enum ArrSel { ARR_R = 0, ARR_Z = 1, ARR_P = 2, ARR_X = 3, ARR_Q = 4 };
+    enum ArrSel { ARR_R = 0, ARR_Z = 1, ARR_P = 2, ARR_X = 3, ARR_Q = 4, ARR_Y0 = 5, ARR_Y1 = 6, ARR_Y2 = 7 };
     static T* arr(Slab<T>& sl, int sel) {
         switch (sel) {
             case ARR_R: return sl.r.p;
             case ARR_Z: return sl.z.p;
             case ARR_P: return sl.p.p;
             case ARR_X: return sl.x.p;
+            case ARR_Y0: return sl.Y0.p;
+            case ARR_Y1: return sl.Y1.p;
+            case ARR_Y2: return sl.Y2.p;
             default: return sl.q.p;
         }
     }
