@@ -201,7 +201,7 @@ struct Solver final : SolverBase {
     double bbox_min[3] = {0, 0, 0};
     int64_t S = 0;
     std::vector<double> h_pos, h_wn, h_area;
-    double area_sum = 0., conv_far_gap = 0., last_host_setup_ms = 0.;
+    double area_sum = 0., conv_far_gap = 0., conv_skip_gap = 3.0e38, last_host_setup_ms = 0.;
     int n_clusters = 0;
     int conv_grid_cap = 1 << 30;
     int num_cus = 256, dct_grid_x16 = 16;
@@ -399,6 +399,13 @@ struct Solver final : SolverBase {
                 const char* e = getenv("SHM_CONV_FAR_LOG");  // experiment knob: -ln of the relative size below which a cluster goes to fp32
                 const double far_log = e ? atof(e) : 25.0;
                 conv_far_gap = (far_log + std::log(std::max(1.0, amax / std::max(amin, 1e-300)))) / lambda;
+                // skipped clusters: every source further than r_hi + skip_gap from the tile contributes less than (Amax/Amin) e^{-lambda gap}
+                // of the tile's dominant term (its nearest source, at most r_hi away); all S of them together stay below eps/64 of it
+                // (eps = 2^-24 / 2^-53: the arithmetic's own rounding unit) when lambda gap > ln(64 S (Amax/Amin) / eps).  Exact to rounding;
+                // bites when the kernel decays over a small part of the grid (SprayBottle.pc at 1024^3: two thirds of the clusters).
+                const double eps = sizeof(T) == 8 ? 1.1e-16 : 6.0e-8;
+                const char* sk = getenv("SHM_CONV_NO_SKIP");
+                conv_skip_gap = sk ? 3.0e38 : std::log(64.0 * (double)S * std::max(1.0, amax / std::max(amin, 1e-300)) / eps) / lambda;
             }
             d_src.upload(packed, stream);
             d_src32.upload(packed32, stream);
@@ -486,6 +493,7 @@ struct Solver final : SolverBase {
             P.S = n_clusters * kConvCluster;
             P.n_clusters = n_clusters;
             P.far_gap = (float)conv_far_gap;
+            P.skip_gap = (float)std::min(conv_skip_gap, 3.0e38);
             P.tiles_x = (n + kConvTile - 1) / kConvTile;
             P.tiles_y = P.tiles_x;
             // nodes per lane (a z-column sharing dx^2 + dy^2): 4 when the grid still yields a full wave of workgroups, else 2

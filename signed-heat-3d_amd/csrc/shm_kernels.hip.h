@@ -139,6 +139,7 @@ struct ConvParams {
     int S;              // padded to whole clusters
     int n_clusters;
     float far_gap;      // fp64 path: a cluster is "far" when d_lo(tile, cluster) - r_hi(tile) > far_gap
+    float skip_gap;     // a cluster is skipped when that gap exceeds skip_gap: S (Amax/Amin) e^{-lambda gap} < eps/64 of the dominant term
     int exact_offset;   // fp32 path only: 1 = per-node nearest-source distance (coarse grids: lambda * tile diameter too large)
     int n_tiles;        // total tiles; workgroups stride over them (fewer workgroups than slots leave room for the set-up stream)
 };
@@ -169,7 +170,6 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
     constexpr bool kMixed = sizeof(T) == 8;
     __shared__ T tile[kSrcTile * 6];
     __shared__ float tile32[kMixed ? kSrcTile * 6 : 1];
-    __shared__ float cls[kConvChunk * 4];
     __shared__ float red[kBlock / kWave];
     constexpr int kTab = kMixed ? (1 << YukawaMath<double>::kExpTabBits) : 1;
     __shared__ double exp_tab[kTab];
@@ -258,20 +258,31 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
     for (int c0 = 0; c0 < P.n_clusters; c0 += kConvChunk) {
         const int ncl = min(kConvChunk, P.n_clusters - c0);
         const int cnt = ncl * kConvCluster;
+        // per cluster: lower bound of every (node of the tile, source of the cluster) distance minus the upper bound of the tile's distance
+        // to its nearest source -- from the bounding spheres (uniform addresses: scalar loads), before anything is staged: a chunk whose
+        // clusters are all negligible costs neither the LDS fill nor its barriers.  All branches below are workgroup-uniform.
+        float gaps[kConvChunk];
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < kConvChunk; c++) {
+            const int cc = min(c0 + c, P.n_clusters - 1);
+            const float gdx = cx - clusters[(size_t)cc * 4], gdy = cy - clusters[(size_t)cc * 4 + 1], gdz = cz - clusters[(size_t)cc * 4 + 2];
+            gaps[c] = sqrtf(gdx * gdx + gdy * gdy + gdz * gdz) * 0.999999f - rt - clusters[(size_t)cc * 4 + 3] - r_hi;
+            any = any || (c < ncl && !(gaps[c] > P.skip_gap));
+        }
+        if (!any) continue;
         __syncthreads();
         for (int a = threadIdx.x; a < cnt * 6; a += kBlock) {
             tile[a] = src[(size_t)c0 * kConvCluster * 6 + a];
             if (kMixed) tile32[a] = src32[(size_t)c0 * kConvCluster * 6 + a];
         }
-        if ((int)threadIdx.x < ncl * 4) cls[threadIdx.x] = clusters[(size_t)c0 * 4 + threadIdx.x];
         __syncthreads();
-        for (int c = 0; c < ncl; c++) {
-            bool far = false;
-            if (kMixed) {
-                const float dx = cx - cls[4 * c], dy = cy - cls[4 * c + 1], dz = cz - cls[4 * c + 2];
-                const float dlo = sqrtf(dx * dx + dy * dy + dz * dz) * 0.999999f - rt - cls[4 * c + 3];
-                far = (dlo - r_hi) > P.far_gap;   // identical in every lane: a workgroup-uniform branch
-            }
+#pragma unroll
+        for (int c = 0; c < kConvChunk; c++) {
+            if (c >= ncl) break;
+            const float gap = gaps[c];
+            if (gap > P.skip_gap) continue;   // all the cluster's terms together stay below the rounding unit of the tile's dominant term
+            const bool far = kMixed && gap > P.far_gap;
             if (far) {
 #pragma unroll 2
                 for (int s = c * kConvCluster; s < (c + 1) * kConvCluster; s++) {
