@@ -831,16 +831,37 @@ struct Solver final : SolverBase {
     void enqueue_invert_G() {
         hipStream_t stream = stream2;
         const int nb = mp / kGJ;
+        static const int outer_env = getenv("SHM_GJ_OUTER") ? atoi(getenv("SHM_GJ_OUTER")) : 0;   // experiment knob: pivot blocks per outer block
+        const int outer = outer_env > 0 ? std::min(outer_env, 8) : (nb >= 64 ? 4 : 1);
         gjP.alloc(kGJ * kGJ);
-        gjR.alloc((size_t)kGJ * mp);
-        gjC.alloc((size_t)mp * kGJ);
+        gjR.alloc((size_t)outer * kGJ * mp);   // [outer * 64][mp]
+        gjC.alloc((size_t)mp * outer * kGJ);   // [mp][outer * 64]
         gjFlag.alloc(1);
         Ginv32.alloc((size_t)mp * mp);
         HIPCHK(hipMemsetAsync(gjFlag.p, 0, sizeof(int), stream));
-        for (int kb = 0; kb < nb; kb++) {
-            hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjP.p, gjFlag.p);
-            hipLaunchKernelGGL(gj_panels_kernel, dim3(nb), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjP.p, gjR.p, gjC.p);
-            hipLaunchKernelGGL(gj_update_kernel, dim3((unsigned)((size_t)nb * (nb + 1) / 2)), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjR.p, gjC.p);
+        const int c_ld = outer * kGJ;
+        if (outer == 1) {
+            for (int kb = 0; kb < nb; kb++) {
+                hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjP.p, gjFlag.p);
+                hipLaunchKernelGGL(gj_panels_kernel, dim3(nb), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjP.p, gjR.p, 0, gjC.p, c_ld, 0);
+                hipLaunchKernelGGL((gj_update_kernel<GJ_ALL>), dim3((unsigned)((size_t)nb * (nb + 1) / 2)), dim3(kBlock), 0, stream, Ginv.p, mp, nb, kb, 0, 1,
+                                   gjR.p, 0, gjC.p, c_ld, 0, kGJ);
+            }
+        } else {
+            for (int k0 = 0; k0 < nb; k0 += outer) {
+                const int nO = std::min(outer, nb - k0);
+                for (int t = 0; t < nO; t++) {
+                    const int kb = k0 + t;
+                    hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjP.p, gjFlag.p);
+                    hipLaunchKernelGGL(gj_panels_kernel, dim3(nb), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjP.p, gjR.p, t * kGJ, gjC.p, c_ld, t * kGJ);
+                    hipLaunchKernelGGL((gj_update_kernel<GJ_CROSS>), dim3((unsigned)(nO * nb + nO * k0)), dim3(kBlock), 0, stream, Ginv.p, mp, nb, kb, k0, nO,
+                                       gjR.p, t * kGJ, gjC.p, c_ld, t * kGJ, kGJ);
+                }
+                const size_t nr = (size_t)(nb - nO);
+                if (nr > 0)
+                    hipLaunchKernelGGL((gj_update_kernel<GJ_REST>), dim3((unsigned)(nr * (nr + 1) / 2)), dim3(kBlock), 0, stream, Ginv.p, mp, nb, -1, k0, nO,
+                                       gjR.p, 0, gjC.p, c_ld, 0, nO * kGJ);
+            }
         }
         if (nb > 1) hipLaunchKernelGGL(gj_mirror_kernel, dim3((unsigned)((size_t)nb * (nb - 1) / 2)), dim3(kBlock), 0, stream, Ginv.p, mp);
         hipLaunchKernelGGL((convert_kernel<double, float>), dim3(grid_for((size_t)mp * mp, 4096)), dim3(kBlock), 0, stream, (size_t)mp * mp, Ginv.p, Ginv32.p);
