@@ -201,7 +201,7 @@ struct Solver final : SolverBase {
     double bbox_min[3] = {0, 0, 0};
     int64_t S = 0;
     std::vector<double> h_pos, h_wn, h_area;
-    double area_sum = 0., conv_far_gap = 0., conv_skip_gap = 3.0e38, last_host_setup_ms = 0.;
+    double area_sum = 0., conv_far_gap = 0., conv_skip_base = 3.0e38, last_host_setup_ms = 0.;
     int n_clusters = 0;
     int conv_grid_cap = 1 << 30;
     int num_cus = 256, dct_grid_x16 = 16;
@@ -358,7 +358,7 @@ struct Solver final : SolverBase {
             n_clusters = (int)((S + kConvCluster - 1) / kConvCluster);
             const int64_t Spad = (int64_t)n_clusters * kConvCluster;
             std::vector<T> packed((size_t)Spad * 6, (T)0);
-            std::vector<float> packed32((size_t)Spad * 6, 0.f), cl((size_t)n_clusters * 4, 0.f);
+            std::vector<float> packed32((size_t)Spad * 6, 0.f), cl((size_t)n_clusters * kConvClusterRec, 0.f);
             double amin = 1e300, amax = 0.;
             for (int64_t t = 0; t < Spad; t++) {
                 const int64_t s = order[(size_t)std::min<int64_t>(t, S - 1)].second;  // padding repeats the last source with zero weight
@@ -390,8 +390,18 @@ struct Solver final : SolverBase {
                     }
                     rad = std::max(rad, std::sqrt(d2));
                 }
-                for (int a = 0; a < 3; a++) cl[4 * (size_t)c + a] = (float)cc[a];
-                cl[4 * (size_t)c + 3] = (float)(rad * 1.00001 + 1e-30);
+                for (int a = 0; a < 3; a++) cl[kConvClusterRec * (size_t)c + a] = (float)cc[a];
+                cl[kConvClusterRec * (size_t)c + 3] = (float)(rad * 1.00001 + 1e-30);
+                double wmax2 = 0.;  // largest source weight |A N| of the cluster (skip test: ln of it, rounded up)
+                for (int e = 0; e < kConvCluster; e++) {
+                    double w2 = 0.;
+                    for (int a = 0; a < 3; a++) {
+                        const double w = (double)packed[6 * ((size_t)c * kConvCluster + e) + 3 + a];
+                        w2 += w * w;
+                    }
+                    wmax2 = std::max(wmax2, w2);
+                }
+                cl[kConvClusterRec * (size_t)c + 4] = wmax2 > 0. ? (float)(0.5 * std::log(wmax2) + 1e-5) : -1.0e30f;
             }
             // far when lambda * (d_lo - r_hi) > 25 + ln(Amax/Amin): the cluster's terms are below e^-25 ~ 1.4e-11 of the
             // tile's dominant term, so their fp32 rounding (~1e-5 incl. the exponent) stays below 2e-16 of it
@@ -399,13 +409,14 @@ struct Solver final : SolverBase {
                 const char* e = getenv("SHM_CONV_FAR_LOG");  // experiment knob: -ln of the relative size below which a cluster goes to fp32
                 const double far_log = e ? atof(e) : 25.0;
                 conv_far_gap = (far_log + std::log(std::max(1.0, amax / std::max(amin, 1e-300)))) / lambda;
-                // skipped clusters: every source further than r_hi + skip_gap from the tile contributes less than (Amax/Amin) e^{-lambda gap}
-                // of the tile's dominant term (its nearest source, at most r_hi away); all S of them together stay below eps/64 of it
-                // (eps = 2^-24 / 2^-53: the arithmetic's own rounding unit) when lambda gap > ln(64 S (Amax/Amin) / eps).  Exact to rounding;
-                // bites when the kernel decays over a small part of the grid (SprayBottle.pc at 1024^3: two thirds of the clusters).
+                // skipped clusters: a source further than r_hi + gap from the tile contributes less than (A_s / A_near) e^{-lambda gap} of
+                // the tile's dominant term (its nearest source: weight A_near, at most r_hi away).  A cluster with largest weight A_c is
+                // skipped when lambda gap > ln(64 S / eps) + ln(A_c / A_near): all skipped sources together (at most S) then stay below eps/64
+                // of the dominant term (eps = 2^-24 / 2^-53: the arithmetic's own rounding unit).  Exact to rounding; bites when the kernel
+                // decays over a small part of the grid (SprayBottle.pc at 1024^3: two thirds of the clusters).
                 const double eps = sizeof(T) == 8 ? 1.1e-16 : 6.0e-8;
                 const char* sk = getenv("SHM_CONV_NO_SKIP");
-                conv_skip_gap = sk ? 3.0e38 : std::log(64.0 * (double)S * std::max(1.0, amax / std::max(amin, 1e-300)) / eps) / lambda;
+                conv_skip_base = sk ? 3.0e38 : std::log(64.0 * (double)S / eps);
             }
             d_src.upload(packed, stream);
             d_src32.upload(packed32, stream);
@@ -493,7 +504,8 @@ struct Solver final : SolverBase {
             P.S = n_clusters * kConvCluster;
             P.n_clusters = n_clusters;
             P.far_gap = (float)conv_far_gap;
-            P.skip_gap = (float)std::min(conv_skip_gap, 3.0e38);
+            P.skip_base = (float)std::min(conv_skip_base, 3.0e38);
+            P.inv_lambda = (float)(1.0 / lambda);
             P.tiles_x = (n + kConvTile - 1) / kConvTile;
             P.tiles_y = P.tiles_x;
             // nodes per lane (a z-column sharing dx^2 + dy^2): 4 when the grid still yields a full wave of workgroups, else 2

@@ -139,7 +139,8 @@ struct ConvParams {
     int S;              // padded to whole clusters
     int n_clusters;
     float far_gap;      // fp64 path: a cluster is "far" when d_lo(tile, cluster) - r_hi(tile) > far_gap
-    float skip_gap;     // a cluster is skipped when that gap exceeds skip_gap: S (Amax/Amin) e^{-lambda gap} < eps/64 of the dominant term
+    float skip_base;    // ln(64 S / eps): a cluster (largest weight A_c) is skipped when lambda gap > skip_base + ln(A_c / A_near)
+    float inv_lambda;
     int exact_offset;   // fp32 path only: 1 = per-node nearest-source distance (coarse grids: lambda * tile diameter too large)
     int n_tiles;        // total tiles; workgroups stride over them (fewer workgroups than slots leave room for the set-up stream)
 };
@@ -148,6 +149,7 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 constexpr int kConvTile = 8;      // 8x8x8 nodes per workgroup, 2 per lane
 constexpr int kConvCluster = 64;  // sources per cluster (Morton-sorted on the host)
 constexpr int kConvChunk = kSrcTile / kConvCluster;  // clusters per LDS fill
+constexpr int kConvClusterRec = 5;  // floats per cluster record: bounding sphere (centre, radius), ln of its largest source weight
 
 // Workgroup = one compact 8x8x8 tile of nodes (2 per lane); sources arrive as Morton-sorted clusters of 64 with bounding
 // spheres, staged through LDS 8 clusters at a time and broadcast-read by every lane.
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
     constexpr bool kMixed = sizeof(T) == 8;
     __shared__ T tile[kSrcTile * 6];
     __shared__ float tile32[kMixed ? kSrcTile * 6 : 1];
-    __shared__ float red[kBlock / kWave];
+    __shared__ float red[kBlock / kWave], redw[kBlock / kWave];
     constexpr int kTab = kMixed ? (1 << YukawaMath<double>::kExpTabBits) : 1;
     __shared__ double exp_tab[kTab];
     if (kMixed)
@@ -211,16 +213,39 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
     const float cx = (float)((i0 + 3.5) * P.cell + P.bbox_min[0]), cy = (float)((j0 + 3.5) * P.cell + P.bbox_min[1]);
     const float cz = (float)((P.k0 + kk0 - 1 + kHalfZ) * P.cell + P.bbox_min[2]);
     const float rt = (float)(sqrt(3.5 * 3.5 * 2 + kHalfZ * kHalfZ) * P.cell) * 1.000001f;
-    float dmin = 3.0e38f;
+    float dmin = 3.0e38f, wnear = 0.f;   // nearest source and |A N|^2 of it (ties -- the zero-weight padding repeats a source -- go to the larger weight)
     for (int s = threadIdx.x; s < P.S; s += kBlock) {
         const float dx = cx - (float)src[(size_t)s * 6], dy = cy - (float)src[(size_t)s * 6 + 1], dz = cz - (float)src[(size_t)s * 6 + 2];
-        dmin = fminf(dmin, dx * dx + dy * dy + dz * dz);
+        const float wx = (float)src[(size_t)s * 6 + 3], wy = (float)src[(size_t)s * 6 + 4], wz = (float)src[(size_t)s * 6 + 5];
+        const float d2 = dx * dx + dy * dy + dz * dz, w2 = wx * wx + wy * wy + wz * wz;
+        if (d2 < dmin || (d2 == dmin && w2 > wnear)) {
+            dmin = d2;
+            wnear = w2;
+        }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, off, kWave));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dmin;
+    for (int off = 32; off > 0; off >>= 1) {
+        const float od = __shfl_xor(dmin, off, kWave), ow = __shfl_xor(wnear, off, kWave);
+        if (od < dmin || (od == dmin && ow > wnear)) {
+            dmin = od;
+            wnear = ow;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = dmin;
+        redw[threadIdx.x >> 6] = wnear;
+    }
     __syncthreads();
-    dmin = sqrtf(fminf(fminf(red[0], red[1]), fminf(red[2], red[3])));
+    dmin = red[0];
+    wnear = redw[0];
+#pragma unroll
+    for (int a = 1; a < kBlock / kWave; a++)
+        if (red[a] < dmin || (red[a] == dmin && redw[a] > wnear)) {
+            dmin = red[a];
+            wnear = redw[a];
+        }
+    dmin = sqrtf(dmin);
+    const float ln_anear = 0.5f * __logf(fmaxf(wnear, 1e-37f)) - 1e-5f;   // rounded down
     const float r_hi = dmin * 1.000001f + rt;                   // every node of the tile has a source at most this far
     const float d0t = fmaxf(0.f, dmin * 0.999999f - rt);        // no source is closer than this to any node of the tile
 
@@ -262,13 +287,16 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
         // to its nearest source -- from the bounding spheres (uniform addresses: scalar loads), before anything is staged: a chunk whose
         // clusters are all negligible costs neither the LDS fill nor its barriers.  All branches below are workgroup-uniform.
         float gaps[kConvChunk];
+        bool skip[kConvChunk];
         bool any = false;
 #pragma unroll
         for (int c = 0; c < kConvChunk; c++) {
             const int cc = min(c0 + c, P.n_clusters - 1);
-            const float gdx = cx - clusters[(size_t)cc * 4], gdy = cy - clusters[(size_t)cc * 4 + 1], gdz = cz - clusters[(size_t)cc * 4 + 2];
-            gaps[c] = sqrtf(gdx * gdx + gdy * gdy + gdz * gdz) * 0.999999f - rt - clusters[(size_t)cc * 4 + 3] - r_hi;
-            any = any || (c < ncl && !(gaps[c] > P.skip_gap));
+            const float* rec = clusters + (size_t)cc * kConvClusterRec;
+            const float gdx = cx - rec[0], gdy = cy - rec[1], gdz = cz - rec[2];
+            gaps[c] = sqrtf(gdx * gdx + gdy * gdy + gdz * gdz) * 0.999999f - rt - rec[3] - r_hi;
+            skip[c] = gaps[c] > (P.skip_base + rec[4] - ln_anear) * P.inv_lambda;   // all its terms together: below the rounding unit of the dominant term
+            any = any || (c < ncl && !skip[c]);
         }
         if (!any) continue;
         __syncthreads();
@@ -281,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
         for (int c = 0; c < kConvChunk; c++) {
             if (c >= ncl) break;
             const float gap = gaps[c];
-            if (gap > P.skip_gap) continue;   // all the cluster's terms together stay below the rounding unit of the tile's dominant term
+            if (skip[c]) continue;
             const bool far = kMixed && gap > P.far_gap;
             if (far) {
 #pragma unroll 2
