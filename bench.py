@@ -241,6 +241,9 @@ def main():
             # Step 1+2 is compute-bound on the vector ALU: 18 nominal flop per (node, source) pair against the
             # fp64 / fp32 vector peak; the fp64 inner loop issues 28 fp64 VALU + 1 rsq + 1 ldexp + 3 int ops per pair (ISA count)
             "step1": {"kernel": "conv_normalize_kernel", "bound": "valu", "pairs": float(N) * float(pre["S"]),
+                      "pairs_note": "nominal N*S; source clusters whose total contribution is below the rounding unit of a tile's dominant term are "
+                                    "skipped (bit-identical result): none on the bunny workloads, ~10% on rocker 512^3, ~70% on SprayBottle 1024^3, "
+                                    "where pairs_per_s and frac therefore overstate the arithmetic actually done",
                       "pairs_per_s": float(N) * float(pre["S"]) / world / (avg["ms_conv"] * 1e-3),
                       "achieved_TFLOPs_nominal_18_per_pair": 18.0 * float(N) * float(pre["S"]) / world / (avg["ms_conv"] * 1e-3) / 1e12,
                       "peak_TFLOPs_vector": 78.6 if precision == 64 else 157.3,
