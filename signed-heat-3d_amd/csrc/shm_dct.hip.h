@@ -45,8 +45,11 @@
 #ifndef SHM_DCT_WAVE_FFT
 #define SHM_DCT_WAVE_FFT 0x100  // bit log2(n): FFT passes of that length are wave-local (a wave owns whole lines: no workgroup barriers).
 #endif                         // Measured: n = 256 4 % faster per dual iteration (dense sweeps +8 %), n = 512 14 % slower -> 256 only
-#ifndef SHM_DCT_LC9
-#define SHM_DCT_LC9 8          // complex lines per tile at n = 512
+#ifndef SHM_DCT_LC9_F64
+#define SHM_DCT_LC9_F64 4      // complex lines per tile at n = 512, fp64 (4: 1.51 ms per dual iteration at 512^3, 8: 1.62)
+#endif
+#ifndef SHM_DCT_LC9_F32
+#define SHM_DCT_LC9_F32 8      // ... fp32 (8: 1.83, 4: 1.89)
 #endif
 #ifndef SHM_DCT_LC8
 #define SHM_DCT_LC8 4          // complex lines per tile at n = 256 (4: 0.224 ms per dual iteration, 8: 0.234)
@@ -70,8 +73,12 @@ enum DctMode : int { DCT_FWD = 0, DCT_INV = 1, DCT_FUSED = 2 };
 // complex lines per tile: 8 (16 real lines = one 128-byte row per element row); 4 at n = 1024, where an fp64 tile of 8 would take
 // 147 KB of LDS (one workgroup per CU).  (Measured at n = 512: 4 instead of 8 lines doubles the residency but halves the access
 // granularity to 64 bytes -- no net change, so 512 keeps the full 128-byte rows.)
-template <int LOG2N> constexpr int dct_lc() { return LOG2N >= 10 ? 4 : (LOG2N == 8 ? SHM_DCT_LC8 : (LOG2N == 9 ? SHM_DCT_LC9 : 8)); }
-constexpr int dct_lines_for(int log2n) { return log2n >= 10 ? 8 : (log2n == 8 ? 2 * SHM_DCT_LC8 : (log2n == 9 ? 2 * SHM_DCT_LC9 : 16)); }
+template <int LOG2N, int TB /* sizeof(real) */> constexpr int dct_lc() {
+    return LOG2N >= 10 ? 4 : (LOG2N == 8 ? SHM_DCT_LC8 : (LOG2N == 9 ? (TB == 8 ? SHM_DCT_LC9_F64 : SHM_DCT_LC9_F32) : 8));
+}
+constexpr int dct_lines_for(int log2n, int tb) {
+    return log2n >= 10 ? 8 : (log2n == 8 ? 2 * SHM_DCT_LC8 : (log2n == 9 ? 2 * (tb == 8 ? SHM_DCT_LC9_F64 : SHM_DCT_LC9_F32) : 16));
+}
 
 // Address of element k of line l of tile t:
 //   off + (t % tiles_a) a_stride + (t / tiles_a) b_stride + l line_stride + (k >> seg_shift) seg_stride + (k & seg_mask) elem_stride
@@ -102,14 +109,14 @@ __device__ __forceinline__ long long dct_addr(const DctAddr& A, long long base, 
 // Twiddles live in LDS up to n = 256; from n = 512 on they are read from global memory (L1/L2 resident, 8-16 KB) so that
 // two fp64 tiles (73.8 KB each at n = 512) fit in one CU's 160 KB and the load/FFT/store phases of two blocks overlap.
 template <int LOG2N> constexpr bool dct_tw_in_lds() { return LOG2N <= SHM_DCT_TW_LDS_MAX; }
-template <int LOG2N> constexpr size_t dct_lds_bytes(size_t cplx_size) {
-    return ((size_t)(1 << LOG2N) * (dct_lc<LOG2N>() + 1) + (dct_tw_in_lds<LOG2N>() ? (size_t)(1 << LOG2N) : 0)) * cplx_size + 64;
+template <int LOG2N, int TB> constexpr size_t dct_lds_bytes() {
+    return ((size_t)(1 << LOG2N) * (dct_lc<LOG2N, TB>() + 1) + (dct_tw_in_lds<LOG2N>() ? (size_t)(1 << LOG2N) : 0)) * (size_t)(2 * TB) + 64;
 }
 
 // One Stockham pass over the tile: every thread holds its work items in registers across the barrier.
 template <typename TP, int LOG2N, int R, int NS, int SIGN>
 __device__ __forceinline__ void dct_fft_pass(Cplx<TP>* buf, const Cplx<TP>* tw, int tid) {
-    constexpr int LC = dct_lc<LOG2N>();
+    constexpr int LC = dct_lc<LOG2N, (int)sizeof(TP)>();
     constexpr int items = PassGeom<LOG2N, R, LC>::items;
     constexpr int IPT = (items + kBlock - 1) / kBlock;
     Cplx<TP> v[IPT][R];
@@ -155,7 +162,7 @@ template <int LOG2N> constexpr bool dct_wave_fft() { return ((SHM_DCT_WAVE_FFT >
 
 template <typename TP, int LOG2N, int R, int NS, int SIGN>
 __device__ __forceinline__ void dct_fft_pass_wave(Cplx<TP>* buf, const Cplx<TP>* tw, int tid) {
-    constexpr int LC = dct_lc<LOG2N>(), n = 1 << LOG2N;
+    constexpr int LC = dct_lc<LOG2N, (int)sizeof(TP)>(), n = 1 << LOG2N;
     constexpr int B = n / R;                      // butterflies per line
     constexpr int LW = LC / (kBlock / kWave);     // lines per wave
     constexpr int IPL = (B + kWave - 1) / kWave;  // butterflies per lane and line
@@ -190,7 +197,7 @@ __device__ __forceinline__ void dct_fft_wave(Cplx<TP>* buf, const Cplx<TP>* tw, 
 // allows them.  Without it the n = 512 fp64 kernels land just above 256 registers, i.e. one tile per CU; asking for more than two
 // (fp32 tiles are half the size) makes the allocator spill.
 template <int LOG2N, int CPLX_BYTES> constexpr int dct_waves_per_simd() {
-    constexpr int by_lds = (int)((size_t)(160 * 1024) / dct_lds_bytes<LOG2N>(CPLX_BYTES));
+    constexpr int by_lds = (int)((size_t)(160 * 1024) / dct_lds_bytes<LOG2N, CPLX_BYTES / 2>());
     constexpr int want = LOG2N <= 8 ? (SHM_DCT_WAVES_256 > 0 ? SHM_DCT_WAVES_256 : 1) : (CPLX_BYTES == 8 ? SHM_DCT_WAVES_F32 : 2);
     return by_lds >= want ? want : (by_lds >= 1 ? by_lds : 1);
 }
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(kBlock, ((LOG2N >= SHM_DCT_WAVES_HINT || SHM_DCT_WA
                                                            double* __restrict__ partials, const int* __restrict__ tile_list /* nullptr: all tiles */,
                                                            const unsigned* __restrict__ elem_mask /* nullptr: all elements; else bit k = element k is non-zero on input / needed on output */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int LC = dct_lc<LOG2N>(), kFftRow = LC + 1, kFftLC = LC;
+    constexpr int LC = dct_lc<LOG2N, (int)sizeof(TP)>(), kFftRow = LC + 1, kFftLC = LC;
     constexpr int n = 1 << LOG2N, L = 2 * LC, LOG2L = ilog2(L), total = n * L;
     constexpr int EPT = (total + kBlock - 1) / kBlock;  // elements per thread (n/16; 1 at n = 16)
     constexpr int CH = EPT < 16 ? EPT : 16;              // register chunk of the global <-> LDS copies

@@ -1049,7 +1049,7 @@ struct Solver final : SolverBase {
     void launch_dct_k(const DctParams& P, int ntiles, const TIn* in, TOut* out, const TOut* dotw, double* partials, const int* tile_list, const unsigned* elem_mask) {
         auto kern = dct_lines_kernel<TP, TIn, TOut, MODE, DOT, LOG2N, XPASS, SEG>;
         static bool configured = false;  // per instantiation
-        constexpr size_t lds = dct_lds_bytes<LOG2N>(sizeof(Cplx<TP>));
+        constexpr size_t lds = dct_lds_bytes<LOG2N, (int)sizeof(TP)>();
         if (!configured) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             configured = true;
@@ -1137,7 +1137,7 @@ struct Solver final : SolverBase {
         const int P = total_slabs;
         const int nzl = n / P, nyl = n / P;  // planes per slab == pencil rows per slab (P | n)
         const double inv8 = 8.0 / ((double)n * n * n);
-        const int kDctLines = dct_lines_for(log2n);                      // real lines per tile (16, or 8 from n = 512 on)
+        const int kDctLines = dct_lines_for(log2n, (int)sizeof(TP));                      // real lines per tile (16, or 8 from n = 512 on)
         const int tiles_slab = (int)((long long)nzl * nn / kDctLines);  // tiles of one slab for the x and y sweeps
         int log2nyl = 0;
         while ((1 << log2nyl) < nyl) log2nyl++;
@@ -1270,7 +1270,7 @@ struct Solver final : SolverBase {
     // the constraint set is built, written only inside it), so the skipped lines transform to the zeros they would produce.
     void build_active_tiles(const std::vector<int64_t>& touched_nodes) {
         Slab<T>& sl = slabs[0];
-        const int L = dct_lines_for(log2n_of(n));
+        const int L = dct_lines_for(log2n_of(n), (int)sizeof(TP));
         const int64_t nn = n, pl = (int64_t)n * n;
         std::vector<int> ax, planes;
         for (int64_t g : touched_nodes) {
@@ -1308,7 +1308,7 @@ struct Solver final : SolverBase {
     void launch_precond_sparse(int in_sel, int out_sel) {
         Slab<T>& sl = slabs[0];
         const long long nn = n, plane = (long long)n * n;
-        const int L = dct_lines_for(log2n);
+        const int L = dct_lines_for(log2n, (int)sizeof(TP));
         const int tiles_all = (int)(plane * nn / L / nn);  // = n*n/L tiles per sweep
         DctParams Q{};
         Q.inv_n3_8 = 8.0 / ((double)n * n * n);
@@ -1472,7 +1472,7 @@ struct Solver final : SolverBase {
             st->preconditioner = SHM_PRECOND_DCT;
             st->solver = total_slabs > 1 ? SHM_SOLVER_DUAL_SLABS : SHM_SOLVER_DUAL;
             if (sparse_ok) {  // bytes the five sparse sweeps actually move: active x tiles, active planes (y sweeps and the masked z sweep)
-                const double L = dct_lines_for(log2n), tile_bytes = L * n * sizeof(TP);
+                const double L = dct_lines_for(log2n, (int)sizeof(TP)), tile_bytes = L * n * sizeof(TP);
                 const double planes_active = (double)slabs[0].n_act_y / (n / L);
                 st->bytes_per_iter = 4.0 * slabs[0].n_act_x * tile_bytes + 4.0 * slabs[0].n_act_y * tile_bytes + 2.0 * planes_active * n * n * sizeof(TP);
             } else {
