@@ -48,6 +48,9 @@
 #ifndef SHM_DCT_LC9_F64
 #define SHM_DCT_LC9_F64 4      // complex lines per tile at n = 512, fp64 (4: 1.51 ms per dual iteration at 512^3, 8: 1.62)
 #endif
+#ifndef SHM_DCT_LC10_F32
+#define SHM_DCT_LC10_F32 4     // complex lines per tile at n = 1024, fp32 (fp64: 4, eight would not fit the LDS)
+#endif
 #ifndef SHM_DCT_LC9_F32
 #define SHM_DCT_LC9_F32 8      // ... fp32 (8: 1.83, 4: 1.89)
 #endif
@@ -74,10 +77,10 @@ enum DctMode : int { DCT_FWD = 0, DCT_INV = 1, DCT_FUSED = 2 };
 // 147 KB of LDS (one workgroup per CU).  (Measured at n = 512: 4 instead of 8 lines doubles the residency but halves the access
 // granularity to 64 bytes -- no net change, so 512 keeps the full 128-byte rows.)
 template <int LOG2N, int TB /* sizeof(real) */> constexpr int dct_lc() {
-    return LOG2N >= 10 ? 4 : (LOG2N == 8 ? SHM_DCT_LC8 : (LOG2N == 9 ? (TB == 8 ? SHM_DCT_LC9_F64 : SHM_DCT_LC9_F32) : 8));
+    return LOG2N >= 10 ? (TB == 8 ? 4 : SHM_DCT_LC10_F32) : (LOG2N == 8 ? SHM_DCT_LC8 : (LOG2N == 9 ? (TB == 8 ? SHM_DCT_LC9_F64 : SHM_DCT_LC9_F32) : 8));
 }
 constexpr int dct_lines_for(int log2n, int tb) {
-    return log2n >= 10 ? 8 : (log2n == 8 ? 2 * SHM_DCT_LC8 : (log2n == 9 ? 2 * (tb == 8 ? SHM_DCT_LC9_F64 : SHM_DCT_LC9_F32) : 16));
+    return log2n >= 10 ? (tb == 8 ? 8 : 2 * SHM_DCT_LC10_F32) : (log2n == 8 ? 2 * SHM_DCT_LC8 : (log2n == 9 ? 2 * (tb == 8 ? SHM_DCT_LC9_F64 : SHM_DCT_LC9_F32) : 16));
 }
 
 // Address of element k of line l of tile t:
