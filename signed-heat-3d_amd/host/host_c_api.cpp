@@ -1,5 +1,6 @@
 // Flat C wrapper around the C++ host layer so that Python tests / bench.py can drive the same code path the
 // headless CLI uses (ctypes cannot call C++ methods).  Not part of the drop-in boundary.
+#include <chrono>
 #include <cstring>
 #include <string>
 
@@ -140,6 +141,25 @@ int shmh_compute_distance(void* hv, double tCoef, double hCoef, double scale, in
         o.fastIntegration = fast != 0;
         VectorXd phi = h->is_cloud ? h->solver.computeDistance(h->cloud, o) : h->solver.computeDistance(h->mesh, o);
         std::memcpy(phi_out, phi.data(), phi.size() * sizeof(double));
+        if (stats) *stats = h->solver.lastStats();
+    });
+}
+
+// Wall time of the C++ drop-in call alone -- computeDistance() returning its VectorXd, as the reference's main.cpp:90-91 consumes it --
+// without this flat wrapper's extra copy into a caller buffer (tools/pcie_inclusive.py).
+int shmh_time_compute_distance(void* hv, double tCoef, double hCoef, double scale, int rebuild, int fast, double* seconds_out, shm_stats* stats) {
+    Host* h = (Host*)hv;
+    return guard([&] {
+        SignedHeat3DOptions o;
+        o.tCoef = tCoef;
+        o.hCoef = hCoef;
+        o.scale = scale;
+        o.rebuild = rebuild != 0;
+        o.fastIntegration = fast != 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        VectorXd phi = h->is_cloud ? h->solver.computeDistance(h->cloud, o) : h->solver.computeDistance(h->mesh, o);
+        const auto t1 = std::chrono::steady_clock::now();
+        if (seconds_out) *seconds_out = std::chrono::duration<double>(t1 - t0).count() + 0. * phi[0];
         if (stats) *stats = h->solver.lastStats();
     });
 }

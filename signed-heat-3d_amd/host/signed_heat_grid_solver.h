@@ -12,7 +12,16 @@
 
 namespace shm_host {
 
-using VectorXd = std::vector<double>;  // stands where geometrycentral::Vector<double> (Eigen::VectorXd) stands in the demo
+// Allocator that default-initialises: VectorXd(n) allocates without zero-filling, like the Eigen::VectorXd it stands for (the
+// reference's `Vector<double> phi` is written by the solve, never read before); a value-initialising std::vector would page in and
+// zero 1 GB at 512^3 before the device copy overwrites it.
+template <typename T> struct DefaultInitAllocator : std::allocator<T> {
+    template <typename U> struct rebind { using other = DefaultInitAllocator<U>; };
+    using std::allocator<T>::allocator;
+    template <typename U> void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void*>(p)) U; }
+    template <typename U, typename... Args> void construct(U* p, Args&&... args) { ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...); }
+};
+using VectorXd = std::vector<double, DefaultInitAllocator<double>>;  // stands where geometrycentral::Vector<double> (Eigen::VectorXd) stands in the demo
 
 class SignedHeatGridSolver {
   public:
