@@ -295,6 +295,44 @@ def test_every_data_file_matches_c_oracle_32(shm, oracle_c, fname):
     assert np.abs(phi - ref).max() < 1e-7 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_fuzz_random_point_sets_match_c_oracle(shm, oracle_c, seed):
+    """Seeded random inputs (a noisy, partly open sphere-like point set with random positive weights) on random grid sizes (powers of
+    two and not), slab counts and solver choices, against the C oracle on the same inputs."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([16, 20, 24, 32, 33, 40, 64]))
+    slabs = int(rng.choice([1, 1, 2, 3]))
+    S = int(rng.integers(40, 400))
+    d = rng.standard_normal((S, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    keep = d[:, 2] > rng.uniform(-1.0, -0.2)                     # open cap
+    d = d[keep]
+    S = len(d)
+    rad = 1.0 + 0.15 * rng.standard_normal(S)
+    pos = d * rad[:, None] * np.array([1.0, rng.uniform(0.5, 1.0), rng.uniform(0.5, 1.0)])
+    nrm = d + 0.2 * rng.standard_normal((S, 3))
+    nrm /= np.linalg.norm(nrm, axis=1)[:, None]
+    area = rng.uniform(0.2, 1.0, S) * (4 * np.pi / S)
+    wn = nrm * area[:, None]
+    c = pos.mean(0)
+    r = np.linalg.norm(pos - c, axis=1).max()
+    s_ = 2.0 * r
+    bbox_min = c - s_
+    cell = 2 * s_ / (n - 1)
+    lam = 1.0 / rng.uniform(0.15, 0.5)
+    mode = ["auto", "primal", "dual"][int(rng.integers(0, 3))] if (n & (n - 1)) == 0 and n % slabs == 0 and (slabs & (slabs - 1)) == 0 else "auto"
+    g = shm.GridSolver(local_slabs=slabs)
+    g.set_problem(pos, wn, area, lam, n, bbox_min, cell)
+    st = g.solve(tol=1e-10, solver=mode)
+    phi, _ = g.get_phi()
+    ref = np.zeros(n ** 3)
+    sto = np.zeros(5)
+    rc = oracle_c.shmo_compute_distance(n, c_(bbox_min), cell, S, c_(pos).reshape(-1), c_(wn).reshape(-1), c_(area), lam, 1, 0, 1e-12, 200000, ref, sto)
+    assert rc == 0
+    assert np.isfinite(phi).all()
+    assert np.abs(phi - ref).max() < 1e-7 * max(1.0, np.abs(ref).max()), (n, slabs, S, mode, st.iters)
+
+
 def test_errors_are_reported(shm):
     d = load_golden("bunny_small_n16")
     s = shm.GridSolver()
