@@ -295,7 +295,7 @@ def test_every_data_file_matches_c_oracle_32(shm, oracle_c, fname):
     assert np.abs(phi - ref).max() < 1e-7 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("seed", list(range(12)))
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("SHM_FUZZ_SEEDS", "12")))))
 def test_fuzz_random_point_sets_match_c_oracle(shm, oracle_c, seed):
     """Seeded random inputs (a noisy, partly open sphere-like point set with random positive weights) on random grid sizes (powers of
     two and not), slab counts and solver choices, against the C oracle on the same inputs."""
