@@ -100,7 +100,7 @@ def cpu_baseline(pre, iters_cpu, tol, seconds_budget=25.0, threads=1):
     total = t_conv + t_div + t_setup + t_iter * iters_cpu
     return {
         "value": N / total, "unit": "grid-nodes/s", "cores": threads, "kind": "port",
-        "sample": "C port of the reference's serial loops (oracle/shm_oracle.c, gcc -O3 -march=native, %d thread(s)): Step 1+2 on %d of %d "
+        "sample": "C port of the reference's serial loops (oracle/shm_oracle.c, gcc -O3 -march=x86-64-v3, %d thread(s)): Step 1+2 on %d of %d "
                   "z-planes (%.2f s, extrapolated linearly to %.0f s), divergence in full (%.2f s), dense-Cholesky projector set-up "
                   "(%.2f s), %d plain projected-CG iterations (%.3f s each) extrapolated to the %d iterations that algorithm needs at "
                   "tolerance %.1e (count taken from an untimed run of the same plain CG on the GPU)"

@@ -76,7 +76,11 @@ typedef struct {
 typedef struct {
     int32_t fast_integration; /* SignedHeat3DOptions::fastIntegration (signed_heat_3d.h:27) */
     int32_t scrub_nonfinite;  /* 1 = mesh overload's divYt scrub (:72-74); 0 = point overload (:180) */
-    double tol;               /* stop when ||P r|| <= tol * ||P b||;  <=0 -> default 1e-8 (fp64) / 1e-5 (fp32) */
+    double tol;               /* relative residual at which the iteration stops; <=0 -> default 1e-8 (fp64) / 1e-5 (fp32).
+                               * PRIMAL: ||P r|| <= tol * ||P b||, r the grid residual projected on null(A).
+                               * DUAL / DUAL_SLABS: ||r_mu|| <= tol * ||r_mu,0||, r_mu = Pm(A K^+ b - S mu) the residual of the
+                               * m-dimensional multiplier system (what that solver iterates on).  Both bound the error of phi; they
+                               * are not the same number (measured at 256^3: tol 1e-8 -> L_inf(phi) 4e-10..3e-9 for DUAL, 4e-8 PRIMAL). */
     int32_t max_iters;        /* <=0 -> default 20*n */
     int32_t check_every;      /* residual is inspected on the host every this many iterations; <=0 -> 32 (4 with the preconditioner) */
     int32_t preconditioner;   /* SHM_PRECOND_AUTO | _NONE | _DCT  (primal solver only) */
@@ -104,7 +108,7 @@ typedef struct {
     int32_t n, m;             /* grid side; constraint rows (distinct source cells) */
     int64_t S;
     int32_t iters;            /* projected-CG iterations executed */
-    double rel_residual;      /* ||P r|| / ||P b|| at exit */
+    double rel_residual;      /* the quantity `tol` bounds, at exit (PRIMAL: ||P r|| / ||P b||; DUAL: ||r_mu|| / ||r_mu,0||) */
     double shift;             /* area-weighted mean of phi over the sources that was subtracted */
     /* device-side timings (hipEvent, ms) */
     double ms_conv;           /* Steps 1+2 */

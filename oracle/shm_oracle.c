@@ -14,7 +14,7 @@
  * feasible form above 64^3.  Everything else follows the reference loop for loop.
  *
  * Node flattening: idx = i + j*n + k*n*n (signed_heat_grid_solver.cpp:505-508).
- * Build: gcc -O3 -march=native -fopenmp -shared -fPIC shm_oracle.c -o _build/libshm_oracle.so -lm
+ * Build: gcc -O3 -march=x86-64-v3 -fopenmp -shared -fPIC shm_oracle.c -o _build/libshm_oracle.so -lm
  * With OMP_NUM_THREADS=1 (or shmo_set_threads(1)) every loop runs in the reference's serial order.
  */
 #include <math.h>

@@ -10,6 +10,7 @@
 // slabs (loop-back transport, used to exercise the slab logic on one GPU); across processes the halo
 // planes and the reduction vectors travel over RCCL (xGMI) on the solver's own stream.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // prototypes and enum values only: librccl itself is dlopen'ed on first multi-process use
 
 #include <dlfcn.h>
 
@@ -55,20 +56,29 @@ static std::string fmt(const char* f, ...) {
     } while (0)
 
 // ---- RCCL, resolved lazily (only multi-process runs touch it) -----------------------------------
+// The library is dlopen'ed at run time (single-GPU users never load it), but the prototypes and enum values come from the
+// real header at build time: the function-pointer types below are decltype(&ncclXxx), so a signature drift in <rccl/rccl.h>
+// is a compile error here, not a silent ABI mismatch.
 struct Rccl {
-    typedef struct ncclComm* comm_t;
-    struct unique_id { char internal[128]; };
-    int (*GetUniqueId)(unique_id*) = nullptr;
-    int (*CommInitRank)(comm_t*, int, unique_id, int) = nullptr;
-    int (*CommDestroy)(comm_t) = nullptr;
-    int (*AllReduce)(const void*, void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
-    int (*Send)(const void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
-    int (*Recv)(void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
+    typedef ncclComm_t comm_t;
+    typedef ncclUniqueId unique_id;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce_ = nullptr;
+    decltype(&ncclSend) Send_ = nullptr;
+    decltype(&ncclRecv) Recv_ = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString_ = nullptr;
     void* h = nullptr;
-    enum { kFloat32 = 7, kFloat64 = 8, kSum = 0 };  // ncclDataType_t / ncclRedOp_t values (rccl.h)
+    enum { kFloat32 = ncclFloat32, kFloat64 = ncclFloat64, kSum = ncclSum };
+    static_assert(sizeof(ncclUniqueId) == 128, "include/shm_grid.h documents a 128-byte unique id");
+    static_assert(ncclFloat32 == 7 && ncclFloat64 == 8 && ncclSum == 0, "tests/native/rccl_mock.c hard-codes these values");
+
+    int AllReduce(const void* s, void* r, size_t c, int dt, int op, comm_t comm, hipStream_t st) { return AllReduce_(s, r, c, (ncclDataType_t)dt, (ncclRedOp_t)op, comm, st); }
+    int Send(const void* s, size_t c, int dt, int peer, comm_t comm, hipStream_t st) { return Send_(s, c, (ncclDataType_t)dt, peer, comm, st); }
+    int Recv(void* r, size_t c, int dt, int peer, comm_t comm, hipStream_t st) { return Recv_(r, c, (ncclDataType_t)dt, peer, comm, st); }
 
     static Rccl& get() {
         static Rccl r;
@@ -79,27 +89,37 @@ struct Rccl {
         // SHM_RCCL_LIB: tests substitute a shared-memory double (tests/native/rccl_mock.c) to run several ranks on one GPU
         const char* override_lib = getenv("SHM_RCCL_LIB");
         const char* names[] = {override_lib ? override_lib : "librccl.so.1", "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        void* lib = nullptr;
         for (const char* nm : names) {
-            h = dlopen(nm, RTLD_NOW | (override_lib ? RTLD_LOCAL : RTLD_GLOBAL));
-            if (h || override_lib) break;
+            lib = dlopen(nm, RTLD_NOW | (override_lib ? RTLD_LOCAL : RTLD_GLOBAL));
+            if (lib || override_lib) break;
         }
-        if (!h) throw Error(SHM_ERR_RCCL, std::string("cannot load librccl: ") + dlerror());
-#define SYM(field, name)                                                                    \
-    *(void**)(&field) = dlsym(h, name);                                                     \
-    if (!field) throw Error(SHM_ERR_RCCL, std::string("librccl lacks symbol ") + name)
-        SYM(GetUniqueId, "ncclGetUniqueId");
-        SYM(CommInitRank, "ncclCommInitRank");
-        SYM(CommDestroy, "ncclCommDestroy");
-        SYM(AllReduce, "ncclAllReduce");
-        SYM(Send, "ncclSend");
-        SYM(Recv, "ncclRecv");
-        SYM(GroupStart, "ncclGroupStart");
-        SYM(GroupEnd, "ncclGroupEnd");
-        SYM(GetErrorString, "ncclGetErrorString");
-#undef SYM
+        if (!lib) throw Error(SHM_ERR_RCCL, std::string("cannot load librccl: ") + dlerror());
+        // resolve into a scratch copy: a failure leaves the singleton untouched (h stays null, the next call retries)
+        Rccl t;
+        const char* missing = nullptr;
+        auto sym = [&](auto& field, const char* name) {
+            *(void**)(&field) = dlsym(lib, name);
+            if (!field && !missing) missing = name;
+        };
+        sym(t.GetUniqueId, "ncclGetUniqueId");
+        sym(t.CommInitRank, "ncclCommInitRank");
+        sym(t.CommDestroy, "ncclCommDestroy");
+        sym(t.AllReduce_, "ncclAllReduce");
+        sym(t.Send_, "ncclSend");
+        sym(t.Recv_, "ncclRecv");
+        sym(t.GroupStart, "ncclGroupStart");
+        sym(t.GroupEnd, "ncclGroupEnd");
+        sym(t.GetErrorString_, "ncclGetErrorString");
+        if (missing) {
+            dlclose(lib);
+            throw Error(SHM_ERR_RCCL, std::string("librccl lacks symbol ") + missing);
+        }
+        t.h = lib;
+        *this = t;
     }
     void chk(int rc, const char* what) {
-        if (rc != 0) throw Error(SHM_ERR_RCCL, fmt("%s failed: %s", what, GetErrorString ? GetErrorString(rc) : "?"));
+        if (rc != 0) throw Error(SHM_ERR_RCCL, fmt("%s failed: %s", what, GetErrorString_ ? GetErrorString_((ncclResult_t)rc) : "?"));
     }
 };
 
@@ -1048,11 +1068,12 @@ struct Solver final : SolverBase {
     template <int MODE, typename TIn, typename TOut, bool DOT, int LOG2N, bool XPASS, bool SEG>
     void launch_dct_k(const DctParams& P, int ntiles, const TIn* in, TOut* out, const TOut* dotw, double* partials, const int* tile_list, const unsigned* elem_mask) {
         auto kern = dct_lines_kernel<TP, TIn, TOut, MODE, DOT, LOG2N, XPASS, SEG>;
-        static bool configured = false;  // per instantiation
+        static uint64_t configured = 0;  // per instantiation, one bit per device (the attribute is per device)
         constexpr size_t lds = dct_lds_bytes<LOG2N, (int)sizeof(TP)>();
-        if (!configured) {
+        const uint64_t dev_bit = 1ull << (cfg.device & 63);
+        if (!(configured & dev_bit) || cfg.device >= 64) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            configured = true;
+            configured |= dev_bit;
         }
         DctParams Q = P;
         Q.ntiles = ntiles;
@@ -1428,7 +1449,7 @@ struct Solver final : SolverBase {
             if (force_iters > 0) converged = it >= force_iters;
             else if (!std::isfinite(rr) || !std::isfinite(rr0) || !std::isfinite(h_pinned[SC_RZ])) breakdown = true;
             else if (rr <= o.tol * o.tol * rr0) converged = true;
-            log("[shm] dual it=%d rel_res=%.3e", it, std::sqrt(std::fabs(rr / rr0)));
+            log("[shm] dual it=%d rel_res=%.3e", it, rr0 > 0. ? std::sqrt(std::fabs(rr / rr0)) : 0.);
         }
         // ---- x = K^+ (A^T mu - b)   (the additive constant cancels in the shift)
         for (Slab<T>& sl : slabs)
@@ -1450,7 +1471,7 @@ struct Solver final : SolverBase {
             st->m = m;
             st->S = S;
             st->iters = it;
-            st->rel_residual = std::sqrt(std::fabs(rr / rr0));
+            st->rel_residual = rr0 > 0. ? std::sqrt(std::fabs(rr / rr0)) : 0.;
             // the reference shifts phi_ref = -x_kkt = -(x0 - mean(A x0)); report ITS shift: shift(-x0) + mean(A x0)
             st->shift = h_pinned[SC_SHIFT] + h_pinned[SC_AXSUM] / (double)m;
             st->ms_conv = elapsed(e_start, e_conv);
@@ -1522,7 +1543,17 @@ struct Solver final : SolverBase {
         f_setup.record(F.stream);
         F.have_div = true;
         shm_stats cst;
-        F.solve_dual(o, &cst, f_start, f_start, f_start, f_setup, c_s2a, c_s2b, wall0);  // synchronises F.stream; phi = F.q
+        memset(&cst, 0, sizeof cst);
+        // "did not converge" still leaves phi (include/shm_grid.h: SHM_ERR_NOCONV): finish the hand-over, then report it
+        bool noconv = false;
+        std::string noconv_msg;
+        try {
+            F.solve_dual(o, &cst, f_start, f_start, f_start, f_setup, c_s2a, c_s2b, wall0);  // synchronises F.stream; phi = F.q
+        } catch (const Error& e) {
+            if (e.code != SHM_ERR_NOCONV) throw;
+            noconv = true;
+            noconv_msg = e.what();
+        }
         for (Slab<T>& sl : slabs)
             HIPCHK(hipMemcpyAsync(sl.q.p + plane, fs.q.p + (size_t)(sl.k0 + 1) * plane, sl.nown * sizeof(T), hipMemcpyDeviceToDevice, stream));
         HIPCHK(hipStreamSynchronize(stream));
@@ -1534,6 +1565,7 @@ struct Solver final : SolverBase {
             st->ms_wait_setup = elapsed(e_div, e_gather);  // here: the gather of b (the set-up was waited for on the host before it)
             st->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
         }
+        if (noconv) throw Error(SHM_ERR_NOCONV, noconv_msg);
     }
 
     // ------------------------------------------------------------------------------------------
@@ -1676,7 +1708,7 @@ struct Solver final : SolverBase {
             st->m = m;
             st->S = S;
             st->iters = it;
-            st->rel_residual = std::sqrt(std::fabs(rr / rr0));
+            st->rel_residual = rr0 > 0. ? std::sqrt(std::fabs(rr / rr0)) : 0.;
             st->shift = h_pinned[SC_SHIFT];
             st->ms_conv = elapsed(e_start, e_conv);
             st->ms_div = elapsed(e_conv, e_div);
@@ -1780,6 +1812,7 @@ struct Solver final : SolverBase {
             hipLaunchKernelGGL((laplacian_kernel<T>), dim3(grid_for(sl.nown, 4096)), dim3(kBlock), 0, stream, sl.gp, sl.p.p, sl.q.p);
         HIPCHK(hipGetLastError());
         copy_owned_to_host(SHM_FIELD_PHI, out);
+        have_phi = false;  // q now holds L u, not phi
     }
 
     void get_constraints(int64_t* nodes, double* coeffs, int32_t* m_out) override {

@@ -627,7 +627,8 @@ __global__ __launch_bounds__(kBlock) void update_xr_kernel(size_t nvec /* owned/
                                                            T* __restrict__ x, const T* __restrict__ p, T* __restrict__ r,
                                                            const T* __restrict__ q, double* __restrict__ partials) {
     __shared__ double red[8];
-    const double alpha_d = sc[rho_slot] / *pq;
+    const double rho_cur = sc[rho_slot];
+    const double alpha_d = rho_cur == 0. ? 0. : rho_cur / *pq;  // rho == 0: already solved, keep x (no 0/0)
     const T alpha = (T)alpha_d;
     double acc = 0.;
     for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += (size_t)gridDim.x * kBlock) {
@@ -673,7 +674,8 @@ __global__ __launch_bounds__(kBlock) void update_p_kernel(size_t nvec, size_t of
                                                           const double* __restrict__ red0, int init, int use_uw, const T* __restrict__ z,
                                                           T* __restrict__ p) {
     const double rho_new = *red0 - (use_uw ? sc[SC_UW] : 0.);
-    const double beta_d = init ? 0. : rho_new / sc[rho_old_slot];
+    const double rho_old = sc[rho_old_slot];
+    const double beta_d = (init || rho_old == 0.) ? 0. : rho_new / rho_old;
     const T beta = (T)beta_d;
     for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += (size_t)gridDim.x * kBlock) {
         const size_t c = off + v * VEC;
@@ -995,7 +997,8 @@ __global__ __launch_bounds__(kDualBlock) void dual_direction_kernel(int m, int i
         rz += r[a] * v;
     }
     rz = block_sum_1024(rz, lds);
-    const double beta = init ? 0. : rz / sc[SC_RZ];
+    const double rz_old = sc[SC_RZ];
+    const double beta = (init || rz_old == 0.) ? 0. : rz / rz_old;
     for (int a = threadIdx.x; a < m; a += kDualBlock) p[a] = init ? z[a] : z[a] + beta * p[a];
     __syncthreads();
     if (threadIdx.x == 0) sc[SC_RZ] = rz;
@@ -1011,7 +1014,8 @@ __global__ __launch_bounds__(kDualBlock) void dual_update_kernel(int m, const do
     double pSp = 0.;
     for (int a = threadIdx.x; a < m; a += kDualBlock) pSp += p[a] * (Sp[a] - mean);
     pSp = block_sum_1024(pSp, lds);
-    const double alpha = sc[SC_RZ] / pSp;
+    const double rz_cur = sc[SC_RZ];
+    const double alpha = rz_cur == 0. ? 0. : rz_cur / pSp;  // r.z == 0: the system is already solved (m == 1, or an exact start) -- no 0/0
     double rr = 0.;
     for (int a = threadIdx.x; a < m; a += kDualBlock) {
         mu[a] += alpha * p[a];

@@ -129,7 +129,21 @@ int shmh_preprocess(void* hv, double tCoef, double hCoef, double scale, double* 
     });
 }
 
-// computeDistance through the C++ class; phi_out holds n^3 doubles (n from shmh_preprocess).
+// Grid block the solver object currently holds (the reference keeps it across calls with rebuild=false, signed_heat_grid_solver.cpp:8):
+// out[0] = nodes per side (0 before the first build), out[1..3] = bboxMin, out[4..6] = bboxMax, out[7] = cellSize.
+void shmh_grid_info(void* hv, double* out) {
+    Host* h = (Host*)hv;
+    out[0] = (double)h->solver.gridSize();
+    const Vector3 lo = h->solver.gridMin(), hi = h->solver.gridMax();
+    for (int a = 0; a < 3; a++) {
+        out[1 + a] = lo[a];
+        out[4 + a] = hi[a];
+    }
+    out[7] = h->solver.gridCell();
+}
+
+// computeDistance through the C++ class; phi_out holds max(n_requested, n_current)^3 doubles (with rebuild=false a mesh solve keeps the
+// grid of the previous call, so the result has shmh_grid_info()[0]^3 entries whatever hCoef says).
 int shmh_compute_distance(void* hv, double tCoef, double hCoef, double scale, int rebuild, int fast, double* phi_out, shm_stats* stats) {
     Host* h = (Host*)hv;
     return guard([&] {

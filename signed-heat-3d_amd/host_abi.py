@@ -37,6 +37,8 @@ def load_host_library():
     lib.shmh_preprocess.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.POINTER(C.c_int64)]
     lib.shmh_compute_distance.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.POINTER(ShmStats)]
+    lib.shmh_grid_info.argtypes = [C.c_void_p, C.c_void_p]
+    lib.shmh_grid_info.restype = None
     _LIB = lib
     return lib
 
@@ -94,9 +96,16 @@ class HostSolver:
             res.update(pos=pos, wnormal=wn, area=area)
         return res
 
+    def grid_info(self):
+        """Grid block the solver object holds right now: dict(n, bbox_min, bbox_max, cell); n == 0 before the first build."""
+        out = np.zeros(8)
+        self._lib.shmh_grid_info(self._h, out.ctypes.data)
+        return dict(n=int(out[0]), bbox_min=out[1:4].copy(), bbox_max=out[4:7].copy(), cell=float(out[7]))
+
     def compute_distance(self, tCoef=1.0, hCoef=0.0, scale=2.0, rebuild=True, fast=False):
-        n = int(2 * 2.0 ** (hCoef + 3))
+        # with rebuild=False a mesh solve keeps the previous call's grid (signed_heat_grid_solver.cpp:8): size the buffer for either
+        n = max(int(2 * 2.0 ** (hCoef + 3)), self.grid_info()["n"])
         phi = np.empty(n ** 3, dtype=np.float64)
         st = ShmStats()
         self._chk(self._lib.shmh_compute_distance(self._h, tCoef, hCoef, scale, int(rebuild), int(fast), phi.ctypes.data, C.byref(st)))
-        return phi, st
+        return phi[:self.grid_info()["n"] ** 3], st

@@ -14,7 +14,26 @@ def main():
     rank, world, uid_hex, case, mode, out_dir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6]
     shm = shm_import.load()
     d = np.load(os.path.join(ROOT, "tests", "golden", case + ".npz"))
-    s = shm.GridSolver(device=0, rank=rank, world=world, rccl_unique_id=bytes.fromhex(uid_hex))
+    # SHM_WORKER_DEVICE_PER_RANK=1: one GPU per rank and the real librccl (test_multiprocess_ranks_real_rccl); default: all ranks share
+    # device 0 through the shared-memory double of librccl
+    device = rank if os.environ.get("SHM_WORKER_DEVICE_PER_RANK") else 0
+    if uid_hex == "file":   # real RCCL: rank 0 creates the ncclUniqueId and hands it over through the scratch directory
+        import time
+        path = os.path.join(out_dir, "uid.bin")
+        if rank == 0:
+            uid = shm.comm_unique_id()
+            with open(path + ".tmp", "wb") as fh:
+                fh.write(uid)
+            os.replace(path + ".tmp", path)
+        else:
+            t0 = time.time()
+            while not os.path.exists(path):
+                if time.time() - t0 > 120:
+                    raise SystemExit("rank %d: no unique id from rank 0" % rank)
+                time.sleep(0.05)
+            uid = open(path, "rb").read()
+        uid_hex = uid.hex()
+    s = shm.GridSolver(device=device, rank=rank, world=world, rccl_unique_id=bytes.fromhex(uid_hex))
     s.set_problem(d["pos"], d["wnormal"], d["area"], float(d["lam"]), int(d["n"]), d["bbox_min"], float(d["cell"]))
     kw = {"primal-plain": dict(solver="primal", precond="none"), "primal-dct": dict(solver="primal", precond="dct"),
           "dual": dict(solver="dual"), "dual-slabs": dict(solver="dual_slabs"), "fast": dict(fast=True)}[mode]

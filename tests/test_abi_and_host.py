@@ -128,6 +128,19 @@ def test_point_cloud_estimator_against_the_matching_meshes(shm):
         assert (r["area"] > 0).all()
 
 
+def test_adapter_syntax_only_against_stubs(tmp_path):
+    """TYPO GUARD, not parity evidence: host/adapter_geometrycentral.h (the file a maintainer of the reference drops in) has no compiler
+    in this image because geometry-central / Polyscope are absent.  It is type-checked (g++ -fsyntax-only, nothing is linked or run)
+    against minimal stub declarations of the names it touches (tests/native/adapter_stubs/) and against the real include/shm_grid.h,
+    used the way src/main.cpp:52,88-100,290-292 uses the class."""
+    import shutil
+    import subprocess
+    shutil.copy(os.path.join(ROOT, "signed-heat-3d_amd", "host", "adapter_geometrycentral.h"), tmp_path)   # away from the host mirror's own signed_heat_3d.h
+    p = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-I", str(tmp_path), "-I", os.path.join(ROOT, "tests", "native", "adapter_stubs"),
+                        "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "adapter_syntax_check.cpp")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+
+
 def test_cli_reports_missing_device_or_runs():
     import subprocess
     exe = os.path.join(ROOT, "signed-heat-3d_amd", "bin", "shm_grid_cli")

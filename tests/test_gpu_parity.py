@@ -333,6 +333,71 @@ def test_fuzz_random_point_sets_match_c_oracle(shm, oracle_c, seed):
     assert np.abs(phi - ref).max() < 1e-7 * max(1.0, np.abs(ref).max()), (n, slabs, S, mode, st.iters)
 
 
+def test_rebuild_false_keeps_the_previous_grid(shm):
+    """signed_heat_grid_solver.cpp:8 / src/main.cpp:113,146-148: the mesh overload rebuilds the grid iff `options.rebuild` or nothing was
+    built yet; a later call with rebuild=false and another hCoef must keep nx, the bounding box and the cell size of the first call
+    (the time step, areas and constraint rows are recomputed every call).  The point overload rebuilds always (:119)."""
+    import os
+    from conftest import ROOT
+    from signed_heat_3d_amd.host_abi import HostSolver
+    h = HostSolver(os.path.join(ROOT, "data", "bunny_small.obj"), tol=1e-10)
+    assert h.grid_info()["n"] == 0
+    phi16, _ = h.compute_distance(hCoef=0.0, rebuild=False)            # nothing built yet: builds although rebuild=false
+    g16 = h.grid_info()
+    assert g16["n"] == 16 and phi16.size == 16 ** 3
+    assert np.abs(phi16 - load_golden("bunny_small_n16")["phi"]).max() < 1e-7
+    phi_keep, st = h.compute_distance(hCoef=1.0, rebuild=False)       # hCoef changed, rebuild=false: the 16^3 grid stays
+    g = h.grid_info()
+    assert g["n"] == 16 and st.n == 16 and phi_keep.size == 16 ** 3
+    assert np.array_equal(g["bbox_min"], g16["bbox_min"]) and g["cell"] == g16["cell"]
+    assert np.abs(phi_keep - phi16).max() < 1e-9                       # same grid, same sources -> same answer
+    phi_scaled, _ = h.compute_distance(hCoef=1.0, scale=3.0, rebuild=False)   # `scale` is a grid parameter too (:15): ignored without rebuild
+    assert np.abs(phi_scaled - phi16).max() < 1e-9
+    phi_t, _ = h.compute_distance(hCoef=1.0, tCoef=2.0, rebuild=False)        # tCoef is NOT cached (:43): the answer changes, the grid does not
+    assert h.grid_info()["n"] == 16 and np.abs(phi_t - phi16).max() > 1e-4
+    phi32, st = h.compute_distance(hCoef=1.0, rebuild=True)            # rebuild=true: new grid
+    assert h.grid_info()["n"] == 32 and st.n == 32
+    assert np.abs(phi32 - load_golden("bunny_small_n32")["phi"]).max() < 1e-7
+    # point overload: rebuilds on every call whatever the flag says
+    d = load_golden("bunny_pc_n16")
+    hp = HostSolver(os.path.join(ROOT, "data", "bunny.pc"), tol=1e-10)
+    hp.set_point_areas(d["area"], float(d["h_in"]))
+    p16, _ = hp.compute_distance(hCoef=0.0, rebuild=False)
+    assert np.abs(p16 - d["phi"]).max() < 1e-7
+    p32, st = hp.compute_distance(hCoef=1.0, rebuild=False)
+    assert hp.grid_info()["n"] == 32 and st.n == 32 and p32.size == 32 ** 3
+
+
+@pytest.mark.parametrize("mode", sorted(MODES))
+@pytest.mark.parametrize("kind", ["single-source", "one-cell"])
+def test_degenerate_constraint_sets_do_not_break_down(shm, oracle_c, kind, mode):
+    """m == 1 (one source, or every source in the same grid cell): the projected residual of the multiplier system is exactly zero, so the
+    CG scalars hit 0/0 unless guarded; the solve must return the oracle's phi, not SHM_ERR_BREAKDOWN."""
+    rng = np.random.default_rng(5)
+    n = 16
+    S = 1 if kind == "single-source" else 6
+    bbox_min = np.array([-1.0, -1.0, -1.0])
+    cell = 2.0 / (n - 1)
+    base = bbox_min + cell * (np.array([7, 8, 6]) + 0.1)
+    pos = base + 0.8 * cell * rng.random((S, 3))                      # all inside cell (7, 8, 6)
+    nrm = np.array([0.3, -0.5, 0.8]) + 0.1 * rng.standard_normal((S, 3))
+    nrm /= np.linalg.norm(nrm, axis=1)[:, None]
+    area = rng.uniform(0.5, 1.0, S)
+    wn = nrm * area[:, None]
+    lam = 3.0
+    g = shm.GridSolver()
+    g.set_problem(pos, wn, area, lam, n, bbox_min, cell)
+    st = g.solve(tol=1e-10, **MODES[mode])
+    assert st.m == 1
+    phi, _ = g.get_phi()
+    ref = np.zeros(n ** 3)
+    sto = np.zeros(5)
+    rc = oracle_c.shmo_compute_distance(n, c_(bbox_min), cell, S, c_(pos).reshape(-1), c_(wn).reshape(-1), c_(area), lam, 1, 0, 1e-13, 100000, ref, sto)
+    assert rc == 0
+    assert np.isfinite(phi).all()
+    assert np.abs(phi - ref).max() < 1e-7, (kind, mode, st.iters)
+
+
 def test_errors_are_reported(shm):
     d = load_golden("bunny_small_n16")
     s = shm.GridSolver()
@@ -382,6 +447,126 @@ def test_fp32_conv_exponent_offset_prevents_underflow(shm, coarse):
     # directions agree wherever fp64 itself is well conditioned (away from the medial axis the agreement is ~1e-4)
     dots = (Y[shm.SHM_F64][ok] * Y[shm.SHM_F32][ok]).sum(axis=1)
     assert np.median(1 - dots) < 1e-6 and np.quantile(1 - dots, 0.99) < 1e-3
+
+
+# ---- BASELINE.json configs[2] (rocker.obj, 512^3, fp32) and configs[4] (SprayBottle, 1024^3, fp32; the .obj is missing upstream, the
+# ---- .pc of the same model stands in): the fp32 path against the fp64 C oracle at sizes the oracle finishes in seconds, against an
+# ---- fp64 GPU run at intermediate sizes, and through size-independent properties at the full sizes.  The north star gates fp64 only
+# ---- ("fp32 configs: report only"); the bounds asserted here are what the fp32 path measurably holds, printed per test.
+FP32_CASES = {"rocker.obj": True, "SprayBottle.pc": False}     # file -> divYt scrub (mesh overload only, :70-74)
+
+
+def _preprocess(fname, hCoef):
+    import os
+    from conftest import ROOT
+    from signed_heat_3d_amd.host_abi import HostSolver
+    return HostSolver(os.path.join(ROOT, "data", fname)).preprocess(hCoef=hCoef)
+
+
+def _gpu_phi(shm, pre, precision, scrub, **kw):
+    s = shm.GridSolver(precision=precision)
+    s.set_problem(pre["pos"], pre["wnormal"], pre["area"], pre["lam"], pre["n"], pre["bbox_min"], pre["cell"])
+    st = s.solve(scrub=scrub, allow_noconv=True, **kw)
+    phi, _ = s.get_phi()
+    return s, st, phi
+
+
+@pytest.mark.parametrize("fname", sorted(FP32_CASES))
+def test_fp32_configs_match_c_oracle_64(shm, oracle_c, fname):
+    """rocker.obj / SprayBottle.pc at 64^3: fp32 HIP path (and the fp64 one beside it) against the fp64 C oracle on the same inputs."""
+    import os
+    scrub = FP32_CASES[fname]
+    pre = _preprocess(fname, 2.0)
+    n, S = pre["n"], pre["S"]
+    assert n == 64
+    ref = np.zeros(n ** 3)
+    st = np.zeros(5)
+    oracle_c.shmo_set_threads(min(64, os.cpu_count() or 1))
+    rc = oracle_c.shmo_compute_distance(n, c_(pre["bbox_min"]), pre["cell"], S, c_(pre["pos"]).reshape(-1), c_(pre["wnormal"]).reshape(-1),
+                                        c_(pre["area"]), pre["lam"], int(scrub), 0, 1e-12, 100000, ref, st)
+    oracle_c.shmo_set_threads(min(8, os.cpu_count() or 1))
+    assert rc == 0 and np.isfinite(ref).all()
+    _, st64, phi64 = _gpu_phi(shm, pre, shm.SHM_F64, scrub, tol=1e-10)
+    _, st32, phi32 = _gpu_phi(shm, pre, shm.SHM_F32, scrub)
+    span = np.abs(ref).max()
+    e64, e32 = np.abs(phi64 - ref).max(), np.abs(phi32 - ref).max()
+    print("\n%s 64^3: L_inf(fp64 - oracle) = %.3e, L_inf(fp32 - oracle) = %.3e (max|phi| = %.3f, fp32 iters %d)" % (fname, e64, e32, span, st32.iters))
+    assert np.isfinite(phi32).all()
+    assert e64 < 1e-7 * max(1.0, span)
+    assert e32 < 2e-4 * span, (e32, span)
+
+
+@pytest.mark.parametrize("fname,hCoef", [("rocker.obj", 3.0), ("SprayBottle.pc", 3.0), ("SprayBottle.pc", 4.0)])
+def test_fp32_configs_track_fp64_gpu(shm, fname, hCoef):
+    """128^3 / 256^3 (the C oracle needs minutes there): fp32 against the fp64 HIP path, itself held to the oracle at <= 64^3 above."""
+    scrub = FP32_CASES[fname]
+    pre = _preprocess(fname, hCoef)
+    _, st64, phi64 = _gpu_phi(shm, pre, shm.SHM_F64, scrub)
+    _, st32, phi32 = _gpu_phi(shm, pre, shm.SHM_F32, scrub)
+    span = np.abs(phi64).max()
+    e = np.abs(phi32 - phi64).max()
+    print("\n%s %d^3: L_inf(fp32 - fp64) = %.3e (max|phi| = %.3f; iters fp64 %d, fp32 %d)" % (fname, pre["n"], e, span, st64.iters, st32.iters))
+    assert np.isfinite(phi32).all() and np.isfinite(phi64).all()
+    assert e < 2e-4 * span, (e, span)
+
+
+def _fullsize_fp32_properties(shm, pre, scrub, with_fp64):
+    """Size-independent checks of an fp32 solve: finite everywhere incl. the bbox corners (SURVEY trap #4: lambda*d ~ 114-172 on rocker
+    underflows a plain fp32 exp), KKT stationarity away from the constraint stencils (independent laplacian_kernel), equal rows of
+    A phi, zero area-weighted source mean; optionally L_inf against an fp64 run of the same configuration."""
+    n = pre["n"]
+    s, st, phi = _gpu_phi(shm, pre, shm.SHM_F32, scrub)
+    assert np.isfinite(phi).all()
+    for corner in (0, n - 1, n * (n - 1), n * n * (n - 1), n ** 3 - 1):
+        assert np.isfinite(phi[corner]) and phi[corner] > 0          # far outside the surface: positive distance
+    s.run_conv()
+    s.run_divergence(scrub)
+    b = s.get_field(s.FIELD_DIV)
+    assert np.isfinite(b).all()
+    g = s.apply_laplacian(phi) + b
+    nodes, coeffs = s.get_constraints()
+    assert nodes.shape[0] == st.m
+    touched = np.zeros(phi.size, dtype=bool)
+    touched[nodes.ravel()] = True
+    scale = np.abs(b).max()
+    res = np.abs(g[~touched]).max() / scale
+    rows = (coeffs * phi[nodes]).sum(axis=1)
+    spread = rows.max() - rows.min()
+    span = np.abs(phi).max()
+    del g, b, touched
+    out = dict(n=n, m=int(st.m), iters=int(st.iters), kkt_residual_rel=float(res), row_spread=float(spread), max_abs_phi=float(span))
+    # fp32: phi carries ~6e-8 * span of rounding per entry, the stencil amplifies it by 12 / h^2
+    h = pre["cell"]
+    assert res < 5e-3 + 12.0 * 6e-8 * span / (h * h) / scale, out
+    assert spread < 2e-4 * span, out
+    if with_fp64:
+        _, st64, phi64 = _gpu_phi(shm, pre, shm.SHM_F64, scrub)
+        e = float(np.abs(phi - phi64).max())
+        out.update(linf_fp32_vs_fp64=e, iters_fp64=int(st64.iters))
+        assert e < 2e-4 * span, out
+    print("\nfull-size fp32 properties:", out)
+    return out
+
+
+def test_config2_rocker_512_fp32_full_size(shm):
+    """BASELINE.json configs[2] at its full size: rocker.obj, 512^3, fp32 (S = 13 819 faces, m = 12 612)."""
+    pre = _preprocess("rocker.obj", 5.0)
+    assert pre["n"] == 512 and pre["S"] == 13819
+    out = _fullsize_fp32_properties(shm, pre, True, with_fp64=True)
+    assert out["m"] == 12612
+
+
+@pytest.mark.skipif(bool(__import__("os").environ.get("SHM_SKIP_1024")), reason="SHM_SKIP_1024 set")
+def test_config4_spraybottle_1024_fp32_full_size(shm):
+    """BASELINE.json configs[4] on one GPU: SprayBottle.pc, 1024^3, fp32 (S = 52 290 points, m = 48 893; ~60 GB of HBM, ~10 s solve).
+    No fp64 run beside it (another 110 GB and ~25 s of Step 1); the fp32-vs-fp64 error of this input is asserted at 128^3 / 256^3."""
+    import psutil
+    if psutil.virtual_memory().available < 80 * 2 ** 30:
+        pytest.skip("needs ~50 GB of host memory for the float64 copies of phi, b and L phi")
+    pre = _preprocess("SprayBottle.pc", 6.0)
+    assert pre["n"] == 1024 and pre["S"] == 52290
+    out = _fullsize_fp32_properties(shm, pre, False, with_fp64=False)
+    assert out["m"] == 48893
 
 
 # ---- fastIntegration (--f): integrateGreedily, signed_heat_grid_solver.cpp:224-275 ---------------------------------------
@@ -614,6 +799,39 @@ def test_multiprocess_ranks_on_one_gpu(shm, tmp_path, world, mode):
         parts.append(np.load(tmp_path / ("phi_%d.npy" % r)))
         assert abs(shift - float(d["shift"])) < 1e-7
     assert covered == 32
+    assert np.abs(np.concatenate(parts) - d["phi"]).max() < (1e-9 if mode == "fast" else 1e-7)
+
+
+def _device_count():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.parametrize("mode", ["dual", "dual-slabs", "primal-plain", "primal-dct", "fast"])
+def test_multiprocess_ranks_real_rccl(shm, tmp_path, mode):
+    """Two ranks on two GPUs through the REAL librccl (no test double): the grouped send/recv of the halo planes and of the gather of
+    D^T Y, the all-to-alls of the distributed DCT, the all-reduces and the slab-chained fast integration.  Skipped on boxes with one GPU
+    (the development pool has only those: until this test has run somewhere, the RCCL transport itself is verified only through the
+    prototypes of <rccl/rccl.h> at build time and through a one-rank communicator)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    if _device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    world = 2
+    case = "bunny_small_fast_n32" if mode == "fast" else "bunny_small_n32"
+    env = dict(os.environ, SHM_WORKER_DEVICE_PER_RANK="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SHM_RCCL_LIB", None)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multiproc_worker.py"), str(r), str(world), "file", case, mode, str(tmp_path)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    d = load_golden(case)
+    parts = [np.load(tmp_path / ("phi_%d.npy" % r)) for r in range(world)]
     assert np.abs(np.concatenate(parts) - d["phi"]).max() < (1e-9 if mode == "fast" else 1e-7)
 
 
