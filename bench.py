@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--workload", default="bunny_small_256_f64", choices=sorted(WORKLOADS))
     ap.add_argument("--tol", type=float, default=0.0, help="projected-CG relative residual tolerance (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-iters", type=int, default=0, help="cap the CG iterations (0 = library default 20 n); a capped run reports kernel rates, not a converged solve")
     ap.add_argument("--precond", default="auto", choices=["auto", "none", "dct"])
     ap.add_argument("--solver", default="auto", choices=["auto", "primal", "dual", "dual_slabs"])
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -172,12 +173,12 @@ def main():
 
     st = None
     for _ in range(args.warmup):
-        st = solver.solve(tol=args.tol, scrub=scrub, precond=args.precond, solver=args.solver)
+        st = solver.solve(tol=args.tol, scrub=scrub, precond=args.precond, solver=args.solver, max_iters=args.max_iters, allow_noconv=args.max_iters > 0)
     barrier()
     t0 = time.perf_counter()
     stats = []
     for _ in range(args.steps):
-        st = solver.solve(tol=args.tol, scrub=scrub, precond=args.precond, solver=args.solver)
+        st = solver.solve(tol=args.tol, scrub=scrub, precond=args.precond, solver=args.solver, max_iters=args.max_iters, allow_noconv=args.max_iters > 0)
         stats.append(st.as_dict())
     barrier()
     elapsed = time.perf_counter() - t0
@@ -196,11 +197,19 @@ def main():
         gathered = world > 1 and int(avg["solver"]) == 2   # every rank solved the whole grid after gathering D^T Y
         TP = T  # the preconditioner sweeps run in the solve precision
         # name: (algorithmic bytes per launch, avg ms per launch, launches per CG iteration)
-        kernels = {
-            "stencil_dot_kernel": (2 * n_local * T, avg["ms_stencil_avg"], 1),
-            "update_xr_kernel": (6 * n_local * T, avg["ms_update_xr_avg"], 1),
-            "update_p_kernel": (3 * n_local * T, avg["ms_update_p_avg"], 1),
-        }
+        if int(avg.get("cg_form", 0)) == 1:
+            # fused sweeps (shm_cg_fused.hip.h): q = Kp is never stored, x is updated every other iteration: 3 + 3 + 4/2 = 8NT per iteration
+            kernels = {
+                "cg_fused_kernel<DIR>": (3 * n_local * T, avg["ms_stencil_avg"], 1),      # reads z, p; writes p'; partial p'.Kp'
+                "cg_fused_kernel<RES>": (3 * n_local * T, avg["ms_update_xr_avg"], 1),    # reads r, p'; writes r; partial ||r||^2
+                "cg_x_update2_kernel": (4 * n_local * T, avg["ms_update_p_avg"], 0.5),    # reads x, p_a, p_b; writes x; every other iteration
+            }
+        else:
+            kernels = {
+                "stencil_dot_kernel": (2 * n_local * T, avg["ms_stencil_avg"], 1),
+                "update_xr_kernel": (6 * n_local * T, avg["ms_update_xr_avg"], 1),
+                "update_p_kernel": (3 * n_local * T, avg["ms_update_p_avg"], 1),
+            }
         if has_pre:  # five DCT sweeps (x-fwd, y-fwd, z-fused, y-inv, x-inv[+dot]): 3T + 8TP bytes per node (2T + 8TP without the dot)
             kernels["dct_lines_kernel"] = (n_local * ((2 if is_dual else 3) * T + 8 * TP) / 5.0, avg["ms_precond_avg"] / 5.0, 5)
         if is_dual:

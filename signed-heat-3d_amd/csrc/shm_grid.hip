@@ -29,6 +29,7 @@
 
 #include "../../include/shm_grid.h"
 #include "shm_kernels.hip.h"
+#include "shm_cg_fused.hip.h"
 #include "shm_dct.hip.h"
 
 namespace shm {
@@ -998,6 +999,69 @@ struct Solver final : SolverBase {
         hipLaunchKernelGGL((norm2_kernel<T, VEC>), dim3(grid), dim3(kBlock), 0, stream, sl.nown / VEC, sl.plane, v, sl.partials.p);
     }
 
+    // ------------------------------------------------------------------------------------------
+    // Fused CG sweeps (shm_cg_fused.hip.h): a workgroup of 8 waves owns whole x rows, so the row must fit WX <= 8 waves of VEC-wide lanes.
+    struct FusedCfg {
+        int wx = 0, ry = 8, zc = 16, yblocks = 0, zchunks = 0;
+    };
+    bool fused_available() const {
+        static const bool off = getenv("SHM_CG_CLASSIC") != nullptr;  // A/B knob: the round-1 four-kernel loop
+        return !off && (n + vec - 1) / vec <= 8 * 64;
+    }
+    FusedCfg fused_cfg(const Slab<T>& sl) const {
+        FusedCfg c;
+        const int lanes = (n + vec - 1) / vec;
+        c.wx = 1;
+        while (c.wx * 64 < lanes) c.wx <<= 1;
+        const int wy = 8 / c.wx;
+        static const int ry_env = getenv("SHM_FUSED_RY") ? atoi(getenv("SHM_FUSED_RY")) : 0;
+        static const int zc_env = getenv("SHM_FUSED_ZC") ? atoi(getenv("SHM_FUSED_ZC")) : 0;
+        // rows per workgroup wy * ry: 8 rows per lane unless that leaves too few workgroups along y to fill the chip with deep z chunks
+        c.ry = 4;  // 8 rows per lane would halve the y halo but spills (3 planes + the prefetched raw planes exceed 256 VGPRs): measured slower
+        if (ry_env == 4 || (ry_env == 8 && vec != 1)) c.ry = ry_env;
+        c.yblocks = (n + wy * c.ry - 1) / (wy * c.ry);
+        const int want = std::max(1, (2 * num_cus + c.yblocks - 1) / c.yblocks);  // z chunks for ~2 workgroups per CU
+        c.zc = std::min(64, std::max(8, sl.nzl / want));
+        if (zc_env > 0) c.zc = zc_env;
+        c.zc = std::max(1, std::min(c.zc, sl.nzl));
+        c.zchunks = (sl.nzl + c.zc - 1) / c.zc;
+        return c;
+    }
+    template <int MODE, int VEC, int RY, int WX>
+    void launch_fused_k(Slab<T>& sl, const FusedCfg& c, int slot_old, int slot_new, int init, int use_uw, int alpha_slot, const T* zsrc, const T* pin, T* pout) {
+        FusedParams F;
+        F.n = n; F.nzl = sl.nzl; F.k0 = sl.k0; F.zc = c.zc; F.yblocks = c.yblocks; F.inv_h2 = sl.gp.inv_h2;
+        hipLaunchKernelGGL((cg_fused_kernel<T, VEC, RY, WX, 8 / WX, MODE>), dim3((unsigned)(c.yblocks * c.zchunks)), dim3(512), 0, stream, F, sl.sc.p, slot_old,
+                           slot_new, sl.red.p, sl.pq.p, init, use_uw, alpha_slot, zsrc, pin, pout, sl.r.p, sl.partials.p);
+    }
+    template <int MODE, int VEC, int RY>
+    void launch_fused_w(Slab<T>& sl, const FusedCfg& c, int slot_old, int slot_new, int init, int use_uw, int alpha_slot, const T* zsrc, const T* pin, T* pout) {
+        switch (c.wx) {
+            case 1: launch_fused_k<MODE, VEC, RY, 1>(sl, c, slot_old, slot_new, init, use_uw, alpha_slot, zsrc, pin, pout); break;
+            case 2: launch_fused_k<MODE, VEC, RY, 2>(sl, c, slot_old, slot_new, init, use_uw, alpha_slot, zsrc, pin, pout); break;
+            case 4: launch_fused_k<MODE, VEC, RY, 4>(sl, c, slot_old, slot_new, init, use_uw, alpha_slot, zsrc, pin, pout); break;
+            default: launch_fused_k<MODE, VEC, RY, 8>(sl, c, slot_old, slot_new, init, use_uw, alpha_slot, zsrc, pin, pout); break;
+        }
+    }
+    // returns the number of block partials the sweep leaves in sl.partials
+    template <int MODE>
+    int launch_fused(Slab<T>& sl, int slot_old, int slot_new, int init, int use_uw, int alpha_slot, const T* zsrc, const T* pin, T* pout) {
+        const FusedCfg c = fused_cfg(sl);
+        if (vec == 1) launch_fused_w<MODE, 1, 4>(sl, c, slot_old, slot_new, init, use_uw, alpha_slot, zsrc, pin, pout);
+        else if (c.ry == 4) launch_fused_w<MODE, vec_width<T>(), 4>(sl, c, slot_old, slot_new, init, use_uw, alpha_slot, zsrc, pin, pout);
+        else launch_fused_w<MODE, vec_width<T>(), 8>(sl, c, slot_old, slot_new, init, use_uw, alpha_slot, zsrc, pin, pout);
+        return c.yblocks * c.zchunks;
+    }
+    void launch_x_update2(Slab<T>& sl, int use_a, int use_b) {
+        const size_t nvec = sl.nown / vec;
+        const unsigned g = (unsigned)((nvec + (size_t)kXuTiles * kBlock - 1) / ((size_t)kXuTiles * kBlock));
+        if (vec == 1)
+            hipLaunchKernelGGL((cg_x_update2_kernel<T, 1>), dim3(g), dim3(kBlock), 0, stream, nvec, sl.plane, sl.sc.p, use_a, use_b, sl.p.p, sl.q.p, sl.x.p);
+        else
+            hipLaunchKernelGGL((cg_x_update2_kernel<T, vec_width<T>()>), dim3(g), dim3(kBlock), 0, stream, nvec, sl.plane, sl.sc.p, use_a, use_b, sl.p.p, sl.q.p,
+                               sl.x.p);
+    }
+
     int stream_grid(const Slab<T>& sl) const { return grid_for(sl.nown / vec, 2048); }
 
     // v <- P v on all slabs (v = r, or z when on_z); leaves red[0] = sum of the first nparts[s] `partials`,
@@ -1569,6 +1633,148 @@ struct Solver final : SolverBase {
     }
 
     // ------------------------------------------------------------------------------------------
+    // Projected (preconditioned) CG with the fused sweeps of shm_cg_fused.hip.h -- same recurrence as the classic loop in solve():
+    //      x=0; r=P b; z=P M^-1 r; p0=-z;
+    //      loop k { a_k = rho_k / (p_k . K p_k);  r = P(r + a_k K p_k);  z = P M^-1 r;  rho_{k+1} = r.z;  p_{k+1} = -z + (rho_{k+1}/rho_k) p_k }
+    //      x = sum_k a_k p_k, accumulated two directions at a time (p_k lives in buffer k & 1: sl.p / sl.q)
+    // N-sized launches per iteration: RES (r += a K p, ||r||^2), DIR (p' = -z + b p, p'.K p'), and x_update2 on odd k: 8 N T bytes.
+    void solve_primal_fused(const shm_opts& o, shm_stats* st, bool pre, Event& e_start, Event& e_conv, Event& e_div, Event& e_setup, Event& e_s2a,
+                            Event& e_s2b, std::chrono::steady_clock::time_point wall0) {
+        Event e_pcg, e_end;
+        std::vector<int> nparts(slabs.size()), zparts(slabs.size(), 0), kparts(slabs.size(), 0);
+        auto dirbuf = [&](Slab<T>& sl, int k) { return (k & 1) ? sl.q.p : sl.p.p; };
+        const int zsel = pre ? ARR_Z : ARR_R;
+        for (size_t s = 0; s < slabs.size(); s++) {
+            Slab<T>& sl = slabs[s];
+            HIPCHK(hipMemsetAsync(sl.x.p, 0, sl.ntot * sizeof(T), stream));
+            nparts[s] = stream_grid(sl);
+            if (vec == 1) launch_norm2<1>(sl, sl.r.p, nparts[s]);
+            else launch_norm2<vec_width<T>()>(sl, sl.r.p, nparts[s]);
+        }
+        launch_projection(nparts, false, 2);
+        if (pre) {
+            const int np = launch_precond(true);
+            for (auto& v : zparts) v = np;
+            launch_projection(zparts, true, 0);
+        }
+        auto run_dir = [&](int k, int slot_old, int slot_new, int init) {  // p_{k+1} (init: p_0) from z and p_k; leaves p'.Kp' in pq
+            if (total_slabs > 1) halo_exchange(zsel);
+            for (size_t s = 0; s < slabs.size(); s++) {
+                Slab<T>& sl = slabs[s];
+                const int out = init ? 0 : k + 1;
+                kparts[s] = launch_fused<CGF_DIR>(sl, slot_old, slot_new, init, pre ? 0 : 1, 0, arr(sl, zsel), dirbuf(sl, k), dirbuf(sl, out));
+            }
+        };
+        auto finalize_pq = [&]() {
+            for (size_t s = 0; s < slabs.size(); s++)
+                hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, stream, slabs[s].partials.p, kparts[s], slabs[s].pq.p);
+            allreduce(1, 1);
+        };
+        run_dir(0, SC_RHO_A, SC_RHO_A, 1);
+        finalize_pq();
+        HIPCHK(hipGetLastError());
+
+        const int kMaxSamples = 32, kEvPer = 8;
+        std::vector<std::unique_ptr<Event>> ev;
+        if (st) for (int a = 0; a < kEvPer * kMaxSamples; a++) ev.emplace_back(new Event());
+        int nsamples = 0;
+        const int sample_stride = pre ? 2 : 8;
+
+        int it = 0;
+        double rr0 = 0., rr = 0.;
+        bool converged = false, breakdown = false;
+        while (it < o.max_iters && !converged && !breakdown) {
+            const int batch_end = std::min(o.max_iters, it + o.check_every);
+            for (; it < batch_end; it++) {
+                const int slot_old = (it & 1) ? SC_RHO_B : SC_RHO_A, slot_new = (it & 1) ? SC_RHO_A : SC_RHO_B;
+                const bool sample = st && nsamples < kMaxSamples && (it % sample_stride == 1);
+                auto mark = [&](int k) {
+                    if (sample) ev[kEvPer * nsamples + k]->record(stream);
+                };
+                mark(0);
+                for (size_t s = 0; s < slabs.size(); s++)
+                    nparts[s] = launch_fused<CGF_RES>(slabs[s], slot_old, slot_new, 0, 0, (it & 1) ? SC_ALPHA_B : SC_ALPHA_A, (const T*)nullptr,
+                                                      dirbuf(slabs[s], it), (T*)nullptr);
+                mark(1);
+                launch_projection(nparts, false, 1);
+                mark(2);
+                if (pre) launch_precond(true);
+                mark(3);
+                if (pre) launch_projection(zparts, true, 0);
+                mark(4);
+                if (it & 1)
+                    for (Slab<T>& sl : slabs) launch_x_update2(sl, 1, 1);
+                mark(5);
+                run_dir(it, slot_old, slot_new, 0);
+                mark(6);
+                finalize_pq();
+                mark(7);
+                if (sample) nsamples++;
+            }
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(h_pinned, slabs[0].sc.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            rr0 = h_pinned[SC_RR0];
+            rr = h_pinned[SC_RR];
+            const double rho = h_pinned[(it & 1) ? SC_RHO_B : SC_RHO_A];
+            if (!std::isfinite(rr) || !std::isfinite(rr0) || !std::isfinite(rho)) breakdown = true;
+            else if (rr <= o.tol * o.tol * rr0) converged = true;
+            log("[shm] it=%d rel_res=%.3e", it, rr0 > 0. ? std::sqrt(std::fabs(rr / rr0)) : 0.);
+        }
+        if (it & 1)  // the last direction has an even index: its step is still missing from x
+            for (Slab<T>& sl : slabs) launch_x_update2(sl, 1, 0);
+        e_pcg.record(stream);
+        launch_shift_and_phi();
+        e_end.record(stream);
+        HIPCHK(hipMemcpyAsync(h_pinned, slabs[0].sc.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        have_phi = true;
+        have_div = false;  // q (a direction buffer, then phi) and r were reused
+        const auto wall1 = std::chrono::steady_clock::now();
+        if (st) {
+            memset(st, 0, sizeof *st);
+            st->n = n;
+            st->m = m;
+            st->S = S;
+            st->iters = it;
+            st->rel_residual = rr0 > 0. ? std::sqrt(std::fabs(rr / rr0)) : 0.;
+            st->shift = h_pinned[SC_SHIFT];
+            st->ms_conv = elapsed(e_start, e_conv);
+            st->ms_div = elapsed(e_conv, e_div);
+            HIPCHK(hipEventSynchronize(e_s2b.e));
+            st->ms_setup = elapsed(e_s2a, e_s2b);
+            st->ms_wait_setup = elapsed(e_div, e_setup);
+            st->ms_pcg = elapsed(e_setup, e_pcg);
+            st->ms_shift = elapsed(e_pcg, e_end);
+            st->ms_total = std::chrono::duration<double, std::milli>(wall1 - wall0).count();
+            double acc[5] = {0, 0, 0, 0, 0};
+            for (int a = 0; a < nsamples; a++) {
+                auto el = [&](int i, int j) { return (double)elapsed(*ev[kEvPer * a + i], *ev[kEvPer * a + j]); };
+                acc[0] += el(5, 6);            // DIR sweep (incl. the halo exchange of z with several slabs)
+                acc[1] += el(0, 1);            // RES sweep
+                acc[2] += el(1, 2) + el(3, 4); // projections
+                acc[3] += el(4, 5);            // x_update2 (sampled iterations are odd: one launch each)
+                acc[4] += el(2, 3);            // DCT
+            }
+            const double inv = nsamples ? 1. / nsamples : 0.;
+            st->ms_stencil_avg = acc[0] * inv;
+            st->ms_update_xr_avg = acc[1] * inv;
+            st->ms_project_avg = acc[2] * inv;
+            st->ms_update_p_avg = acc[3] * inv;
+            st->ms_precond_avg = pre ? acc[4] * inv : 0.;
+            st->kernel_samples = nsamples;
+            st->preconditioner = pre ? SHM_PRECOND_DCT : SHM_PRECOND_NONE;
+            st->solver = SHM_SOLVER_PRIMAL;
+            st->cg_form = 1;
+            // 3NT (DIR) + 3NT (RES) + 4NT every other iteration (x_update2); the five DCT sweeps move 3T + 8TP more
+            st->bytes_per_iter = 8.0 * (double)N * sizeof(T) + (pre ? (double)N * (3.0 * sizeof(T) + 8.0 * sizeof(TP)) : 0.);
+        }
+        if (breakdown) throw Error(SHM_ERR_BREAKDOWN, fmt("projected CG broke down at iteration %d (rr=%g, rr0=%g)", it, rr, rr0));
+        if (!converged) throw Error(SHM_ERR_NOCONV, fmt("projected CG: max_iters=%d reached, rel. residual %.3e > tol %.1e", o.max_iters,
+                                                          rr0 > 0. ? std::sqrt(std::fabs(rr / rr0)) : 0., o.tol));
+    }
+
+    // ------------------------------------------------------------------------------------------
     void solve(const shm_opts& o_in, shm_stats* st) override {
         need_problem();
         HIPCHK(hipSetDevice(cfg.device));
@@ -1620,7 +1826,11 @@ struct Solver final : SolverBase {
             return;
         }
 
-        // ---- projected (preconditioned) CG, SURVEY 7.3:
+        if (fused_available()) {
+            solve_primal_fused(o, st, pre, e_start, e_conv, e_div, e_setup, e_s2a, e_s2b, wall0);
+            return;
+        }
+        // ---- projected (preconditioned) CG, SURVEY 7.3 (the classic four-kernel loop: grids wider than 8 waves of vector lanes, or SHM_CG_CLASSIC):
         //      x=0; r=P b; z=P M^-1 r; p=-z; loop { q=Kp; a=rho/p.q; x+=a p; r=P(r+a q); z=P M^-1 r; rho'=r.z; p=-z+(rho'/rho) p }
         std::vector<int> nparts(slabs.size()), zparts(slabs.size(), 0);
         for (size_t s = 0; s < slabs.size(); s++) {

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Round-2 probe: fused stencil-CG sweeps (512^3, capped iterations): A/B of builds / knobs.
+set -u
+cd "$(dirname "$0")/.."
+O=gpurun_out/cg_probe; mkdir -p $O
+run() { # name, env...
+  local name=$1; shift
+  env "$@" python bench.py --no-cpu-baseline --steps 1 --warmup 1 --solver primal --precond none --max-iters 200 --workload ${WL} > $O/${WL}_$name.json 2> $O/${WL}_$name.err
+  python - $O/${WL}_$name.json $name <<'P'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    k=d["kernels"]; print(sys.argv[2], d["config"]["workload"], "ms/iter %.3f"%d["pcg"]["ms_per_iter"], {a:(round(b["avg_ms_per_launch"],4), round(b["achieved_GBps"] or 0)) for a,b in k.items()}, "proj %.3f"%d["pcg"]["ms_project_avg"])
+except Exception as e: print(sys.argv[2],"FAILED",e)
+P
+}
+for WL in bunny_small_512_f64 rocker_512_f32 bunny_small_256_f64; do
+  run nt X=1
+  run nont SHM_GRID_LIB=$PWD/tools/bin/libshm_grid_nont.so
+  run nt_again X=1
+  run classic SHM_CG_CLASSIC=1
+done 2>&1 | tee $O/summary.txt
