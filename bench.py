@@ -109,6 +109,97 @@ def cpu_baseline(pre, iters_cpu, tol, seconds_budget=25.0, threads=1):
     }
 
 
+def kernel_table(avg, n_local, T, world, gathered):
+    """Per-kernel algorithmic bytes of the decomposition actually launched against the HIP-event launch durations the
+    library sampled.  name -> (algorithmic bytes per launch, avg ms per launch, launches per CG iteration)."""
+    has_pre = int(avg["preconditioner"]) == 2
+    is_dual = int(avg["solver"]) in (2, 3)
+    TP = T  # the preconditioner sweeps run in the solve precision
+    if int(avg.get("cg_form", 0)) == 1:
+        # fused sweeps (shm_cg_fused.hip.h): q = Kp is never stored, x is updated every other iteration: 3 + 3 + 4/2 = 8NT per iteration
+        kernels = {
+            "cg_fused_kernel<DIR>": (3 * n_local * T, avg["ms_stencil_avg"], 1),      # reads z, p; writes p'; partial p'.Kp'
+            "cg_fused_kernel<RES>": (3 * n_local * T, avg["ms_update_xr_avg"], 1),    # reads r, p'; writes r; partial ||r||^2
+            "cg_x_update2_kernel": (4 * n_local * T, avg["ms_update_p_avg"], 0.5),    # reads x, p_a, p_b; writes x; every other iteration
+        }
+    else:
+        kernels = {
+            "stencil_dot_kernel": (2 * n_local * T, avg["ms_stencil_avg"], 1),
+            "update_xr_kernel": (6 * n_local * T, avg["ms_update_xr_avg"], 1),
+            "update_p_kernel": (3 * n_local * T, avg["ms_update_p_avg"], 1),
+        }
+    if has_pre:  # five DCT sweeps (x-fwd, y-fwd, z-fused, y-inv, x-inv[+dot]): 3T + 8TP bytes per node (2T + 8TP without the dot)
+        kernels["dct_lines_kernel"] = (n_local * ((2 if is_dual else 3) * T + 8 * TP) / 5.0, avg["ms_precond_avg"] / 5.0, 5)
+    if is_dual:
+        # the dual solver has no N-sized CG sweeps (its vectors are m-dimensional); on one GPU its five sweeps per iteration are
+        # sparse (active x tiles, active z-planes, masked z I/O) and the library reports the bytes they actually move
+        kernels = {"dct_lines_kernel": (avg["bytes_per_iter"] / (1 if gathered else world) / 5.0, avg["ms_precond_avg"] / 5.0, 5)}
+    kinfo = {k: {"algorithmic_bytes_per_launch": b, "avg_ms_per_launch": ms, "launches_per_iter": cnt,
+                 "achieved_GBps": (b / (ms * 1e-3) / 1e9 if ms > 0 else None),
+                 "frac_of_hbm_peak": (b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None)}
+             for k, (b, ms, cnt) in kernels.items()}
+    return kernels, kinfo
+
+
+def also_legs(shm, HostSolver, device, tol):
+    """Extra N=1 legs so that the driver's line carries the whole BASELINE.json metric ("256^3 & 512^3") and the north star's
+    "stencil-PCG at 512^3" as driver-observed numbers: (1) the 512^3 end-to-end solve (default dual solver), (2) the primal stencil-PCG at
+    512^3 in fp64 and fp32 for a fixed iteration count with per-kernel achieved GB/s, (3) configs[2] (rocker 512^3 fp32) with the L_inf of
+    its fp32 phi against an fp64 run of the same configuration ("fp32 configs: report only")."""
+    out = {}
+    pre = HostSolver(os.path.join(ROOT, "data/bunny_small.obj")).preprocess(hCoef=5.0)
+    n = pre["n"]
+    N = n ** 3
+    for precision, name in ((64, "f64"), (32, "f32")):
+        T = precision // 8
+        s = shm.GridSolver(device=device, precision=precision)
+        s.set_problem(pre["pos"], pre["wnormal"], pre["area"], pre["lam"], n, pre["bbox_min"], pre["cell"])
+        if precision == 64:
+            s.solve(tol=tol)
+            t0 = time.perf_counter()
+            reps = 2
+            sts = [s.solve(tol=tol).as_dict() for _ in range(reps)]
+            dt = (time.perf_counter() - t0) / reps
+            a = {k: float(np.mean([x[k] for x in sts])) for k in sts[0]}
+            _, kinfo = kernel_table(a, N, T, 1, False)
+            out["bunny_small_512_f64_end_to_end"] = {
+                "value": N / dt, "unit": "grid-nodes/s", "ms_per_step": 1e3 * dt, "solver": "dual (library default)", "cg_iters": int(a["iters"]),
+                "phases_ms": {k: a[k] for k in ("ms_conv", "ms_div", "ms_wait_setup", "ms_pcg", "ms_shift", "ms_total")},
+                "ms_per_iter": a["ms_pcg"] / max(1.0, a["iters"]), "kernels": kinfo}
+        iters = 200
+        s.solve(tol=1e-30, solver="primal", precond="none", max_iters=16, allow_noconv=True)
+        st = s.solve(tol=1e-30, solver="primal", precond="none", max_iters=iters, allow_noconv=True).as_dict()
+        _, kinfo = kernel_table(st, N, T, 1, False)
+        per_iter = st["ms_pcg"] / max(1.0, st["iters"])
+        out["stencil_pcg_512_" + name] = {
+            "workload": "bunny_small.obj 512^3, primal projected stencil CG, %d iterations (fixed count: kernel rates, not a converged solve)" % iters,
+            "dtype": name, "iters": int(st["iters"]), "ms_per_iter": per_iter, "algorithmic_bytes_per_iter": st["bytes_per_iter"],
+            "loop_achieved_GBps": st["bytes_per_iter"] / (per_iter * 1e-3) / 1e9, "loop_frac_of_hbm_peak": st["bytes_per_iter"] / (per_iter * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "ms_project_avg": st["ms_project_avg"], "kernels": kinfo,
+            "note": "N-sized launches per iteration: DIR (3NT) + RES (3NT) + x_update2 (4NT every other iteration) = 8NT; the loop figure also contains "
+                    "the m-sized projection (gather, (A A^T)^-1 mat-vec, scatter) and the scalar reductions"}
+        s.close()
+    # configs[2]: rocker.obj 512^3 fp32, and the same configuration in fp64 for the error of the fp32 path
+    pre = HostSolver(os.path.join(ROOT, "data/rocker.obj")).preprocess(hCoef=5.0)
+    n = pre["n"]
+    phis = {}
+    for precision in (32, 64):
+        s = shm.GridSolver(device=device, precision=precision)
+        s.set_problem(pre["pos"], pre["wnormal"], pre["area"], pre["lam"], n, pre["bbox_min"], pre["cell"])
+        s.solve()
+        t0 = time.perf_counter()
+        st = s.solve().as_dict()
+        dt = time.perf_counter() - t0
+        phis[precision] = s.get_phi()[0]
+        if precision == 32:
+            out["rocker_512_f32"] = {"value": n ** 3 / dt, "unit": "grid-nodes/s", "ms_per_step": 1e3 * dt, "cg_iters": int(st["iters"]),
+                                     "constraint_rows": int(st["m"]), "phases_ms": {k: st[k] for k in ("ms_conv", "ms_div", "ms_wait_setup", "ms_pcg", "ms_shift")}}
+        s.close()
+    out["rocker_512_f32"]["linf_fp32_vs_fp64"] = float(np.abs(phis[32] - phis[64]).max())
+    out["rocker_512_f32"]["max_abs_phi"] = float(np.abs(phis[64]).max())
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,6 +208,7 @@ def main():
     ap.add_argument("--workload", default="bunny_small_256_f64", choices=sorted(WORKLOADS))
     ap.add_argument("--tol", type=float, default=0.0, help="projected-CG relative residual tolerance (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra N=1 legs (512^3 end-to-end, 512^3 stencil-PCG fp64/fp32, rocker 512^3 fp32 vs fp64)")
     ap.add_argument("--max-iters", type=int, default=0, help="cap the CG iterations (0 = library default 20 n); a capped run reports kernel rates, not a converged solve")
     ap.add_argument("--precond", default="auto", choices=["auto", "none", "dct"])
     ap.add_argument("--solver", default="auto", choices=["auto", "primal", "dual", "dual_slabs"])
@@ -195,34 +287,14 @@ def main():
         has_pre = int(avg["preconditioner"]) == 2
         is_dual = int(avg["solver"]) in (2, 3)
         gathered = world > 1 and int(avg["solver"]) == 2   # every rank solved the whole grid after gathering D^T Y
-        TP = T  # the preconditioner sweeps run in the solve precision
-        # name: (algorithmic bytes per launch, avg ms per launch, launches per CG iteration)
-        if int(avg.get("cg_form", 0)) == 1:
-            # fused sweeps (shm_cg_fused.hip.h): q = Kp is never stored, x is updated every other iteration: 3 + 3 + 4/2 = 8NT per iteration
-            kernels = {
-                "cg_fused_kernel<DIR>": (3 * n_local * T, avg["ms_stencil_avg"], 1),      # reads z, p; writes p'; partial p'.Kp'
-                "cg_fused_kernel<RES>": (3 * n_local * T, avg["ms_update_xr_avg"], 1),    # reads r, p'; writes r; partial ||r||^2
-                "cg_x_update2_kernel": (4 * n_local * T, avg["ms_update_p_avg"], 0.5),    # reads x, p_a, p_b; writes x; every other iteration
-            }
-        else:
-            kernels = {
-                "stencil_dot_kernel": (2 * n_local * T, avg["ms_stencil_avg"], 1),
-                "update_xr_kernel": (6 * n_local * T, avg["ms_update_xr_avg"], 1),
-                "update_p_kernel": (3 * n_local * T, avg["ms_update_p_avg"], 1),
-            }
-        if has_pre:  # five DCT sweeps (x-fwd, y-fwd, z-fused, y-inv, x-inv[+dot]): 3T + 8TP bytes per node (2T + 8TP without the dot)
-            kernels["dct_lines_kernel"] = (n_local * ((2 if is_dual else 3) * T + 8 * TP) / 5.0, avg["ms_precond_avg"] / 5.0, 5)
-        if is_dual:
-            # the dual solver has no N-sized CG sweeps (its vectors are m-dimensional); on one GPU its five sweeps per iteration are
-            # sparse (active x tiles, active z-planes, masked z I/O) and the library reports the bytes they actually move
-            kernels = {"dct_lines_kernel": (avg["bytes_per_iter"] / (1 if gathered else world) / 5.0, avg["ms_precond_avg"] / 5.0, 5)}
-        kinfo = {k: {"algorithmic_bytes_per_launch": b, "avg_ms_per_launch": ms, "launches_per_iter": cnt,
-                     "achieved_GBps": (b / (ms * 1e-3) / 1e9 if ms > 0 else None)}
-                 for k, (b, ms, cnt) in kernels.items()}
+        kernels, kinfo = kernel_table(avg, n_local, T, world, gathered)
         dominant = max(kernels, key=lambda k: kernels[k][1] * kernels[k][2])
         ach = kinfo[dominant]["achieved_GBps"] or 0.0
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        # HBM bytes per launch from the rocprofv3 PMC passes of THIS command (tools/pmc_traffic.py; FETCH_SIZE doubled per the gfx950
+        # correction), committed per round; PMC counters cannot be collected from inside the run
+        tfile = next((f for f in (os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"), os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))
+                      if os.path.exists(f)), "")
         if os.path.exists(tfile):
             try:
                 traffic = json.load(open(tfile)).get(args.workload, {}).get(dominant)
@@ -275,11 +347,11 @@ def main():
             except Exception:
                 conv_traffic = None
         if avg["ms_conv"] >= avg["ms_pcg"]:
-            # "mfma" = the compute roofline of the contract (the alternative to "hbm"); the kernel's arithmetic is on the vector ALU,
-            # whose fp64 / fp32 peaks equal the dense matrix-core peaks of those types on MI355X (78.6 / 157.3 TFLOP/s)
-            out["roofline"] = {"kernel": "conv_normalize_kernel", "bound": "mfma",
-                               "bound_detail": "compute: vector-ALU issue (no matrix-core shape in the kernel); fp64 and fp32 vector peaks = dense "
-                                               "matrix peaks of the same types on MI355X",
+            # the kernel is bound by vector-ALU instruction issue -- neither of the contract's two labels ("hbm", "mfma") describes it, so it
+            # is called what it is; its peak is the fp64 / fp32 VECTOR peak (78.6 / 157.3 TFLOP/s on MI355X)
+            out["roofline"] = {"kernel": "conv_normalize_kernel", "bound": "valu",
+                               "bound_detail": "compute: vector-ALU issue (no matrix-core shape in the kernel, no MFMA instruction); peak = fp64 / fp32 "
+                                               "vector peak; SQ counters of this kernel: profiles/r02_sq_counters_conv.txt",
                                "achieved": s1["achieved_TFLOPs_nominal_18_per_pair"],
                                "peak": s1["peak_TFLOPs_vector"], "unit": "TFLOP/s", "frac": s1["frac"], "traffic": conv_traffic,
                                # wave-instruction issue: slots per pair (ISA count of the inner loop, weighted by the measured issue cost of
@@ -305,6 +377,12 @@ def main():
                     out["cpu_baseline"]["openmp"] = {"value": allc["value"], "cores": nthr, "seconds_extrapolated": allc["seconds_extrapolated"]}
             except Exception as e:  # the baseline is informational; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "unit": "grid-nodes/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+        if world == 1 and not args.no_also and args.workload == "bunny_small_256_f64":
+            try:
+                solver.close()
+                out["also"] = also_legs(shm, HostSolver, local_rank, args.tol)
+            except Exception as e:  # never lose the headline over an extra leg
+                out["also"] = {"failed": repr(e)}
         print(json.dumps(out))
     if dist.is_initialized():
         dist.barrier()

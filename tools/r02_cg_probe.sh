@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 O=gpurun_out/cg_probe; mkdir -p $O
 run() { # name, env...
   local name=$1; shift
-  env "$@" python bench.py --no-cpu-baseline --steps 1 --warmup 1 --solver primal --precond none --max-iters 200 --workload ${WL} > $O/${WL}_$name.json 2> $O/${WL}_$name.err
+  env "$@" python bench.py --no-cpu-baseline --no-also --steps 1 --warmup 1 --solver primal --precond none --max-iters 200 --workload ${WL} > $O/${WL}_$name.json 2> $O/${WL}_$name.err
   python - $O/${WL}_$name.json $name <<'P'
 import json,sys
 try:
