@@ -206,6 +206,8 @@ struct Slab {
     DevArray<T> S1, S2, S4;  // sparse-sweep buffers of the dual solver's per-iteration solve (single slab)
     DevArray<int> act_x, act_y;  // active tiles of the x sweeps / y sweeps
     DevArray<unsigned> act_z;    // bit k: z-plane k holds touched nodes
+    DevArray<int> act_planes;    // the same as an ascending list (zsolve_sparse_kernel)
+    int n_act_planes = 0;
     int n_act_x = 0, n_act_y = 0;
     int n_touched = 0, n_shift = 0;
     GridParams gp{};
@@ -249,6 +251,7 @@ struct Solver final : SolverBase {
     using TP = T;  // precision of the preconditioner sweeps
     DevArray<Cplx<TP>> d_tw, d_om;
     DevArray<TP> d_lam;
+    DevArray<double> d_lam64;  // the same eigenvalues in double (zsolve_sparse_kernel computes in double whatever T)
     int log2n = 0;
     bool precond_ready = false;
     double* h_pinned = nullptr;
@@ -1105,6 +1108,9 @@ struct Solver final : SolverBase {
         d_tw.upload(tw, stream);
         d_om.upload(om, stream);
         d_lam.upload(lam, stream);
+        std::vector<double> lam64(n);
+        for (int k = 0; k < n; k++) lam64[k] = (2. - 2. * std::cos(pi * k / n)) / (cell * cell);
+        d_lam64.upload(lam64, stream);
         for (Slab<T>& sl : slabs) {
             sl.W1.alloc(sl.nown);
             if (total_slabs > 1) sl.W2.alloc(sl.nown);
@@ -1374,6 +1380,8 @@ struct Solver final : SolverBase {
         std::vector<unsigned> zm((size_t)(n + 31) / 32, 0u);
         for (int z : planes) zm[(size_t)z >> 5] |= 1u << (z & 31);
         sl.act_z.upload(zm, stream2);
+        sl.n_act_planes = (int)planes.size();
+        sl.act_planes.upload(planes, stream2);
         sl.n_act_x = (int)ax.size();
         sl.n_act_y = (int)ay.size();
         sl.act_x.upload(ax, stream2);
@@ -1411,7 +1419,16 @@ struct Solver final : SolverBase {
         // z-fused over all lines, but only the active planes are read (the others hold zeros) and written (the others are not needed): S2 -> W1
         Q.in = plain_addr(0, L, nn, 1, plane);
         Q.out = Q.in;
-        launch_dct<DCT_FUSED, TP, TP, false, false>(Q, tiles_all, sl.S2.p, sl.W1.p, (const TP*)nullptr, nullptr, nullptr, sl.act_z.p);
+        // the recursive z step wins from n = 256 on (256^3: 79 -> 42 us, 512^3: 0.61 -> 0.09 ms per application); below that the transform of
+        // all lines is cheaper than one more launch.  SHM_DUAL_Z_FFT: A/B knob for the transform version
+        static const bool fft_z_env = getenv("SHM_DUAL_Z_FFT") != nullptr;
+        const bool fft_z = fft_z_env || n < 256;
+        if (fft_z) launch_dct<DCT_FUSED, TP, TP, false, false>(Q, tiles_all, sl.S2.p, sl.W1.p, (const TP*)nullptr, nullptr, nullptr, sl.act_z.p);
+        else {
+            hipLaunchKernelGGL((zsolve_sparse_kernel<TP>), dim3((unsigned)((plane + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, n, sl.n_act_planes,
+                               sl.act_planes.p, d_lam64.p, sl.gp.inv_h2, sl.S2.p, sl.W1.p);
+            hipLaunchKernelGGL((zsolve_zero_line_kernel<TP>), dim3(1), dim3(1024), 0, stream, n, sl.n_act_planes, sl.act_planes.p, sl.gp.inv_h2, sl.S2.p, sl.W1.p);
+        }
         // y-inv on the active planes: W1 -> S4
         Q.in = plain_addr(0, L, plane, 1, nn);
         Q.out = Q.in;
