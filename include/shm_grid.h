@@ -113,7 +113,8 @@ typedef struct {
     /* device-side timings (hipEvent, ms) */
     double ms_conv;           /* Steps 1+2 */
     double ms_div;            /* D^T Y (+ scrub) */
-    double ms_setup;          /* constraint rows, A A^T and its blocked Gauss-Jordan inverse; on a 2nd stream, overlapping ms_conv */
+    double ms_setup;          /* constraint rows, A A^T and its inverse (dense blocked Gauss-Jordan, or two-level for large m): host wall time from the
+                               * start of the set-up until the inverse is ready; runs on a 2nd stream beside ms_conv */
     double ms_wait_setup;     /* time the main stream actually waited for the set-up after the divergence */
     double ms_pcg;            /* projected CG loop */
     double ms_shift;          /* shift + phi write-out */

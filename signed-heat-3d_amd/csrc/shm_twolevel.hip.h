@@ -1,0 +1,159 @@
+// Exact two-level (one-step nested dissection) inverse of G = A A^T for large constraint sets.
+//
+// The dense (A A^T)^-1 of the small cases costs m^3 flops to build and m^2 bytes per application (SprayBottle 1024^3, m = 48 893: 7.6 s
+// of Gauss-Jordan and 9.6 GB per mat-vec).  G is sparse with the geometry of the source surface: rows = distinct source cells
+// (signed_heat_grid_solver.cpp:80-98), two rows couple iff their cells share a grid node, i.e. the cells are 26-neighbours.  Cells
+// whose i, j or k is a multiple of the box size b form a separator Sigma (planes one cell thick); the remaining cells fall into
+// b^3-boxes whose interiors cannot touch each other.  With the rows ordered [interiors I_1..I_P | Sigma]:
+//
+//        G = [ D   E ]      D = blockdiag(D_a) (a few hundred rows each),   S = F - sum_a E_a^T D_a^-1 E_a  (|Sigma| ~ 3 m / b rows),
+//            [ E^T F ]
+//        u_I = t - T u_S ,  u_S = S^-1 (w_S - E^T t) ,  t = D^-1 w_I ,  T_a = D_a^-1 E_a .
+//
+// Set-up: batched in-place Gauss-Jordan of the D_a (one workgroup each), T_a and the Schur update per box (boxes of one colour -- box
+// coordinates of equal parity -- touch disjoint separator rows, so eight passes need no atomics and the sums have a fixed order),
+// then the existing blocked Gauss-Jordan on the |Sigma| x |Sigma| Schur complement: (3/b)^3 of the flops of the full inversion.
+// Application (4 launches): per-box mat-vecs with D_a^-1 and E_a^T, the gather of w_S - E^T t, the dense S^-1 mat-vec, per-box
+// mat-vecs with T_a.  Exact up to rounding, so the projector and the dual preconditioner are the same operators as with the dense
+// inverse (same iteration counts); matrices in double for the projector, an fp32 copy for the dual preconditioner.
+#pragma once
+#include "shm_kernels.hip.h"
+
+namespace shm {
+
+struct TlBoxes {               // device views shared by the kernels below (all arrays indexed by box a unless noted)
+    const int* ptrI;           // [P+1] interior slots of box a: [ptrI[a], ptrI[a+1])
+    const int* ptrS;           // [P+1] separator columns of box a (slots of the y buffer)
+    const size_t* offD;        // [P] offset of D_a (s_a x s_a, row-major)
+    const size_t* offE;        // [P] offset of E_a and T_a (s_a x c_a, row-major)
+    const int* rowsI;          // [nI] global row of an interior slot
+    const int* colsS;          // [sum c_a] separator index (0..nS) of a box-local column
+};
+
+// In-place inverse of every SPD block D_a by Gauss-Jordan without pivoting (the Schur complements of an SPD matrix stay SPD).
+// One workgroup per box; the pivot row and column of a step are staged in LDS.  flag != 0: a non-positive pivot was met.
+constexpr int kTlMaxBox = 2048;  // rows of a box the LDS staging can hold
+__global__ __launch_bounds__(kBlock) void tl_block_inverse_kernel(TlBoxes B, const int* __restrict__ box_list, double* __restrict__ D, int* __restrict__ flag) {
+    __shared__ double prow[kTlMaxBox], pcol[kTlMaxBox];
+    const int a = box_list ? box_list[blockIdx.x] : blockIdx.x;
+    const int s = B.ptrI[a + 1] - B.ptrI[a];
+    double* M = D + B.offD[a];
+    for (int k = 0; k < s; k++) {
+        const double piv = M[(size_t)k * s + k];
+        if (!(piv > 0.)) {
+            if (threadIdx.x == 0) *flag = 1;
+            return;
+        }
+        const double ip = 1. / piv;
+        for (int j = threadIdx.x; j < s; j += kBlock) {
+            prow[j] = M[(size_t)k * s + j] * ip;
+            pcol[j] = M[(size_t)j * s + k];
+        }
+        __syncthreads();
+        {
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            for (int i = wave; i < s; i += kBlock / kWave) {   // a wave per row, lanes stride the columns (no integer division, coalesced)
+                const double ci = pcol[i];
+                double* Mi = M + (size_t)i * s;
+                for (int j = lane; j < s; j += kWave) {
+                    double v;
+                    if (i == k) v = (j == k) ? ip : prow[j];
+                    else if (j == k) v = -ci * ip;
+                    else v = Mi[j] - ci * prow[j];
+                    Mi[j] = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// T_a = D_a^-1 E_a, then S[Sigma_a, Sigma_a] -= E_a^T T_a for the boxes of one colour (disjoint separator rows: plain read-modify-write).
+__global__ __launch_bounds__(kBlock) void tl_schur_kernel(TlBoxes B, const int* __restrict__ box_list, const double* __restrict__ Dinv, const double* __restrict__ E,
+                                                          double* __restrict__ Tm, double* __restrict__ S, int ldS) {
+    const int a = box_list[blockIdx.x];
+    const int s = B.ptrI[a + 1] - B.ptrI[a], c = B.ptrS[a + 1] - B.ptrS[a];
+    const double* Di = Dinv + B.offD[a];
+    const double* Ea = E + B.offE[a];
+    double* Ta = Tm + B.offE[a];
+    const int* cols = B.colsS + B.ptrS[a];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < s; i += kBlock / kWave)        // a wave per row of T, lanes = consecutive columns l (coalesced E reads)
+        for (int l = lane; l < c; l += kWave) {
+            double acc = 0.;
+            for (int j = 0; j < s; j++) acc += Di[(size_t)i * s + j] * Ea[(size_t)j * c + l];
+            Ta[(size_t)i * c + l] = acc;
+        }
+    __syncthreads();   // (global writes of this workgroup are visible to it after the barrier)
+    for (int p = wave; p < c; p += kBlock / kWave)
+        for (int q = lane; q < c; q += kWave) {
+            double acc = 0.;
+            for (int i = 0; i < s; i++) acc += Ea[(size_t)i * c + p] * Ta[(size_t)i * c + q];
+            S[(size_t)cols[p] * ldS + cols[q]] -= acc;
+        }
+}
+
+// Application, step 1 (one workgroup per box):  t = D_a^-1 w_I  ->  tbuf ;  y = E_a^T t  ->  ybuf
+template <typename TM>
+__global__ __launch_bounds__(kBlock) void tl_apply_boxes_kernel(TlBoxes B, const TM* __restrict__ Dinv, const TM* __restrict__ E, const double* __restrict__ w,
+                                                                double* __restrict__ tbuf, double* __restrict__ ybuf) {
+    __shared__ double wl[kTlMaxBox], tl[kTlMaxBox];
+    const int a = blockIdx.x;
+    const int i0 = B.ptrI[a], s = B.ptrI[a + 1] - i0, c0 = B.ptrS[a], c = B.ptrS[a + 1] - c0;
+    const TM* Di = Dinv + B.offD[a];
+    const TM* Ea = E + B.offE[a];
+    for (int j = threadIdx.x; j < s; j += kBlock) wl[j] = w[B.rowsI[i0 + j]];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < s; i += kBlock / kWave) {   // a wave per row: lanes stride the columns
+        double acc = 0.;
+        for (int j = lane; j < s; j += kWave) acc += (double)Di[(size_t)i * s + j] * wl[j];
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            tl[i] = acc;
+            tbuf[i0 + i] = acc;
+        }
+    }
+    __syncthreads();
+    for (int l = threadIdx.x; l < c; l += kBlock) {    // a thread per separator column: consecutive threads read consecutive l
+        double acc = 0.;
+        for (int i = 0; i < s; i++) acc += (double)Ea[(size_t)i * c + l] * tl[i];
+        ybuf[c0 + l] = acc;
+    }
+}
+
+// step 2: v_S = w_S - E^T t, gathered per separator row from the boxes that border it (fixed order); the padded tail stays 0
+__global__ __launch_bounds__(kBlock) void tl_gather_sep_kernel(int nS, const int* __restrict__ sepRow, const int* __restrict__ adj_ptr, const int* __restrict__ adj_idx,
+                                                               const double* __restrict__ w, const double* __restrict__ ybuf, double* __restrict__ vS) {
+    const int g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= nS) return;
+    double v = w[sepRow[g]];
+    for (int e = adj_ptr[g]; e < adj_ptr[g + 1]; e++) v -= ybuf[adj_idx[e]];
+    vS[g] = v;
+}
+
+// step 4: u_I = t - T_a u_S (one workgroup per box), u_S copied to its rows (workgroups beyond the boxes)
+template <typename TM>
+__global__ __launch_bounds__(kBlock) void tl_finish_kernel(TlBoxes B, int P, int nS, const int* __restrict__ sepRow, const TM* __restrict__ Tm,
+                                                           const double* __restrict__ tbuf, const double* __restrict__ uS, double* __restrict__ u) {
+    __shared__ double ul[kTlMaxBox];
+    const int a = blockIdx.x;
+    if (a >= P) {
+        const int g = (a - P) * kBlock + threadIdx.x;
+        if (g < nS) u[sepRow[g]] = uS[g];
+        return;
+    }
+    const int i0 = B.ptrI[a], s = B.ptrI[a + 1] - i0, c0 = B.ptrS[a], c = B.ptrS[a + 1] - c0;
+    const TM* Ta = Tm + B.offE[a];
+    for (int l = threadIdx.x; l < c; l += kBlock) ul[l] = uS[B.colsS[c0 + l]];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < s; i += kBlock / kWave) {
+        double acc = 0.;
+        for (int l = lane; l < c; l += kWave) acc += (double)Ta[(size_t)i * c + l] * ul[l];
+        acc = wave_sum(acc);
+        if (lane == 0) u[B.rowsI[i0 + i]] = tbuf[i0 + i] - acc;
+    }
+}
+
+}  // namespace shm

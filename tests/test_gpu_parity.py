@@ -398,6 +398,51 @@ def test_degenerate_constraint_sets_do_not_break_down(shm, oracle_c, kind, mode)
     assert np.abs(phi - ref).max() < 1e-7, (kind, mode, st.iters)
 
 
+@pytest.mark.parametrize("box", [4, 8])
+@pytest.mark.parametrize("case,scrub", [("bunny_small_n32", True), ("bunny_pc_n32", False), ("bunny_small_n64", True)])
+def test_two_level_inverse_of_AAT_matches_lu_golden(case, scrub, box, tmp_path):
+    """The two-level (boxes + separator) inverse of A A^T that replaces the dense one for large constraint sets, forced onto the small
+    fixtures (SHM_TL_MIN_M=32, boxes of 4^3 / 8^3 cells): it is exact, so the projector (primal solvers) and the dual preconditioner are the
+    same operators -- same LU-golden phi, same iteration counts as the dense path -- and A P v = 0 to rounding."""
+    import os
+    import subprocess
+    import sys
+    from conftest import GOLDEN, ROOT
+    if not os.path.exists(os.path.join(GOLDEN, case + ".npz")):
+        pytest.skip("fixture not generated")
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import shm_import
+shm = shm_import.load()
+d = np.load(%r)
+out = {}
+for mode, kw in (("dual", dict(solver="dual")), ("primal-dct", dict(solver="primal", precond="dct")), ("primal-plain", dict(solver="primal", precond="none"))):
+    s = shm.GridSolver()
+    s.set_problem(d["pos"], d["wnormal"], d["area"], float(d["lam"]), int(d["n"]), d["bbox_min"], float(d["cell"]))
+    st = s.solve(tol=1e-10, scrub=%r, **kw)
+    phi, _ = s.get_phi()
+    out[mode] = (float(np.abs(phi - d["phi"]).max()), int(st.iters))
+    if mode == "dual":
+        rng = np.random.default_rng(1)
+        v = rng.standard_normal(int(d["n"]) ** 3)
+        Pv = s.apply_projector(v)
+        nodes, coeffs = s.get_constraints()
+        out["APv"] = float(np.abs((coeffs * Pv[nodes]).sum(axis=1)).max())
+print(repr(out))
+""" % (ROOT, os.path.join(GOLDEN, case + ".npz"), scrub)
+    res = {}
+    for name, env in (("dense", {}), ("two-level", {"SHM_TL_MIN_M": "32", "SHM_TL_BOX": str(box)})):
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr
+        res[name] = eval(p.stdout.strip().splitlines()[-1])
+    for mode in ("dual", "primal-dct", "primal-plain"):
+        err, iters = res["two-level"][mode]
+        assert err < (1e-6 if case.endswith("n64") else 1e-7), (mode, res)
+        assert abs(iters - res["dense"][mode][1]) <= 4, (mode, res)       # same operator -> same iteration count (check granularity: 2-4)
+    assert res["two-level"]["APv"] < 1e-10, res
+
+
 def test_errors_are_reported(shm):
     d = load_golden("bunny_small_n16")
     s = shm.GridSolver()
