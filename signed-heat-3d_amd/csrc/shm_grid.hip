@@ -1270,10 +1270,14 @@ struct Solver final : SolverBase {
         static const int ry_env = getenv("SHM_FUSED_RY") ? atoi(getenv("SHM_FUSED_RY")) : 0;
         static const int zc_env = getenv("SHM_FUSED_ZC") ? atoi(getenv("SHM_FUSED_ZC")) : 0;
         // rows per workgroup wy * ry: 8 rows per lane unless that leaves too few workgroups along y to fill the chip with deep z chunks
-        c.ry = 4;  // 8 rows per lane would halve the y halo but spills (3 planes + the prefetched raw planes exceed 256 VGPRs): measured slower
-        if (ry_env == 4 || (ry_env == 8 && vec != 1)) c.ry = ry_env;
+        // rows per lane.  The bordering rows / planes a workgroup re-reads are served by L2 (PMC: HBM traffic of both sweeps = 3.0 N T, the
+        // algorithmic figure), so small row blocks cost nothing in HBM bytes and what matters is memory-level parallelism: 2 rows per lane keep
+        // the kernel under 128 VGPRs = two workgroups per CU running out of phase (512^3 fp64: DIR 0.70 -> 0.60 ms, RES 0.64 -> 0.58 ms against
+        // 4 rows per lane / one workgroup per CU; 8 rows per lane spill)
+        c.ry = (vec == 1) ? 4 : 2;
+        if (ry_env == 4 || (ry_env == 2 && vec != 1)) c.ry = ry_env;   // (1 row per lane measured no better than 2)
         c.yblocks = (n + wy * c.ry - 1) / (wy * c.ry);
-        const int want = std::max(1, (2 * num_cus + c.yblocks - 1) / c.yblocks);  // z chunks for ~2 workgroups per CU
+        const int want = std::max(1, (4 * num_cus + c.yblocks - 1) / c.yblocks);  // z chunks for ~4 workgroups per CU (two resident, two rounds)
         c.zc = std::min(64, std::max(8, sl.nzl / want));
         if (zc_env > 0) c.zc = zc_env;
         c.zc = std::max(1, std::min(c.zc, sl.nzl));
@@ -1302,7 +1306,7 @@ struct Solver final : SolverBase {
         const FusedCfg c = fused_cfg(sl);
         if (vec == 1) launch_fused_w<MODE, 1, 4>(sl, c, slot_old, slot_new, init, use_uw, alpha_slot, zsrc, pin, pout);
         else if (c.ry == 4) launch_fused_w<MODE, vec_width<T>(), 4>(sl, c, slot_old, slot_new, init, use_uw, alpha_slot, zsrc, pin, pout);
-        else launch_fused_w<MODE, vec_width<T>(), 8>(sl, c, slot_old, slot_new, init, use_uw, alpha_slot, zsrc, pin, pout);
+        else launch_fused_w<MODE, vec_width<T>(), 2>(sl, c, slot_old, slot_new, init, use_uw, alpha_slot, zsrc, pin, pout);
         return c.yblocks * c.zchunks;
     }
     void launch_x_update2(Slab<T>& sl, int use_a, int use_b) {

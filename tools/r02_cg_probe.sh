@@ -14,9 +14,11 @@ try:
 except Exception as e: print(sys.argv[2],"FAILED",e)
 P
 }
-for WL in bunny_small_512_f64 rocker_512_f32 bunny_small_256_f64; do
-  run nt X=1
-  run nont SHM_GRID_LIB=$PWD/tools/bin/libshm_grid_nont.so
-  run nt_again X=1
-  run classic SHM_CG_CLASSIC=1
+for WL in bunny_small_512_f64 rocker_512_f32; do
+  run default X=1
+  run ry1_zc32 SHM_FUSED_RY=1 SHM_FUSED_ZC=32
+  run ry2_zc64 SHM_FUSED_RY=2 SHM_FUSED_ZC=64
+  run ry1_zc64 SHM_FUSED_RY=1 SHM_FUSED_ZC=64
+  run ry1_zc16 SHM_FUSED_RY=1 SHM_FUSED_ZC=16
+  run default_again X=1
 done 2>&1 | tee $O/summary.txt
