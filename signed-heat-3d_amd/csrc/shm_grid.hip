@@ -884,12 +884,16 @@ struct Solver final : SolverBase {
             sl.u.alloc((size_t)std::max(m, 1));
             sl.dv.alloc((size_t)7 * std::max(mp, 64));
         }
+        lap("slab uploads");
         if (total_slabs == 1 && precond_available()) build_active_tiles(unode);
+        lap("active tiles");
         Bptr.upload(bptr, stream);
         Bcol.upload(bcol, stream);
         Bval.upload(bval, stream);
         have_B = true;
+        lap("B uploaded");
         upload_red_tables(stream);
+        lap("B, reduction tables uploaded");
         last_host_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
         log("[shm] constraint set-up: host part %.2f ms (m=%d)", last_host_setup_ms, m);
         finish_invert_G();  // synchronises the set-up stream (d_tidx/d_tval go out of scope after it)
@@ -2077,6 +2081,8 @@ struct Solver final : SolverBase {
             solve_gathered(o, st, e_start, e_conv, e_div, wall0);
             return;
         }
+        static const bool setup_alone = getenv("SHM_SETUP_ALONE") != nullptr;  // measurement knob: wait for Step 1 first, so that shm_stats.ms_setup is
+        if (setup_alone) HIPCHK(hipStreamSynchronize(stream));                  // the set-up's time on an otherwise idle GPU (tools/scaling_model.py)
         e_s2a.record(stream2);
         build_constraints();  // on stream2: overlaps the Step-1 kernel; returns once (A A^T)^-1 is ready
         e_s2b.record(stream2);
