@@ -481,50 +481,78 @@ __global__ __launch_bounds__(kBlock, ((LOG2N >= SHM_DCT_WAVES_HINT || SHM_DCT_WA
 // =================================================================================================
 // The (0, 0) line of the sparse z step: d = 0, K_z singular -> pseudo-inverse (what zeroing the (0,0,0) mode does in the transform
 // version).  f~ = f - mean f ; flux g_z = -sum_{j<=z} f~_j ; u_z = (1/a) sum_{j<z} g_j ; u -= mean u : two prefix sums over the n planes,
-// done by one workgroup of n threads (Hillis-Steele in LDS; a single thread walking the planes with dependent loads cost ~100 us).
-__device__ __forceinline__ double zs_scan_inclusive(double v, double* buf /* [2][1024] */, int n) {
+// done by ONE extra workgroup of the same launch (a single thread walking the planes with dependent loads cost ~100 us, a launch of its
+// own 8 us): a thread owns kZsPer consecutive planes, the 256 thread totals are scanned in LDS (Hillis-Steele).
+constexpr int kZsPer = 4;   // n <= 1024 = 256 threads x 4 planes
+__device__ __forceinline__ double zs_block_exclusive(double v, double* buf /* [2][256] */, double& total) {
     const int t = threadIdx.x;
     int cur = 0;
     buf[t] = v;
     __syncthreads();
-    for (int off = 1; off < n; off <<= 1) {
-        const double x = buf[cur * 1024 + t] + (t >= off ? buf[cur * 1024 + t - off] : 0.);
-        buf[(cur ^ 1) * 1024 + t] = x;
+    for (int off = 1; off < kBlock; off <<= 1) {
+        const double x = buf[cur * kBlock + t] + (t >= off ? buf[cur * kBlock + t - off] : 0.);
+        buf[(cur ^ 1) * kBlock + t] = x;
         cur ^= 1;
         __syncthreads();
     }
-    const double r = buf[cur * 1024 + t];
+    const double incl = buf[cur * kBlock + t];
+    total = buf[cur * kBlock + kBlock - 1];
     __syncthreads();
-    return r;
+    return incl - v;
 }
 template <typename T>
-__global__ __launch_bounds__(1024) void zsolve_zero_line_kernel(int n, int n_act, const int* __restrict__ planes, double inv_h2, const T* __restrict__ in,
-                                                                T* __restrict__ out) {
-    __shared__ double fz[1024], buf[2 * 1024];
+__device__ void zsolve_zero_line(int n, int n_act, const int* __restrict__ planes, double inv_h2, const T* __restrict__ in, T* __restrict__ out) {
+    __shared__ double fz[kBlock * kZsPer], buf[2 * kBlock];
     const int t = threadIdx.x;
     const size_t plane = (size_t)n * n;
-    fz[t] = 0.;
+    for (int a = t; a < kBlock * kZsPer; a += kBlock) fz[a] = 0.;
     __syncthreads();
-    if (t < n_act) fz[planes[t]] = (double)in[(size_t)planes[t] * plane];
-    for (int a = t + 1024; a < n_act; a += 1024) fz[planes[a]] = (double)in[(size_t)planes[a] * plane];
+    for (int a = t; a < n_act; a += kBlock) fz[planes[a]] = (double)in[(size_t)planes[a] * plane];
     __syncthreads();
-    const double fsum = zs_scan_inclusive(t < n ? fz[t] : 0., buf, 1024);   // thread 1023 holds the total
-    __shared__ double tot[2];
-    if (t == 1023) tot[0] = fsum;
-    __syncthreads();
-    const double fmean = tot[0] / n;
-    const double pf = zs_scan_inclusive(t < n ? fz[t] - fmean : 0., buf, 1024);        // sum_{j<=t} f~_j
-    const double g = -pf;                                                               // g_t
-    const double su = zs_scan_inclusive(t < n ? g : 0., buf, 1024);                    // sum_{j<=t} g_j
-    const double u = (su - g) * (1. / inv_h2);                                         // u_t = (1/a) sum_{j<t} g_j
-    const double usum = zs_scan_inclusive(t < n ? u : 0., buf, 1024);
-    if (t == 1023) tot[1] = usum;
-    __syncthreads();
-    const double umean = tot[1] / n;
-    fz[t] = u - umean;
-    __syncthreads();
+    double f[kZsPer], loc = 0., tot = 0.;
+#pragma unroll
+    for (int e = 0; e < kZsPer; e++) {
+        const int z = t * kZsPer + e;
+        f[e] = z < n ? fz[z] : 0.;
+        loc += f[e];
+    }
+    zs_block_exclusive(loc, buf, tot);
+    const double fmean = tot / n;
+    // g_z = -sum_{j<=z} (f_j - fmean)
+    loc = 0.;
+#pragma unroll
+    for (int e = 0; e < kZsPer; e++) {
+        const int z = t * kZsPer + e;
+        f[e] = z < n ? f[e] - fmean : 0.;
+        loc += f[e];
+    }
+    double before = zs_block_exclusive(loc, buf, tot);
+    double g[kZsPer];
+#pragma unroll
+    for (int e = 0; e < kZsPer; e++) {
+        before += f[e];
+        g[e] = -before;
+    }
+    // u_z = (1/a) sum_{j<z} g_j
+    loc = 0.;
+#pragma unroll
+    for (int e = 0; e < kZsPer; e++) loc += (t * kZsPer + e < n) ? g[e] : 0.;
+    before = zs_block_exclusive(loc, buf, tot);
+    double u[kZsPer], usum = 0.;
+#pragma unroll
+    for (int e = 0; e < kZsPer; e++) {
+        const int z = t * kZsPer + e;
+        u[e] = before / inv_h2;
+        before += z < n ? g[e] : 0.;
+        usum += z < n ? u[e] : 0.;
+    }
+    zs_block_exclusive(usum, buf, tot);
+    const double umean = tot / n;
     const double scale = 0.25 * 4.0 / ((double)n * (double)n);   // s_x s_y with kx = ky = 0
-    for (int a = t; a < n_act; a += 1024) out[(size_t)planes[a] * plane] = (T)(scale * fz[planes[a]]);
+#pragma unroll
+    for (int e = 0; e < kZsPer; e++) fz[t * kZsPer + e] = u[e] - umean;
+    __syncthreads();
+    for (int a = t; a < n_act; a += kBlock) out[(size_t)planes[a] * plane] = (T)(scale * fz[planes[a]]);
 }
 
 constexpr int kZsChunk = 16;
@@ -532,12 +560,16 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void zsolve_sparse_kernel(int n, int n_act, const int* __restrict__ planes /* ascending */, const double* __restrict__ lam /* [n] */,
                                                                double inv_h2, const T* __restrict__ in, T* __restrict__ out) {
     const size_t plane = (size_t)n * n;
+    if (blockIdx.x == gridDim.x - 1) {   // one extra workgroup: the singular (0, 0) line
+        zsolve_zero_line<T>(n, n_act, planes, inv_h2, in, out);
+        return;
+    }
     const size_t gid = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (gid >= plane) return;
     const int kx = (int)(gid % (size_t)n), ky = (int)(gid / (size_t)n);
     const double scale = (kx == 0 ? 0.5 : 1.0) * (ky == 0 ? 0.5 : 1.0) * 4.0 / ((double)n * (double)n);
     const double a = inv_h2;
-    if (gid == 0) return;  // the singular (0, 0) line: zsolve_zero_line_kernel
+    if (gid == 0) return;  // the singular (0, 0) line: the extra workgroup above
     const double d = lam[kx] + lam[ky];
     const double delta = d / (2. * a), tt = delta + sqrt(delta * (delta + 2.));
     const double r = 1. / (1. + tt), lnr = -log1p(tt);

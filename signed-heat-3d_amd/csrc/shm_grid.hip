@@ -1682,9 +1682,8 @@ struct Solver final : SolverBase {
         const bool fft_z = fft_z_env || n < 256;
         if (fft_z) launch_dct<DCT_FUSED, TP, TP, false, false>(Q, tiles_all, sl.S2.p, sl.W1.p, (const TP*)nullptr, nullptr, nullptr, sl.act_z.p);
         else {
-            hipLaunchKernelGGL((zsolve_sparse_kernel<TP>), dim3((unsigned)((plane + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, n, sl.n_act_planes,
-                               sl.act_planes.p, d_lam64.p, sl.gp.inv_h2, sl.S2.p, sl.W1.p);
-            hipLaunchKernelGGL((zsolve_zero_line_kernel<TP>), dim3(1), dim3(1024), 0, stream, n, sl.n_act_planes, sl.act_planes.p, sl.gp.inv_h2, sl.S2.p, sl.W1.p);
+            hipLaunchKernelGGL((zsolve_sparse_kernel<TP>), dim3((unsigned)((plane + kBlock - 1) / kBlock) + 1), dim3(kBlock), 0, stream, n, sl.n_act_planes,
+                               sl.act_planes.p, d_lam64.p, sl.gp.inv_h2, sl.S2.p, sl.W1.p);   // + 1: the workgroup of the singular (0, 0) line
         }
         // y-inv on the active planes: W1 -> S4
         Q.in = plain_addr(0, L, plane, 1, nn);
