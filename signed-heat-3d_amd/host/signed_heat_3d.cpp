@@ -1,8 +1,12 @@
 #include "signed_heat_3d.h"
 
 #include <algorithm>
+#include <array>
+#include <cmath>
 #include <cstdint>
+#include <unordered_map>
 #include <unordered_set>
+#include <vector>
 
 namespace shm_host {
 
@@ -82,11 +86,15 @@ Vector3 barycenter(const VertexPositionGeometry& geometry, size_t fi) {
 //   2. neighbours on the same side of the surface (normals agree) projected onto the point's tangent plane; the triangles of the planar Delaunay
 //      triangulation incident to the point are read off the convex hull of the INVERTED neighbours (u -> u/|u|^2: circles through the
 //      point become lines, an empty circumcircle becomes a hull edge with the origin on its inner side),
-//   3. the union of the local triangles that at least two of their corners agree on is the triangulation; dual area = a third of
-//      the area of every triangle at the point (3-D area), h = mean length of its unique edges.
-// On bunny.pc (= the vertices of bunny_small.obj, 2856 faces) this gives 2836 triangles, total area 9.43 (mesh: 9.4887), h = 0.0912
-// (mesh: 0.095001) and per-point areas correlated 0.79 with the mesh's barycentric dual areas (the k-NN disk estimate it replaces:
-// 8.31, 0.0859, 0.61).
+//   3. the union of the local triangles that at least two of their corners agree on is the triangulation,
+//   4. flipped to intrinsic Delaunay where it is manifold (edge lengths intrinsic); dual area = a third of the area of every triangle at
+//      the point, h = mean length of its edges.
+// Anchor: bunny.pc / rocker.pc are the vertices of bunny_small.obj / rocker.obj, and what geometry-central would report for them is the
+// mean edge length of an intrinsic DELAUNAY triangulation of that surface, not of the mesh as modelled: flipping the meshes themselves
+// (tools/delaunay_anchor.py) gives 0.091045 (as modelled: 0.095001) and 0.105880 (0.108126).  This estimator: 0.091222 (+0.2 %) and
+// 0.107997 (+2.0 %); total area 9.44 (mesh 9.4887) and 72.80; per-point areas correlated 0.79 / 0.75 with the meshes' barycentric dual
+// areas.  The union is already nearly Delaunay (the local triangulations are), so the flips move h by < 0.1 %; what is not reproduced is
+// the tufted double cover at the union's non-manifold spots.
 namespace {
 
 struct GridHash {
@@ -246,23 +254,86 @@ void estimatePointAreas(PointPositionNormalGeometry& g, int k) {
         }
         tris = agreed.size() * 2 >= P ? agreed : all;
     }
-    std::vector<std::pair<int, int>> edges;
-    edges.reserve(tris.size() * 3);
-    for (const Tri& t : tris) {
-        const Vector3 &p0 = g.positions[(size_t)t.a], &p1 = g.positions[(size_t)t.b], &p2 = g.positions[(size_t)t.c];
-        const double area = 0.5 * cross(p1 - p0, p2 - p0).norm();
-        g.dualAreas[(size_t)t.a] += area / 3.;
-        g.dualAreas[(size_t)t.b] += area / 3.;
-        g.dualAreas[(size_t)t.c] += area / 3.;
-        edges.push_back({t.a, t.b});
-        edges.push_back({t.b, t.c});
-        edges.push_back({t.a, t.c});
+    // ---- intrinsic Delaunay flips (the reference's tufted triangulation is flipped to intrinsic Delaunay before its edge lengths and dual
+    // areas are read, signed_heat_grid_solver.cpp:149-151,165).  Edge lengths are intrinsic (a flipped edge gets the length of the
+    // diagonal of the unfolded quad); an edge is flipped while the two angles opposite to it sum to more than pi.  Edges with other than two
+    // incident triangles (boundary, or the non-manifold spots of the union, which geometry-central resolves with the tufted double cover)
+    // and flips that would duplicate an existing edge are left alone.
+    struct ERec { double len; int f[2]; int nf; };
+    std::unordered_map<uint64_t, ERec> emap;
+    emap.reserve(tris.size() * 3);
+    auto ekey = [](int a, int b) { return ((uint64_t)(uint32_t)std::min(a, b) << 32) | (uint32_t)std::max(a, b); };
+    std::vector<std::array<int, 3>> F(tris.size());
+    for (size_t f = 0; f < tris.size(); f++) {
+        F[f] = {tris[f].a, tris[f].b, tris[f].c};
+        for (int s = 0; s < 3; s++) {
+            const int a = F[f][(size_t)s], b = F[f][(size_t)((s + 1) % 3)];
+            auto it = emap.find(ekey(a, b));
+            if (it == emap.end()) emap.emplace(ekey(a, b), ERec{(g.positions[(size_t)a] - g.positions[(size_t)b]).norm(), {(int)f, -1}, 1});
+            else {
+                if (it->second.nf < 2) it->second.f[it->second.nf] = (int)f;
+                it->second.nf++;
+            }
+        }
     }
-    std::sort(edges.begin(), edges.end());
-    edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
+    auto elen = [&](int a, int b) { return emap.find(ekey(a, b))->second.len; };
+    auto opposite = [&](int f, int a, int b) {
+        for (int s = 0; s < 3; s++)
+            if (F[(size_t)f][(size_t)s] != a && F[(size_t)f][(size_t)s] != b) return F[(size_t)f][(size_t)s];
+        return -1;
+    };
+    auto angle = [](double a, double b, double c) {  // angle between sides a and b, opposite c
+        return std::acos(std::min(1.0, std::max(-1.0, (a * a + b * b - c * c) / (2. * a * b))));
+    };
+    {
+        std::vector<uint64_t> queue;
+        queue.reserve(emap.size());
+        for (const auto& kv : emap) queue.push_back(kv.first);
+        std::sort(queue.begin(), queue.end());  // deterministic order
+        size_t head = 0, budget = 20 * queue.size() + 1000;
+        while (head < queue.size() && budget-- > 0) {
+            const uint64_t key = queue[head++];
+            auto it = emap.find(key);
+            if (it == emap.end() || it->second.nf != 2) continue;
+            const int i = (int)(key >> 32), j = (int)(key & 0xffffffffu), f0 = it->second.f[0], f1 = it->second.f[1];
+            const int k = opposite(f0, i, j), mm = opposite(f1, i, j);
+            if (k < 0 || mm < 0 || k == mm || emap.count(ekey(k, mm))) continue;
+            const double lij = it->second.len, lik = elen(i, k), ljk = elen(j, k), lim = elen(i, mm), ljm = elen(j, mm);
+            const double alpha = angle(lik, ljk, lij), beta = angle(lim, ljm, lij);   // the angles opposite the edge
+            if (alpha + beta <= 3.14159265358979323846 + 1e-12) continue;            // locally Delaunay
+            const double thi = angle(lij, lik, ljk) + angle(lij, lim, ljm), thj = angle(lij, ljk, lik) + angle(lij, ljm, lim);
+            if (thi >= 3.14159265358979 || thj >= 3.14159265358979) continue;        // the unfolded quad is not convex: not flippable
+            const double lkm = std::sqrt(std::max(0., lik * lik + lim * lim - 2. * lik * lim * std::cos(thi)));
+            emap.erase(it);
+            emap.emplace(ekey(k, mm), ERec{lkm, {f0, f1}, 2});
+            F[(size_t)f0] = {k, i, mm};
+            F[(size_t)f1] = {mm, j, k};
+            auto move = [&](int a, int b, int from, int to) {  // side (a, b) belonged to face `from`, now to `to`
+                ERec& r = emap.find(ekey(a, b))->second;
+                for (int t = 0; t < 2; t++)
+                    if (r.f[t] == from) r.f[t] = to;
+            };
+            move(i, mm, f1, f0);
+            move(j, k, f0, f1);
+            for (uint64_t e : {ekey(i, k), ekey(i, mm), ekey(j, k), ekey(j, mm)}) queue.push_back(e);
+        }
+    }
+    // dual area = a third of the (intrinsic, Heron) area of every triangle at the point; h = mean intrinsic edge length
+    for (const auto& f : F) {
+        const double a = elen(f[0], f[1]), b = elen(f[1], f[2]), c = elen(f[0], f[2]);
+        const double sp = 0.5 * (a + b + c);
+        const double area = std::sqrt(std::max(0., sp * (sp - a) * (sp - b) * (sp - c)));
+        for (int t = 0; t < 3; t++) g.dualAreas[(size_t)f[(size_t)t]] += area / 3.;
+    }
     double hsum = 0.;
-    for (const auto& e : edges) hsum += (g.positions[(size_t)e.first] - g.positions[(size_t)e.second]).norm();
-    g.meanEdgeLength = edges.empty() ? 0. : hsum / (double)edges.size();
+    {
+        std::vector<std::pair<uint64_t, double>> el;
+        el.reserve(emap.size());
+        for (const auto& kv : emap) el.push_back({kv.first, kv.second.len});
+        std::sort(el.begin(), el.end());   // fixed summation order
+        for (const auto& e : el) hsum += e.second;
+    }
+    g.meanEdgeLength = emap.empty() ? 0. : hsum / (double)emap.size();
     // isolated points (no local triangle, e.g. zero normal): fall back to the mean so that they still act as sources
     double asum = 0.;
     size_t acount = 0;
