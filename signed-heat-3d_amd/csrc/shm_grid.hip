@@ -1259,7 +1259,7 @@ struct Solver final : SolverBase {
     // ------------------------------------------------------------------------------------------
     // Fused CG sweeps (shm_cg_fused.hip.h): a workgroup of 8 waves owns whole x rows, so the row must fit WX <= 8 waves of VEC-wide lanes.
     struct FusedCfg {
-        int wx = 0, ry = 8, zc = 16, yblocks = 0, zchunks = 0;
+        int wx = 0, ry = 8, zc = 16, yblocks = 0, zchunks = 0, nw = 8;
     };
     bool fused_available() const {
         static const bool off = getenv("SHM_CG_CLASSIC") != nullptr;  // A/B knob: the round-1 four-kernel loop
@@ -1270,7 +1270,9 @@ struct Solver final : SolverBase {
         const int lanes = (n + vec - 1) / vec;
         c.wx = 1;
         while (c.wx * 64 < lanes) c.wx <<= 1;
-        const int wy = 8 / c.wx;
+        static const int nw_env = getenv("SHM_FUSED_WAVES") ? atoi(getenv("SHM_FUSED_WAVES")) : 0;  // experiment knob: 4 waves per workgroup instead of 8
+        c.nw = (nw_env == 4 && c.wx <= 4) ? 4 : 8;
+        const int wy = c.nw / c.wx;
         static const int ry_env = getenv("SHM_FUSED_RY") ? atoi(getenv("SHM_FUSED_RY")) : 0;
         static const int zc_env = getenv("SHM_FUSED_ZC") ? atoi(getenv("SHM_FUSED_ZC")) : 0;
         // rows per workgroup wy * ry: 8 rows per lane unless that leaves too few workgroups along y to fill the chip with deep z chunks
@@ -1292,6 +1294,13 @@ struct Solver final : SolverBase {
     void launch_fused_k(Slab<T>& sl, const FusedCfg& c, int slot_old, int slot_new, int init, int use_uw, int alpha_slot, const T* zsrc, const T* pin, T* pout) {
         FusedParams F;
         F.n = n; F.nzl = sl.nzl; F.k0 = sl.k0; F.zc = c.zc; F.yblocks = c.yblocks; F.inv_h2 = sl.gp.inv_h2;
+        if constexpr (WX <= 4) {
+            if (c.nw == 4) {
+                hipLaunchKernelGGL((cg_fused_kernel<T, VEC, RY, WX, 4 / WX, MODE>), dim3((unsigned)(c.yblocks * c.zchunks)), dim3(256), 0, stream, F, sl.sc.p, slot_old,
+                                   slot_new, sl.red.p, sl.pq.p, init, use_uw, alpha_slot, zsrc, pin, pout, sl.r.p, sl.partials.p);
+                return;
+            }
+        }
         hipLaunchKernelGGL((cg_fused_kernel<T, VEC, RY, WX, 8 / WX, MODE>), dim3((unsigned)(c.yblocks * c.zchunks)), dim3(512), 0, stream, F, sl.sc.p, slot_old,
                            slot_new, sl.red.p, sl.pq.p, init, use_uw, alpha_slot, zsrc, pin, pout, sl.r.p, sl.partials.p);
     }

@@ -856,6 +856,33 @@ def test_multiprocess_ranks_on_one_gpu(shm, tmp_path, world, mode):
         assert np.abs(phi - ref).max() < 1e-9
 
 
+def test_multiprocess_noconv_still_returns_phi(shm, tmp_path):
+    """Two ranks, default (gathered dual) solver stopped after 4 iterations: every rank gets SHM_ERR_NOCONV *and* its planes of the
+    unconverged phi plus filled statistics (the single-rank contract of include/shm_grid.h), not SHM_ERR_STATE from get_phi."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    so = str(tmp_path / "librccl_mock.so")
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", os.path.join(ROOT, "tests", "native", "rccl_mock.c"), "-o", so, "-I/opt/rocm/include",
+                           "-D__HIP_PLATFORM_AMD__", "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread"])
+    world, case = 2, "bunny_small_n32"
+    uid = ("/shmmock_%d_noconv" % os.getpid()).encode().ljust(128, b"\x00")
+    env = dict(os.environ, SHM_RCCL_LIB=so, SHM_WORKER_MAX_ITERS="4")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multiproc_worker.py"), str(r), str(world), uid.hex(), case, "dual", str(tmp_path)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    d = load_golden(case)
+    phi = np.concatenate([np.load(tmp_path / ("phi_%d.npy" % r)) for r in range(world)])
+    err = np.abs(phi - d["phi"]).max()
+    assert np.isfinite(phi).all() and 1e-7 < err < 1e-1, err          # a usable, visibly unconverged field
+    s1 = make_solver(shm, d)
+    s1.solve(tol=1e-10, max_iters=4, allow_noconv=True, solver="dual")
+    ref, _ = s1.get_phi()
+    assert np.abs(phi - ref).max() < 1e-9                              # the same four iterations as on one rank
+
+
 def _device_count():
     try:
         import torch

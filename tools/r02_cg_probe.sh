@@ -16,9 +16,9 @@ P
 }
 for WL in bunny_small_512_f64 rocker_512_f32; do
   run default X=1
-  run ry1_zc32 SHM_FUSED_RY=1 SHM_FUSED_ZC=32
-  run ry2_zc64 SHM_FUSED_RY=2 SHM_FUSED_ZC=64
-  run ry1_zc64 SHM_FUSED_RY=1 SHM_FUSED_ZC=64
-  run ry1_zc16 SHM_FUSED_RY=1 SHM_FUSED_ZC=16
+  run w4_ry2 SHM_FUSED_WAVES=4
+  run w4_ry4 SHM_FUSED_WAVES=4 SHM_FUSED_RY=4
+  run w4_ry2_zc32 SHM_FUSED_WAVES=4 SHM_FUSED_ZC=32
+  run w4_ry4_zc32 SHM_FUSED_WAVES=4 SHM_FUSED_RY=4 SHM_FUSED_ZC=32
   run default_again X=1
 done 2>&1 | tee $O/summary.txt
