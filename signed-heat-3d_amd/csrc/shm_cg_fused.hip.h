@@ -25,7 +25,9 @@ namespace shm {
 struct FusedParams {
     int n, nzl, k0;  // grid side, owned planes of this slab, global index of its first owned plane
     int zc;          // planes per workgroup
-    int yblocks;     // workgroups along y (z chunks: gridDim.x / yblocks)
+    int yblocks;     // workgroups along y (z chunks of this launch: gridDim.x / yblocks)
+    int zc_first, zc_stride;  // z chunk of a workgroup = zc_first + (logical block / yblocks) * zc_stride: a launch covers all chunks (0, 1), the
+                              // interior ones (1, 1) or the first and the last (0, zchunks - 1) -- the latter two overlap the halo exchange
     double inv_h2;
 };
 
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(WX* WY * 64) void cg_fused_kernel(FusedParams F, do
     // only per-lane address register is the x offset: global_load ... v_off, s[base:base+1]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wx = wave % WX, wy = wave / WX;
     const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
-    const int yb = (int)(lb % (unsigned)F.yblocks), zci = (int)(lb / (unsigned)F.yblocks);
+    const int yb = (int)(lb % (unsigned)F.yblocks), zci = F.zc_first + (int)(lb / (unsigned)F.yblocks) * F.zc_stride;
     const int n = F.n;
     const size_t plane = (size_t)n * n;
     const int i = (wx * 64 + lane) * VEC;
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(WX* WY * 64) void cg_fused_kernel(FusedParams F, do
         double s = 0.;
 #pragma unroll
         for (int a = 0; a < NW; a++) s += red[a];
-        partials[lb] = s;
+        partials[zci * F.yblocks + yb] = s;
     }
 }
 

@@ -219,6 +219,7 @@ struct Solver final : SolverBase {
     shm_config cfg;
     hipStream_t stream = nullptr;   // conv, divergence, CG
     hipStream_t stream2 = nullptr;  // constraint set-up ((A A^T)^-1), overlapped with the Step-1 kernel
+    hipStream_t stream_h = nullptr;  // halo exchange of the fused primal CG, overlapped with the interior z chunks of its DIR sweep (created on first use)
     int n = 0, alloc_n = -1;
     size_t N = 0;
     double cell = 0., lambda = 0.;
@@ -315,6 +316,7 @@ struct Solver final : SolverBase {
         slabs.clear();
         if (stream) (void)hipStreamDestroy(stream);
         if (stream2) (void)hipStreamDestroy(stream2);
+        if (stream_h) (void)hipStreamDestroy(stream_h);
     }
 
     void log(const char* f, ...) {
@@ -1183,7 +1185,8 @@ struct Solver final : SolverBase {
 
     // transport: fill the ghost planes of `field` (p) from the neighbouring slabs
     void halo_exchange_p() { halo_exchange(ARR_P); }
-    void halo_exchange(int sel) {
+    void halo_exchange(int sel) { halo_exchange(sel, stream); }
+    void halo_exchange(int sel, hipStream_t stream) {
         const size_t pb = slabs[0].plane * sizeof(T);
         for (size_t s = 0; s + 1 < slabs.size(); s++) {
             Slab<T>&a = slabs[s], &b = slabs[s + 1];
@@ -1259,7 +1262,7 @@ struct Solver final : SolverBase {
     // ------------------------------------------------------------------------------------------
     // Fused CG sweeps (shm_cg_fused.hip.h): a workgroup of 8 waves owns whole x rows, so the row must fit WX <= 8 waves of VEC-wide lanes.
     struct FusedCfg {
-        int wx = 0, ry = 8, zc = 16, yblocks = 0, zchunks = 0, nw = 8;
+        int wx = 0, ry = 8, zc = 16, yblocks = 0, zchunks = 0, nw = 8, part = 0;
     };
     bool fused_available() const {
         static const bool off = getenv("SHM_CG_CLASSIC") != nullptr;  // A/B knob: the round-1 four-kernel loop
@@ -1290,10 +1293,15 @@ struct Solver final : SolverBase {
         c.zchunks = (sl.nzl + c.zc - 1) / c.zc;
         return c;
     }
+    enum FusedPart { FUSED_ALL = 0, FUSED_INTERIOR = 1, FUSED_BOUNDARY = 2 };
     template <int MODE, int VEC, int RY, int WX>
-    void launch_fused_k(Slab<T>& sl, const FusedCfg& c, int slot_old, int slot_new, int init, int use_uw, int alpha_slot, const T* zsrc, const T* pin, T* pout) {
+    void launch_fused_k(Slab<T>& sl, const FusedCfg& cc, int slot_old, int slot_new, int init, int use_uw, int alpha_slot, const T* zsrc, const T* pin, T* pout) {
+        FusedCfg c = cc;
         FusedParams F;
         F.n = n; F.nzl = sl.nzl; F.k0 = sl.k0; F.zc = c.zc; F.yblocks = c.yblocks; F.inv_h2 = sl.gp.inv_h2;
+        F.zc_first = 0; F.zc_stride = 1;
+        if (c.part == FUSED_INTERIOR) { F.zc_first = 1; c.zchunks -= 2; }
+        else if (c.part == FUSED_BOUNDARY) { F.zc_stride = c.zchunks - 1; c.zchunks = 2; }
         if constexpr (WX <= 4) {
             if (c.nw == 4) {
                 hipLaunchKernelGGL((cg_fused_kernel<T, VEC, RY, WX, 4 / WX, MODE>), dim3((unsigned)(c.yblocks * c.zchunks)), dim3(256), 0, stream, F, sl.sc.p, slot_old,
@@ -1315,8 +1323,9 @@ struct Solver final : SolverBase {
     }
     // returns the number of block partials the sweep leaves in sl.partials
     template <int MODE>
-    int launch_fused(Slab<T>& sl, int slot_old, int slot_new, int init, int use_uw, int alpha_slot, const T* zsrc, const T* pin, T* pout) {
-        const FusedCfg c = fused_cfg(sl);
+    int launch_fused(Slab<T>& sl, int slot_old, int slot_new, int init, int use_uw, int alpha_slot, const T* zsrc, const T* pin, T* pout, int part = FUSED_ALL) {
+        FusedCfg c = fused_cfg(sl);
+        c.part = part;
         if (vec == 1) launch_fused_w<MODE, 1, 4>(sl, c, slot_old, slot_new, init, use_uw, alpha_slot, zsrc, pin, pout);
         else if (c.ry == 4) launch_fused_w<MODE, vec_width<T>(), 4>(sl, c, slot_old, slot_new, init, use_uw, alpha_slot, zsrc, pin, pout);
         else launch_fused_w<MODE, vec_width<T>(), 2>(sl, c, slot_old, slot_new, init, use_uw, alpha_slot, zsrc, pin, pout);
@@ -1939,13 +1948,34 @@ struct Solver final : SolverBase {
             for (auto& v : zparts) v = np;
             launch_projection(zparts, true, 0);
         }
+        // Several slabs: the ghost planes of z travel on a second stream while the z chunks that do not touch them are swept (the first and the
+        // last chunk of every slab follow once the planes have arrived).  One host thread issues everything in the same order on every rank; RCCL
+        // orders the operations of one communicator across streams itself.  SHM_HALO_SERIAL: exchange first, then one sweep (A/B knob).
+        static const bool halo_serial = getenv("SHM_HALO_SERIAL") != nullptr;
+        bool overlap = total_slabs > 1 && !halo_serial;
+        for (Slab<T>& sl : slabs) overlap = overlap && fused_cfg(sl).zchunks >= 3;
+        if (overlap && !stream_h) HIPCHK(hipStreamCreateWithFlags(&stream_h, hipStreamNonBlocking));
+        Event e_ready, e_halo;
         auto run_dir = [&](int k, int slot_old, int slot_new, int init) {  // p_{k+1} (init: p_0) from z and p_k; leaves p'.Kp' in pq
-            if (total_slabs > 1) halo_exchange(zsel);
-            for (size_t s = 0; s < slabs.size(); s++) {
-                Slab<T>& sl = slabs[s];
-                const int out = init ? 0 : k + 1;
-                kparts[s] = launch_fused<CGF_DIR>(sl, slot_old, slot_new, init, pre ? 0 : 1, 0, arr(sl, zsel), dirbuf(sl, k), dirbuf(sl, out));
+            auto sweep = [&](int part) {
+                for (size_t s = 0; s < slabs.size(); s++) {
+                    Slab<T>& sl = slabs[s];
+                    const int out = init ? 0 : k + 1;
+                    kparts[s] = launch_fused<CGF_DIR>(sl, slot_old, slot_new, init, pre ? 0 : 1, 0, arr(sl, zsel), dirbuf(sl, k), dirbuf(sl, out), part);
+                }
+            };
+            if (!overlap) {
+                if (total_slabs > 1) halo_exchange(zsel);
+                sweep(FUSED_ALL);
+                return;
             }
+            e_ready.record(stream);                                   // z is final (projection done)
+            HIPCHK(hipStreamWaitEvent(stream_h, e_ready.e, 0));
+            sweep(FUSED_INTERIOR);
+            halo_exchange(zsel, stream_h);
+            e_halo.record(stream_h);
+            HIPCHK(hipStreamWaitEvent(stream, e_halo.e, 0));
+            sweep(FUSED_BOUNDARY);
         };
         auto finalize_pq = [&]() {
             for (size_t s = 0; s < slabs.size(); s++)

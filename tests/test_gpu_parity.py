@@ -816,7 +816,8 @@ def test_preconditioner_1024_property(shm):
 
 # ---- several PROCESSES (ranks) on one GPU through a shared-memory double of librccl --------------------------------------
 @pytest.mark.parametrize("world,mode", [(2, "dual"), (4, "dual"), (8, "dual"), (2, "dual-slabs"), (4, "dual-slabs"), (2, "primal-plain"), (8, "primal-plain"),
-                                        (2, "primal-dct"), (8, "primal-dct"), (4, "fast"), (8, "fast")])
+                                        (2, "primal-dct"), (8, "primal-dct"), (4, "fast"), (8, "fast"),
+                                        (2, "primal-plain+overlap"), (4, "primal-dct+overlap")])
 def test_multiprocess_ranks_on_one_gpu(shm, tmp_path, world, mode):
     """The real multi-rank code path (rank-major z-slabs, halo send/recv, all-reduces, the gather of D^T Y in front of the whole-grid
     dual solve ("dual"), the all-to-all transposes of the distributed DCT ("dual-slabs", "primal-dct"), the slab-chained fast
@@ -830,8 +831,13 @@ def test_multiprocess_ranks_on_one_gpu(shm, tmp_path, world, mode):
     subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", os.path.join(ROOT, "tests", "native", "rccl_mock.c"), "-o", so, "-I/opt/rocm/include",
                            "-D__HIP_PLATFORM_AMD__", "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread"])
     case = "bunny_small_fast_n32" if mode == "fast" else "bunny_small_n32"
-    uid = ("/shmmock_%d_%s_%d" % (os.getpid(), mode.replace("-", ""), world)).encode().ljust(128, b"\x00")
+    uid = ("/shmmock_%d_%s_%d" % (os.getpid(), mode.replace("-", "").replace("+", ""), world)).encode().ljust(128, b"\x00")
     env = dict(os.environ, SHM_RCCL_LIB=so)
+    if mode.endswith("+overlap"):
+        # z chunks of 2 planes: every slab (16 / 8 planes) has interior chunks, so the ghost planes of z travel on the second stream while the
+        # interior chunks of the DIR sweep run, and the first / last chunk follow (the default chunking leaves < 3 chunks at 32^3: no split)
+        env["SHM_FUSED_ZC"] = "2"
+        mode = mode[:-len("+overlap")]
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multiproc_worker.py"), str(r), str(world), uid.hex(), case, mode, str(tmp_path)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
