@@ -579,8 +579,8 @@ struct Solver final : SolverBase {
 
     void launch_div(int scrub) {
         for (Slab<T>& sl : slabs)
-            hipLaunchKernelGGL((divergence_kernel<T>), dim3(grid_for(sl.nown, 4096)), dim3(kBlock), 0, stream, sl.gp, sl.Y0.p, sl.Y1.p, sl.Y2.p,
-                               sl.r.p, scrub);
+            hipLaunchKernelGGL((divergence_kernel<T>), dim3((unsigned)((n + kBlock - 1) / kBlock), (unsigned)n, (unsigned)sl.nzl), dim3(kBlock), 0, stream, sl.gp,
+                               sl.Y0.p, sl.Y1.p, sl.Y2.p, sl.r.p, scrub);
         HIPCHK(hipGetLastError());
         have_div = true;
     }
