@@ -1291,6 +1291,10 @@ struct Solver final : SolverBase {
         if (zc_env > 0) c.zc = zc_env;
         c.zc = std::max(1, std::min(c.zc, sl.nzl));
         c.zchunks = (sl.nzl + c.zc - 1) / c.zc;
+        while ((size_t)c.yblocks * c.zchunks > sl.partials.count && c.zc < sl.nzl) {  // one block partial per workgroup: never more than the buffer holds
+            c.zc = std::min(sl.nzl, 2 * c.zc);
+            c.zchunks = (sl.nzl + c.zc - 1) / c.zc;
+        }
         return c;
     }
     enum FusedPart { FUSED_ALL = 0, FUSED_INTERIOR = 1, FUSED_BOUNDARY = 2 };
