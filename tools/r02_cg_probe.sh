@@ -15,10 +15,10 @@ except Exception as e: print(sys.argv[2],"FAILED",e)
 P
 }
 for WL in bunny_small_512_f64 rocker_512_f32; do
-  run default X=1
-  run w4_ry2 SHM_FUSED_WAVES=4
-  run w4_ry4 SHM_FUSED_WAVES=4 SHM_FUSED_RY=4
-  run w4_ry2_zc32 SHM_FUSED_WAVES=4 SHM_FUSED_ZC=32
-  run w4_ry4_zc32 SHM_FUSED_WAVES=4 SHM_FUSED_RY=4 SHM_FUSED_ZC=32
-  run default_again X=1
+  run skew0 X=1
+  run skew256 SHM_ARRAY_SKEW_BYTES=256
+  run skew4352 SHM_ARRAY_SKEW_BYTES=4352
+  run skew69888 SHM_ARRAY_SKEW_BYTES=69888
+  run skew1M SHM_ARRAY_SKEW_BYTES=1052928
+  run skew0_again X=1
 done 2>&1 | tee $O/summary.txt
