@@ -13,9 +13,11 @@
 // there is no halo in x), WY * RY consecutive rows and a chunk of ZC planes; a lane keeps VEC consecutive x nodes of RY rows of the
 // planes k-1, k, k+1 in registers.  x neighbours come from the adjacent lanes (wave shuffles); the values at wave boundaries --
 // first / last lane in x, first / last row in y -- are exchanged through LDS once per plane (one barrier per plane, double
-// buffered); only the two rows bordering the workgroup's row block are read again from HBM (halo factor 1 + 2 / (WY RY) in y,
-// 1 + 2 / ZC in z).  The raw loads of plane k+2 are in flight while plane k is computed (software prefetch in registers: the
-// kernel runs at two waves per SIMD by design).
+// buffered); only the two rows bordering the workgroup's row block and the two planes bordering its chunk are read a second time (a
+// factor 1 + 2 / (WY RY) in y, 1 + 2 / ZC in z of loads) -- and those re-reads are L2 hits: the PMC-measured HBM traffic of both sweeps
+// is 3.0 N T, the algorithmic figure (profiles/r02_pmc_traffic.json).  The raw loads of plane k+2 are in flight while plane k is computed
+// (software prefetch in registers).  Shipped shape: RY = 2 rows per lane (103-117 VGPRs: two 512-thread workgroups per CU, out of phase),
+// chunks of ~64 planes, ~4 workgroups per CU in the grid; measured alternatives in DESIGN.md 4c / 6.
 // K = -L with the reference's Neumann convention (laplacian(): :278-334): an out-of-grid neighbour is the node itself.
 #pragma once
 #include "shm_kernels.hip.h"
