@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SHM_GRID_ABI_VERSION 1
+#define SHM_GRID_ABI_VERSION 2 /* 2: shm_stats grew by cg_form (round 2); callers allocate shm_stats by this header */
 
 typedef struct shm_solver shm_solver; /* opaque */
 
