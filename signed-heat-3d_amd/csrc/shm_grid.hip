@@ -229,6 +229,7 @@ struct Solver final : SolverBase {
     double area_sum = 0., conv_far_gap = 0., conv_skip_base = 3.0e38, last_host_setup_ms = 0., last_setup_wall_ms = 0.;
     int n_clusters = 0;
     int conv_grid_cap = 1 << 30;
+    bool o_fast_hint = false;  // the running solve is a fast-integration one: no constraint set-up beside Step 1
     int num_cus = 256, dct_grid_x16 = 16;
     DevArray<T> d_src;          // [Spad][6] Morton-sorted, padded to whole clusters
     DevArray<float> d_src32;    // same in fp32 (far clusters of the fp64 path)
@@ -557,8 +558,22 @@ struct Solver final : SolverBase {
             P.exact_offset = (lambda * tile_diam > 30.0) ? 1 : 0;  // tile-diameter bound looser than e^-30: per-node offsets
             const int tiles_z = (planes + tile_z - 1) / tile_z;
             P.n_tiles = P.tiles_x * P.tiles_y * tiles_z;
-            // fewer workgroups than the chip has slots (4 per CU by LDS): the set-up stream's kernels find room beside Step 1
-            const unsigned grid = (unsigned)std::min(P.n_tiles, conv_grid_cap);
+            // Step 1 strides a fixed grid of workgroups over the tiles.  The constraint set-up (second stream, dozens of short dependent kernels) can
+            // only run in slots Step 1 leaves free: when every CU is full (the fp64 kernel's registers admit two workgroups per CU) a set-up kernel
+            // waits for a Step-1 workgroup to finish a tile column, and the set-up stretches to Step 1's length and beyond (measured at 128^3: 3-5 ms of
+            // exposed wait on a 6 ms Step 1).  So when Step 1 is short against the set-up (small grids; one slab of many on a multi-GPU run), an
+            // eighth of the resident slots is left free for the set-up stream; long Step-1 launches keep the whole chip (the set-up hides anyway).
+            unsigned grid = (unsigned)std::min(P.n_tiles, conv_grid_cap);
+            {
+                int occ = 0;
+                const void* kfn = npt4 ? reinterpret_cast<const void*>(conv_normalize_kernel<T, 4>) : reinterpret_cast<const void*>(conv_normalize_kernel<T, 2>);
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, kBlock, 0) != hipSuccess || occ < 1) occ = 2;
+                const unsigned resident = (unsigned)(occ * num_cus);
+                const double pairs = (double)sl.nown * (double)S;
+                const double conv_est_ms = pairs / (sizeof(T) == 8 ? 1.2e9 : 3.5e9), setup_est_ms = 2.2e-3 * (double)std::min<int64_t>(S, (int64_t)8 * n * n);
+                static const bool no_reserve = getenv("SHM_CONV_NO_RESERVE") != nullptr;  // A/B knob
+                if (!no_reserve && !o_fast_hint && conv_est_ms < 4.0 * setup_est_ms && grid > resident - resident / 8) grid = resident - resident / 8;
+            }
             if (npt4)
                 hipLaunchKernelGGL((conv_normalize_kernel<T, 4>), dim3(grid), dim3(kBlock), 0, stream, P, d_src.p, d_src32.p, d_clusters.p, d_exptab.p, sl.Y0.p,
                                    sl.Y1.p, sl.Y2.p);
@@ -2111,6 +2126,7 @@ struct Solver final : SolverBase {
         Event e_start, e_conv, e_div, e_setup, e_pcg, e_end, e_s2a, e_s2b;
         const auto wall0 = std::chrono::steady_clock::now();
         e_start.record(stream);
+        o_fast_hint = o.fast_integration != 0;
         launch_conv();
         e_conv.record(stream);
         launch_div(o.scrub_nonfinite);
