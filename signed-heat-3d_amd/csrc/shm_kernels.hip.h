@@ -170,8 +170,12 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
     // dx^2 + dy^2 of every source
     constexpr int kTileZ = (kBlock / 64) * NPT;
     constexpr bool kMixed = sizeof(T) == 8;
-    __shared__ T tile[kSrcTile * 6];
-    __shared__ float tile32[kMixed ? kSrcTile * 6 : 1];
+    // sources per LDS fill: 256 (4 clusters) in fp64, where the fill shares the LDS with the exponential table and the fp32 copy; 1024 (16 clusters,
+    // 24 KB) in fp32, whose LDS is otherwise empty -- a quarter of the fills and barriers (rocker 512^3: 54 -> 14 per tile)
+    constexpr int kChunk = kMixed ? kConvChunk : 4 * kConvChunk;
+    constexpr int kFill = kChunk * kConvCluster;
+    __shared__ T tile[kFill * 6];
+    __shared__ float tile32[kMixed ? kFill * 6 : 1];
     __shared__ float red[kBlock / kWave], redw[kBlock / kWave];
     constexpr int kTab = kMixed ? (1 << YukawaMath<double>::kExpTabBits) : 1;
     __shared__ double exp_tab[kTab];
@@ -257,8 +261,8 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
         float m2[NPT];
 #pragma unroll
         for (int e = 0; e < NPT; e++) m2[e] = 3.0e38f;
-        for (int s0 = 0; s0 < P.S; s0 += kSrcTile) {
-            const int cnt = min(kSrcTile, P.S - s0);
+        for (int s0 = 0; s0 < P.S; s0 += kFill) {
+            const int cnt = min(kFill, P.S - s0);
             __syncthreads();
             for (int a = threadIdx.x; a < cnt * 6; a += kBlock) tile[a] = src[(size_t)s0 * 6 + a];
             __syncthreads();
@@ -280,23 +284,24 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
     float coff[NPT];
 #pragma unroll
     for (int e = 0; e < NPT; e++) coff[e] = (float)(P.lambda * 1.4426950408889634 * (double)d0[e]);
-    for (int c0 = 0; c0 < P.n_clusters; c0 += kConvChunk) {
-        const int ncl = min(kConvChunk, P.n_clusters - c0);
+    for (int c0 = 0; c0 < P.n_clusters; c0 += kChunk) {
+        const int ncl = min(kChunk, P.n_clusters - c0);
         const int cnt = ncl * kConvCluster;
         // per cluster: lower bound of every (node of the tile, source of the cluster) distance minus the upper bound of the tile's distance
         // to its nearest source -- from the bounding spheres (uniform addresses: scalar loads), before anything is staged: a chunk whose
         // clusters are all negligible costs neither the LDS fill nor its barriers.  All branches below are workgroup-uniform.
-        float gaps[kConvChunk];
-        bool skip[kConvChunk];
-        bool any = false;
-#pragma unroll
-        for (int c = 0; c < kConvChunk; c++) {
-            const int cc = min(c0 + c, P.n_clusters - 1);
+        auto cluster_gap = [&](int cc) {
             const float* rec = clusters + (size_t)cc * kConvClusterRec;
             const float gdx = cx - rec[0], gdy = cy - rec[1], gdz = cz - rec[2];
-            gaps[c] = sqrtf(gdx * gdx + gdy * gdy + gdz * gdz) * 0.999999f - rt - rec[3] - r_hi;
-            skip[c] = gaps[c] > (P.skip_base + rec[4] - ln_anear) * P.inv_lambda;   // all its terms together: below the rounding unit of the dominant term
-            any = any || (c < ncl && !skip[c]);
+            return sqrtf(gdx * gdx + gdy * gdy + gdz * gdz) * 0.999999f - rt - rec[3] - r_hi;
+        };
+        unsigned skipmask = 0;   // bit c: cluster c0 + c is skipped -- all its terms together are below the rounding unit of the dominant term
+        bool any = false;
+        for (int c = 0; c < ncl; c++) {
+            const float* rec = clusters + (size_t)(c0 + c) * kConvClusterRec;
+            const bool sk = cluster_gap(c0 + c) > (P.skip_base + rec[4] - ln_anear) * P.inv_lambda;
+            skipmask |= sk ? (1u << c) : 0u;
+            any = any || !sk;
         }
         if (!any) continue;
         __syncthreads();
@@ -305,11 +310,10 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
             if (kMixed) tile32[a] = src32[(size_t)c0 * kConvCluster * 6 + a];
         }
         __syncthreads();
-#pragma unroll
-        for (int c = 0; c < kConvChunk; c++) {
-            if (c >= ncl) break;
-            const float gap = gaps[c];
-            if (skip[c]) continue;
+#pragma unroll 1
+        for (int c = 0; c < ncl; c++) {
+            if ((skipmask >> c) & 1u) continue;
+            const float gap = cluster_gap(c0 + c);
             const bool far = kMixed && gap > P.far_gap;
             if (far) {
 #pragma unroll 2
