@@ -461,6 +461,31 @@ struct Solver final : SolverBase {
             }
             d_src.upload(packed, stream);
             d_src32.upload(packed32, stream);
+            {   // one more level: bounding sphere / largest weight of every LDS fill's worth of clusters (kernel: kChunk = 4 in fp64, 16 in fp32), appended
+                // to the cluster records -- a node tile tests the whole fill first and only then its clusters
+                const int per = sizeof(T) == 8 ? kConvChunk : 4 * kConvChunk;
+                const int nchunks = (n_clusters + per - 1) / per;
+                for (int g = 0; g < nchunks; g++) {
+                    const int a = g * per, b = std::min(n_clusters, a + per);
+                    double cc[3] = {0, 0, 0};
+                    for (int c = a; c < b; c++)
+                        for (int t = 0; t < 3; t++) cc[t] += cl[kConvClusterRec * (size_t)c + t];
+                    for (int t = 0; t < 3; t++) cc[t] /= (b - a);
+                    double rad = 0., lnw = -1.0e30;
+                    for (int c = a; c < b; c++) {
+                        double d2 = 0.;
+                        for (int t = 0; t < 3; t++) {
+                            const double d = (double)cl[kConvClusterRec * (size_t)c + t] - cc[t];
+                            d2 += d * d;
+                        }
+                        rad = std::max(rad, std::sqrt(d2) + (double)cl[kConvClusterRec * (size_t)c + 3]);
+                        lnw = std::max(lnw, (double)cl[kConvClusterRec * (size_t)c + 4]);
+                    }
+                    for (int t = 0; t < 3; t++) cl.push_back((float)cc[t]);
+                    cl.push_back((float)(rad * 1.00001 + 1e-30));
+                    cl.push_back((float)lnw);
+                }
+            }
             d_clusters.upload(cl, stream);
             if (!d_exptab.p) {
                 std::vector<double> tab(2048);
