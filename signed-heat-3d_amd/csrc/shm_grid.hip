@@ -577,8 +577,12 @@ struct Solver final : SolverBase {
             // nodes per lane (a z-column sharing dx^2 + dy^2): 4 when the grid still yields a full wave of workgroups, else 2
             const int planes = P.kk_end - P.kk_begin;
             const bool npt4 = (long long)P.tiles_x * P.tiles_y * ((planes + 15) / 16) >= conv_grid_cap;
-            const int tile_z = npt4 ? 16 : 8;
-            const double half_z = 0.5 * (tile_z - 1);
+            // fp32: 8 nodes per lane on grids large enough, culled as two 16-plane halves (see the kernel); fp64 stays at 4 (8 needs 256 VGPRs: 57 against
+            // 44 ms at 256^3).  SHM_CONV_NPT4: A/B knob, and the reference for the bit-identity check of the two shapes (tools/skip_check.py)
+            const bool npt4_env = getenv("SHM_CONV_NPT4") != nullptr;   // (read per launch: the check flips it inside one process)
+            const bool npt8 = sizeof(T) == 4 && !npt4_env && npt4 && (long long)P.tiles_x * P.tiles_y * ((planes + 31) / 32) >= conv_grid_cap;
+            const int tile_z = npt8 ? 32 : npt4 ? 16 : 8;
+            const double half_z = 0.5 * ((npt8 ? 16 : tile_z) - 1);   // extent of the unit that is culled and carries one exponent offset
             const double tile_diam = 2.0 * std::sqrt(2 * 3.5 * 3.5 + half_z * half_z) * cell;
             P.exact_offset = (lambda * tile_diam > 30.0) ? 1 : 0;  // tile-diameter bound looser than e^-30: per-node offsets
             const int tiles_z = (planes + tile_z - 1) / tile_z;
@@ -592,6 +596,8 @@ struct Solver final : SolverBase {
             {
                 int occ = 0;
                 const void* kfn = npt4 ? reinterpret_cast<const void*>(conv_normalize_kernel<T, 4>) : reinterpret_cast<const void*>(conv_normalize_kernel<T, 2>);
+                if constexpr (sizeof(T) == 4)
+                    if (npt8) kfn = reinterpret_cast<const void*>(conv_normalize_kernel<float, 8>);
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, kBlock, 0) != hipSuccess || occ < 1) occ = 2;
                 const unsigned resident = (unsigned)(occ * num_cus);
                 const double pairs = (double)sl.nown * (double)S;
@@ -599,7 +605,16 @@ struct Solver final : SolverBase {
                 static const bool no_reserve = getenv("SHM_CONV_NO_RESERVE") != nullptr;  // A/B knob
                 if (!no_reserve && !o_fast_hint && conv_est_ms < 4.0 * setup_est_ms && grid > resident - resident / 8) grid = resident - resident / 8;
             }
-            if (npt4)
+            bool launched = false;
+            if constexpr (sizeof(T) == 4) {
+                if (npt8) {
+                    hipLaunchKernelGGL((conv_normalize_kernel<float, 8>), dim3(grid), dim3(kBlock), 0, stream, P, d_src.p, d_src32.p, d_clusters.p, d_exptab.p,
+                                       sl.Y0.p, sl.Y1.p, sl.Y2.p);
+                    launched = true;
+                }
+            }
+            if (launched) {
+            } else if (npt4)
                 hipLaunchKernelGGL((conv_normalize_kernel<T, 4>), dim3(grid), dim3(kBlock), 0, stream, P, d_src.p, d_src32.p, d_clusters.p, d_exptab.p, sl.Y0.p,
                                    sl.Y1.p, sl.Y2.p);
             else

@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace shm {
 
 constexpr int kWave = 64;       // CDNA wavefront
@@ -170,6 +172,13 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
     // dx^2 + dy^2 of every source
     constexpr int kTileZ = (kBlock / 64) * NPT;
     constexpr bool kMixed = sizeof(T) == 8;
+    // fp32, 8 nodes per lane: the tile is culled as two halves of 16 planes (nodes e < 4 / e >= 4 of every lane), each with its own bounding sphere,
+    // nearest-source bound and exponent offset -- exactly the quantities of two NPT = 4 tiles, so the skipped set and every node's sum are those of the
+    // NPT = 4 kernel bit for bit, while the clusters both halves need (most of them where the kernel spans the object) share dx^2 + dy^2 and the LDS
+    // reads over 8 nodes instead of 4 (rocker 512^3: 484 -> 450 ms)
+    constexpr int kHalves = (!kMixed && NPT == 8) ? 2 : 1;
+    constexpr int kNH = NPT / kHalves;            // nodes of a lane per half
+    constexpr int kHalfPlanes = kTileZ / kHalves;
     // sources per LDS fill: 256 (4 clusters) in fp64, where the fill shares the LDS with the exponential table and the fp32 copy; 1024 (16 clusters,
     // 24 KB) in fp32, whose LDS is otherwise empty -- a quarter of the fills and barriers (rocker 512^3: 54 -> 14 per tile)
     constexpr int kChunk = kMixed ? kConvChunk : 4 * kConvChunk;
@@ -213,49 +222,54 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
         fx[e] = fy[e] = fz[e] = 0.f;
     }
     // tile centre / circumscribed radius, then the workgroup-wide minimum distance from the centre to the sources
-    constexpr double kHalfZ = 0.5 * (kTileZ - 1);
+    constexpr double kHalfZ = 0.5 * (kHalfPlanes - 1);
     const float cx = (float)((i0 + 3.5) * P.cell + P.bbox_min[0]), cy = (float)((j0 + 3.5) * P.cell + P.bbox_min[1]);
-    const float cz = (float)((P.k0 + kk0 - 1 + kHalfZ) * P.cell + P.bbox_min[2]);
     const float rt = (float)(sqrt(3.5 * 3.5 * 2 + kHalfZ * kHalfZ) * P.cell) * 1.000001f;
-    float dmin = 3.0e38f, wnear = 0.f;   // nearest source and |A N|^2 of it (ties -- the zero-weight padding repeats a source -- go to the larger weight)
-    for (int s = threadIdx.x; s < P.S; s += kBlock) {
-        const float dx = cx - (float)src[(size_t)s * 6], dy = cy - (float)src[(size_t)s * 6 + 1], dz = cz - (float)src[(size_t)s * 6 + 2];
-        const float wx = (float)src[(size_t)s * 6 + 3], wy = (float)src[(size_t)s * 6 + 4], wz = (float)src[(size_t)s * 6 + 5];
-        const float d2 = dx * dx + dy * dy + dz * dz, w2 = wx * wx + wy * wy + wz * wz;
-        if (d2 < dmin || (d2 == dmin && w2 > wnear)) {
-            dmin = d2;
-            wnear = w2;
-        }
-    }
+    float cz[kHalves], ln_anear[kHalves], r_hi[kHalves], d0t[kHalves];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float od = __shfl_xor(dmin, off, kWave), ow = __shfl_xor(wnear, off, kWave);
-        if (od < dmin || (od == dmin && ow > wnear)) {
-            dmin = od;
-            wnear = ow;
+    for (int h = 0; h < kHalves; h++) {
+        cz[h] = (float)((P.k0 + kk0 + h * kHalfPlanes - 1 + kHalfZ) * P.cell + P.bbox_min[2]);
+        float dmin = 3.0e38f, wnear = 0.f;   // nearest source and |A N|^2 of it (ties -- the zero-weight padding repeats a source -- go to the larger weight)
+        for (int s = threadIdx.x; s < P.S; s += kBlock) {
+            const float dx = cx - (float)src[(size_t)s * 6], dy = cy - (float)src[(size_t)s * 6 + 1], dz = cz[h] - (float)src[(size_t)s * 6 + 2];
+            const float wx = (float)src[(size_t)s * 6 + 3], wy = (float)src[(size_t)s * 6 + 4], wz = (float)src[(size_t)s * 6 + 5];
+            const float d2 = dx * dx + dy * dy + dz * dz, w2 = wx * wx + wy * wy + wz * wz;
+            if (d2 < dmin || (d2 == dmin && w2 > wnear)) {
+                dmin = d2;
+                wnear = w2;
+            }
         }
-    }
-    if ((threadIdx.x & 63) == 0) {
-        red[threadIdx.x >> 6] = dmin;
-        redw[threadIdx.x >> 6] = wnear;
-    }
-    __syncthreads();
-    dmin = red[0];
-    wnear = redw[0];
 #pragma unroll
-    for (int a = 1; a < kBlock / kWave; a++)
-        if (red[a] < dmin || (red[a] == dmin && redw[a] > wnear)) {
-            dmin = red[a];
-            wnear = redw[a];
+        for (int off = 32; off > 0; off >>= 1) {
+            const float od = __shfl_xor(dmin, off, kWave), ow = __shfl_xor(wnear, off, kWave);
+            if (od < dmin || (od == dmin && ow > wnear)) {
+                dmin = od;
+                wnear = ow;
+            }
         }
-    dmin = sqrtf(dmin);
-    const float ln_anear = 0.5f * __logf(fmaxf(wnear, 1e-37f)) - 1e-5f;   // rounded down
-    const float r_hi = dmin * 1.000001f + rt;                   // every node of the tile has a source at most this far
-    const float d0t = fmaxf(0.f, dmin * 0.999999f - rt);        // no source is closer than this to any node of the tile
+        if (h > 0) __syncthreads();   // the previous half's partials have been read
+        if ((threadIdx.x & 63) == 0) {
+            red[threadIdx.x >> 6] = dmin;
+            redw[threadIdx.x >> 6] = wnear;
+        }
+        __syncthreads();
+        dmin = red[0];
+        wnear = redw[0];
+#pragma unroll
+        for (int a = 1; a < kBlock / kWave; a++)
+            if (red[a] < dmin || (red[a] == dmin && redw[a] > wnear)) {
+                dmin = red[a];
+                wnear = redw[a];
+            }
+        dmin = sqrtf(dmin);
+        ln_anear[h] = 0.5f * __logf(fmaxf(wnear, 1e-37f)) - 1e-5f;   // rounded down
+        r_hi[h] = dmin * 1.000001f + rt;                   // every node of the (half) tile has a source at most this far
+        d0t[h] = fmaxf(0.f, dmin * 0.999999f - rt);        // no source is closer than this to any node of the (half) tile
+    }
 
     T d0[NPT];
 #pragma unroll
-    for (int e = 0; e < NPT; e++) d0[e] = kMixed ? (T)0 : (T)d0t;
+    for (int e = 0; e < NPT; e++) d0[e] = kMixed ? (T)0 : (T)d0t[e / kNH];
     if (!kMixed && P.exact_offset) {
         // coarse grid, fp32 solve: one extra sweep over the sources for the exact nearest distance of every node
         float m2[NPT];
@@ -290,27 +304,33 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
         // per cluster: lower bound of every (node of the tile, source of the cluster) distance minus the upper bound of the tile's distance
         // to its nearest source -- from the bounding spheres (uniform addresses: scalar loads), before anything is staged: a chunk whose
         // clusters are all negligible costs neither the LDS fill nor its barriers.  All branches below are workgroup-uniform.
-        auto cluster_gap = [&](int cc) {
-            const float* rec = clusters + (size_t)cc * kConvClusterRec;
-            const float gdx = cx - rec[0], gdy = cy - rec[1], gdz = cz - rec[2];
-            return sqrtf(gdx * gdx + gdy * gdy + gdz * gdz) * 0.999999f - rt - rec[3] - r_hi;
+        auto record_gap = [&](const float* rec, int h) {
+            const float gdx = cx - rec[0], gdy = cy - rec[1], gdz = cz[h] - rec[2];
+            return sqrtf(gdx * gdx + gdy * gdy + gdz * gdz) * 0.999999f - rt - rec[3] - r_hi[h];
         };
         {   // the whole fill first: its bounding sphere contains every cluster's and its weight bounds theirs, so passing this test implies every
             // cluster of the fill passes its own (same skipped set, one test instead of kChunk -- two thirds of the fills at SprayBottle 1024^3)
             const float* rec = clusters + (size_t)(P.n_clusters + c0 / kChunk) * kConvClusterRec;
-            const float gdx = cx - rec[0], gdy = cy - rec[1], gdz = cz - rec[2];
-            const float gapf = sqrtf(gdx * gdx + gdy * gdy + gdz * gdz) * 0.999999f - rt - rec[3] - r_hi;
-            if (gapf > (P.skip_base + rec[4] - ln_anear) * P.inv_lambda) continue;
+            bool all_skipped = true;
+#pragma unroll
+            for (int h = 0; h < kHalves; h++) all_skipped = all_skipped && record_gap(rec, h) > (P.skip_base + rec[4] - ln_anear[h]) * P.inv_lambda;
+            if (all_skipped) continue;
         }
-        unsigned skipmask = 0, farmask = 0;   // bit c: cluster c0 + c is skipped (all its terms together are below the rounding unit of the dominant term) / far
+        // bit c: cluster c0 + c is skipped for that half (all its terms together are below the rounding unit of the half's dominant term) / far
+        unsigned skipmask[kHalves], farmask = 0;
+#pragma unroll
+        for (int h = 0; h < kHalves; h++) skipmask[h] = 0;
         bool any = false;
         for (int c = 0; c < ncl; c++) {
             const float* rec = clusters + (size_t)(c0 + c) * kConvClusterRec;
-            const float gap = cluster_gap(c0 + c);
-            const bool sk = gap > (P.skip_base + rec[4] - ln_anear) * P.inv_lambda;
-            skipmask |= sk ? (1u << c) : 0u;
-            farmask |= (kMixed && gap > P.far_gap) ? (1u << c) : 0u;
-            any = any || !sk;
+#pragma unroll
+            for (int h = 0; h < kHalves; h++) {
+                const float gap = record_gap(rec, h);
+                const bool sk = gap > (P.skip_base + rec[4] - ln_anear[h]) * P.inv_lambda;
+                skipmask[h] |= sk ? (1u << c) : 0u;
+                if (h == 0) farmask |= (kMixed && gap > P.far_gap) ? (1u << c) : 0u;
+                any = any || !sk;
+            }
         }
         if (!any) continue;
         __syncthreads();
@@ -321,7 +341,8 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
         __syncthreads();
 #pragma unroll 1
         for (int c = 0; c < ncl; c++) {
-            if ((skipmask >> c) & 1u) continue;
+            const bool sk0 = (skipmask[0] >> c) & 1u, sk1 = (skipmask[kHalves - 1] >> c) & 1u;
+            if (sk0 && sk1) continue;
             const bool far = (farmask >> c) & 1u;
             if (far) {
 #pragma unroll 2
@@ -335,7 +356,7 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
                         const float dz = qz[e] - sz;
                         float r, rinv;
                         YukawaMath<float>::rsqrt_and_sqrt(dxy2 + dz * dz, rinv, r);
-                        const float g = YukawaMath<float>::exp_neg(-lamf * (r - d0t)) * rinv;
+                        const float g = YukawaMath<float>::exp_neg(-lamf * (r - d0t[0])) * rinv;
                         fx[e] += wx * g; fy[e] += wy * g; fz[e] += wz * g;
                     }
                 }
@@ -357,33 +378,41 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
                 // fp32: the lane's nodes two at a time in packed registers (v_pk_add/mul/fma_f32: two values per issue slot); per pair
                 // of nodes and source: 8 packed + 2 v_rsq_f32 + 2 v_exp_f32.  exp(-lambda (r - d0)) = 2^(r c + c0), c = -lambda log2(e).
                 static_assert(NPT % 2 == 0, "packed fp32 path handles the lane's nodes in pairs");
+                auto sweep = [&](auto e_begin, auto e_end) {   // nodes [e_begin, e_end) of every lane against cluster c
+                    constexpr int E0 = decltype(e_begin)::value, E1 = decltype(e_end)::value;
 #pragma unroll 2
-                for (int s = c * kConvCluster; s < (c + 1) * kConvCluster; s++) {
-                    const float sz = tile[6 * s + 2];
-                    const float wx = tile[6 * s + 3], wy = tile[6 * s + 4], wz = tile[6 * s + 5];
-                    const float dx = px - tile[6 * s], dy = py - tile[6 * s + 1];
-                    const float dxy2 = dx * dx + dy * dy;
+                    for (int s = c * kConvCluster; s < (c + 1) * kConvCluster; s++) {
+                        const float sz = tile[6 * s + 2];
+                        const float wx = tile[6 * s + 3], wy = tile[6 * s + 4], wz = tile[6 * s + 5];
+                        const float dx = px - tile[6 * s], dy = py - tile[6 * s + 1];
+                        const float dxy2 = dx * dx + dy * dy;
 #pragma unroll
-                    for (int e = 0; e < NPT; e += 2) {
-                        const float2v z2 = {pz[e], pz[e + 1]}, c02 = {coff[e], coff[e + 1]};
-                        const float2v dz = z2 - sz;
-                        const float2v d2 = __builtin_elementwise_fma(dz, dz, float2v{dxy2, dxy2});
-                        const float2v rinv = {__builtin_amdgcn_rsqf(d2.x), __builtin_amdgcn_rsqf(d2.y)};   // r = 0 -> inf -> NaN below
-                        const float2v r = d2 * rinv;
-                        const float2v arg = __builtin_elementwise_fma(r, float2v{cexp32, cexp32}, c02);
-                        const float2v ex = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
-                        const float2v g = ex * rinv;
-                        float2v a;
-                        a = __builtin_elementwise_fma(float2v{wx, wx}, g, float2v{ax[e], ax[e + 1]}); ax[e] = a.x; ax[e + 1] = a.y;
-                        a = __builtin_elementwise_fma(float2v{wy, wy}, g, float2v{ay[e], ay[e + 1]}); ay[e] = a.x; ay[e + 1] = a.y;
-                        a = __builtin_elementwise_fma(float2v{wz, wz}, g, float2v{az[e], az[e + 1]}); az[e] = a.x; az[e + 1] = a.y;
+                        for (int e = E0; e < E1; e += 2) {
+                            const float2v z2 = {pz[e], pz[e + 1]}, c02 = {coff[e], coff[e + 1]};
+                            const float2v dz = z2 - sz;
+                            const float2v d2 = __builtin_elementwise_fma(dz, dz, float2v{dxy2, dxy2});
+                            const float2v rinv = {__builtin_amdgcn_rsqf(d2.x), __builtin_amdgcn_rsqf(d2.y)};   // r = 0 -> inf -> NaN below
+                            const float2v r = d2 * rinv;
+                            const float2v arg = __builtin_elementwise_fma(r, float2v{cexp32, cexp32}, c02);
+                            const float2v ex = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+                            const float2v g = ex * rinv;
+                            float2v a;
+                            a = __builtin_elementwise_fma(float2v{wx, wx}, g, float2v{ax[e], ax[e + 1]}); ax[e] = a.x; ax[e + 1] = a.y;
+                            a = __builtin_elementwise_fma(float2v{wy, wy}, g, float2v{ay[e], ay[e + 1]}); ay[e] = a.x; ay[e + 1] = a.y;
+                            a = __builtin_elementwise_fma(float2v{wz, wz}, g, float2v{az[e], az[e + 1]}); az[e] = a.x; az[e + 1] = a.y;
+                        }
                     }
-                }
+                };
+                using std::integral_constant;
+                if constexpr (kHalves == 1) sweep(integral_constant<int, 0>{}, integral_constant<int, NPT>{});
+                else if (!sk0 && !sk1) sweep(integral_constant<int, 0>{}, integral_constant<int, NPT>{});
+                else if (!sk0) sweep(integral_constant<int, 0>{}, integral_constant<int, kNH>{});
+                else sweep(integral_constant<int, kNH>{}, integral_constant<int, NPT>{});
             }
         }
     }
     if (kMixed) {
-        const double e0 = YukawaMath<double>::exp_neg(-P.lambda * (double)d0t);
+        const double e0 = YukawaMath<double>::exp_neg(-P.lambda * (double)d0t[0]);
 #pragma unroll
         for (int e = 0; e < NPT; e++) {
             ax[e] += (T)((double)fx[e] * e0);
