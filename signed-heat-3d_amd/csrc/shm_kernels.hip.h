@@ -308,7 +308,7 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
             const float gdx = cx - rec[0], gdy = cy - rec[1], gdz = cz[h] - rec[2];
             return sqrtf(gdx * gdx + gdy * gdy + gdz * gdz) * 0.999999f - rt - rec[3] - r_hi[h];
         };
-        {   // the whole fill first: its bounding sphere contains every cluster's and its weight bounds theirs, so passing this test implies every
+        if constexpr (!kMixed) {   // the whole fill first: its bounding sphere contains every cluster's and its weight bounds theirs, so passing this test implies every
             // cluster of the fill passes its own (same skipped set, one test instead of kChunk -- two thirds of the fills at SprayBottle 1024^3)
             const float* rec = clusters + (size_t)(P.n_clusters + c0 / kChunk) * kConvClusterRec;
             bool all_skipped = true;
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
             if (all_skipped) continue;
         }
         // bit c: cluster c0 + c is skipped for that half (all its terms together are below the rounding unit of the half's dominant term) / far
-        unsigned skipmask[kHalves], farmask = 0;
+        unsigned skipmask[kHalves];
 #pragma unroll
         for (int h = 0; h < kHalves; h++) skipmask[h] = 0;
         bool any = false;
@@ -328,7 +328,6 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
                 const float gap = record_gap(rec, h);
                 const bool sk = gap > (P.skip_base + rec[4] - ln_anear[h]) * P.inv_lambda;
                 skipmask[h] |= sk ? (1u << c) : 0u;
-                if (h == 0) farmask |= (kMixed && gap > P.far_gap) ? (1u << c) : 0u;
                 any = any || !sk;
             }
         }
@@ -343,7 +342,9 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
         for (int c = 0; c < ncl; c++) {
             const bool sk0 = (skipmask[0] >> c) & 1u, sk1 = (skipmask[kHalves - 1] >> c) & 1u;
             if (sk0 && sk1) continue;
-            const bool far = (farmask >> c) & 1u;
+            // (fp64: classified here, from the scalar record, not from a mask built above -- with the mask the compiler schedules the fp64 loop
+            // below into 165 instead of 241 registers and Step 1 takes 44.0 instead of 40.8 ms at 256^3)
+            const bool far = kMixed && record_gap(clusters + (size_t)(c0 + c) * kConvClusterRec, 0) > P.far_gap;
             if (far) {
 #pragma unroll 2
                 for (int s = c * kConvCluster; s < (c + 1) * kConvCluster; s++) {
