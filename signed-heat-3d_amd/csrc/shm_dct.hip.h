@@ -199,13 +199,16 @@ __device__ __forceinline__ void dct_fft_wave(Cplx<TP>* buf, const Cplx<TP>* tw, 
 // Occupancy the register allocator is held to for the long transforms: two waves per SIMD (= two tiles per CU) when the LDS footprint
 // allows them.  Without it the n = 512 fp64 kernels land just above 256 registers, i.e. one tile per CU; asking for more than two
 // (fp32 tiles are half the size) makes the allocator spill.
+#ifndef SHM_DCT_SEG9_ONE_WAVE
+#define SHM_DCT_SEG9_ONE_WAVE 1
+#endif
 template <int LOG2N, int CPLX_BYTES> constexpr int dct_waves_per_simd() {
     constexpr int by_lds = (int)((size_t)(160 * 1024) / dct_lds_bytes<LOG2N, CPLX_BYTES / 2>());
     constexpr int want = LOG2N <= 8 ? (SHM_DCT_WAVES_256 > 0 ? SHM_DCT_WAVES_256 : 1) : (CPLX_BYTES == 8 ? SHM_DCT_WAVES_F32 : 2);
     return by_lds >= want ? want : (by_lds >= 1 ? by_lds : 1);
 }
 template <typename TP, typename TIn, typename TOut, int MODE, bool DOT, int LOG2N, bool XPASS, bool SEG>
-__global__ __launch_bounds__(kBlock, ((LOG2N >= SHM_DCT_WAVES_HINT || SHM_DCT_WAVES_256 > 0) ? dct_waves_per_simd<LOG2N, (int)sizeof(Cplx<TP>)>() : 1)) void dct_lines_kernel(DctParams P, const TIn* __restrict__ in, TOut* __restrict__ out,
+__global__ __launch_bounds__(kBlock, ((LOG2N >= SHM_DCT_WAVES_HINT || SHM_DCT_WAVES_256 > 0) && !(SHM_DCT_SEG9_ONE_WAVE && SEG && LOG2N == 9 && sizeof(TP) == 8) ? dct_waves_per_simd<LOG2N, (int)sizeof(Cplx<TP>)>() : 1)) void dct_lines_kernel(DctParams P, const TIn* __restrict__ in, TOut* __restrict__ out,
                                                            const Cplx<TP>* __restrict__ tw_g, const Cplx<TP>* __restrict__ om_g,
                                                            const TP* __restrict__ lam_g, const TOut* __restrict__ dot_with,
                                                            double* __restrict__ partials, const int* __restrict__ tile_list /* nullptr: all tiles */,
