@@ -381,7 +381,7 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
                 static_assert(NPT % 2 == 0, "packed fp32 path handles the lane's nodes in pairs");
                 auto sweep = [&](auto e_begin, auto e_end) {   // nodes [e_begin, e_end) of every lane against cluster c
                     constexpr int E0 = decltype(e_begin)::value, E1 = decltype(e_end)::value;
-#pragma unroll 2
+#pragma unroll(NPT == 8 ? 4 : 2)   // four sources in flight: 228 registers, two waves per SIMD, rocker 512^3 474 -> 455 ms (8: 480, 6: 460)
                     for (int s = c * kConvCluster; s < (c + 1) * kConvCluster; s++) {
                         const float sz = tile[6 * s + 2];
                         const float wx = tile[6 * s + 3], wy = tile[6 * s + 4], wz = tile[6 * s + 5];

@@ -194,8 +194,8 @@ def test_kernel_register_schedules():
     assert not spilled, spilled
     conv = by_name["void shm::conv_normalize_kernel<double, 4>"]
     assert conv["VGPRs"] >= 200 and conv["Occupancy"] == 2, conv
-    conv32 = by_name["void shm::conv_normalize_kernel<float, 8>"]
-    assert conv32["Occupancy"] >= 3, conv32
+    conv32 = by_name["void shm::conv_normalize_kernel<float, 8>"]   # four sources in flight
+    assert conv32["VGPRs"] >= 200 and conv32["Occupancy"] == 2, conv32
     for k, v in by_name.items():   # the shipped shape of the fused stencil-CG sweeps: two rows per lane, four waves per SIMD
         if re.match(r"void shm::cg_fused_kernel<(double, 2|float, 4), 2, ", k):
             assert v["Occupancy"] >= 4, (k, v)
