@@ -29,7 +29,11 @@ def setup_alone_ms(m, host_ms):
 
 
 def main():
-    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    text = open(sys.argv[1]).read().strip()
+    try:
+        d = json.loads(text)                      # profiles/*.json (pretty-printed)
+    except ValueError:
+        d = json.loads(text.splitlines()[-1])     # raw bench.py output: the JSON line is the last one
     ph, cfg = d["phases_ms"], d["config"]
     n = int(cfg["grid"].split("^")[0])
     T = 8 if d["dtype"] == "f64" else 4
