@@ -31,6 +31,7 @@
 #include "shm_kernels.hip.h"
 #include "shm_cg_fused.hip.h"
 #include "shm_twolevel.hip.h"
+#include "shm_schur.hip.h"
 #include "shm_dct.hip.h"
 
 namespace shm {
@@ -171,6 +172,8 @@ static float elapsed(Event& a, Event& b) {
 struct Row {
     int64_t nodes[8];
     double coeffs[8];
+    int cell[3];   // (i, j, k) of the cell and the trilinear parameters of the sample point in it: the separable form of coeffs
+    double t[3];   // that the explicit Schur complement (shm_schur.hip.h) is assembled from
 };
 
 struct SolverBase {
@@ -185,6 +188,7 @@ struct SolverBase {
     virtual void get_constraints(int64_t*, double*, int32_t*) = 0;
     virtual void apply_projector(double*) = 0;
     virtual void apply_preconditioner(const double*, double*) = 0;
+    virtual void get_schur(double*, int32_t*) = 0;
     virtual void isosurface(double, int64_t*, int64_t*) = 0;
     virtual void get_isosurface(double*, int64_t*) = 0;
 };
@@ -219,6 +223,8 @@ struct Solver final : SolverBase {
     shm_config cfg;
     hipStream_t stream = nullptr;   // conv, divergence, CG
     hipStream_t stream2 = nullptr;  // constraint set-up ((A A^T)^-1), overlapped with the Step-1 kernel
+    hipStream_t stream3 = nullptr;  // explicit Schur complement of the dual solver: beside the inversion of G (stream2) and Step 1 (created on first use)
+    std::unique_ptr<Event> e_sch_in, e_sch_done;
     hipStream_t stream_h = nullptr;  // halo exchange of the fused primal CG, overlapped with the interior z chunks of its DIR sweep (created on first use)
     int n = 0, alloc_n = -1;
     size_t N = 0;
@@ -268,6 +274,16 @@ struct Solver final : SolverBase {
     DevArray<Cplx<TP>> d_tw, d_om;
     DevArray<TP> d_lam;
     DevArray<double> d_lam64;  // the same eigenvalues in double (zsolve_sparse_kernel computes in double whatever T)
+    // explicit Schur complement S = A K^+ A^T of the dual solver (shm_schur.hip.h): image-sum Green's table T and its work arrays, the per-row cells /
+    // trilinear parameters, S itself (mp x mp, zero-padded)
+    DevArray<double> gs_lam, gs_ctab, gs_Cm, gs_Ct, gs_W0, gs_W1, gs_W2, gs_T, Sdense, d_rowT;
+    DevArray<int> d_rowX;
+    std::vector<double> h_gs_lam, h_gs_ctab, h_rowT;   // host staging outlives the asynchronous uploads
+    std::vector<int> h_rowX;
+    bool have_S = false;
+    double conv_est_total_ms = 1e30;   // estimate of this rank's last Step-1 launch (1e30: none was launched -- stand-alone set-up, test entry points)
+    int gs_n = 0, schur_table_builds = 0;   // grid the Green's table in gs_T was built for (0: none)
+    double gs_cell = 0.;
     int log2n = 0;
     bool precond_ready = false;
     double* h_pinned = nullptr;
@@ -317,6 +333,7 @@ struct Solver final : SolverBase {
         slabs.clear();
         if (stream) (void)hipStreamDestroy(stream);
         if (stream2) (void)hipStreamDestroy(stream2);
+        if (stream3) (void)hipStreamDestroy(stream3);
         if (stream_h) (void)hipStreamDestroy(stream_h);
     }
 
@@ -601,7 +618,9 @@ struct Solver final : SolverBase {
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, kBlock, 0) != hipSuccess || occ < 1) occ = 2;
                 const unsigned resident = (unsigned)(occ * num_cus);
                 const double pairs = (double)sl.nown * (double)S;
-                const double conv_est_ms = pairs / (sizeof(T) == 8 ? 1.2e9 : 3.5e9), setup_est_ms = 2.2e-3 * (double)std::min<int64_t>(S, (int64_t)8 * n * n);
+                const double conv_est_ms = pairs / (sizeof(T) == 8 ? 1.2e9 : 3.5e9);
+                conv_est_total_ms = (&sl == &slabs[0] ? 0. : conv_est_total_ms) + conv_est_ms;
+                const double setup_est_ms = 2.2e-3 * (double)std::min<int64_t>(S, (int64_t)8 * n * n);
                 static const bool no_reserve = getenv("SHM_CONV_NO_RESERVE") != nullptr;  // A/B knob
                 if (!no_reserve && !o_fast_hint && conv_est_ms < 4.0 * setup_est_ms && grid > resident - resident / 8) grid = resident - resident / 8;
             }
@@ -689,6 +708,8 @@ struct Solver final : SolverBase {
             r.coeffs[5] = tx * (1. - ty) * tz;
             r.coeffs[6] = (1. - tx) * ty * tz;
             r.coeffs[7] = tx * ty * tz;
+            r.cell[0] = (int)i; r.cell[1] = (int)j; r.cell[2] = (int)k;
+            r.t[0] = tx; r.t[1] = ty; r.t[2] = tz;
             rows.push_back(r);
         }
         m = (int)rows.size();
@@ -850,8 +871,11 @@ struct Solver final : SolverBase {
                                d_tval.p, Ginv.p);
             HIPCHK(hipGetLastError());
         }
+        prepare_schur();
         enqueue_invert_G();
         lap("G uploaded, inversion enqueued");
+        enqueue_schur();
+        lap("explicit S enqueued");
 
         // ---- host work that the inversion does not need, while the GPU inverts
         std::vector<int> bptr(m + 1, 0), bcol;
@@ -1213,6 +1237,115 @@ struct Solver final : SolverBase {
         if (nb > 1) hipLaunchKernelGGL(gj_mirror_kernel, dim3((unsigned)((size_t)nb * (nb - 1) / 2)), dim3(kBlock), 0, stream, Ginv.p, mp);
         hipLaunchKernelGGL((convert_kernel<double, float>), dim3(grid_for((size_t)mp * mp, 4096)), dim3(kBlock), 0, stream, (size_t)mp * mp, Ginv.p, Ginv32.p);
         HIPCHK(hipGetLastError());
+    }
+    // S = A K^+ A^T explicitly (shm_schur.hip.h), on the set-up stream.  For one slab, a DCT-sized grid and a moderate number of rows.
+    //   prepare_schur(): host tables and their uploads -- BEFORE the inversion of G is queued (a pageable copy waits for everything queued on its stream)
+    //   enqueue_schur(): the launches -- AFTER it (the inversion is a chain of short dependent kernels; these few throughput-bound ones fill the slots it
+    //                    leaves idle)
+    // The Green's table T depends on the grid alone (n, h) -- it is to K what the reference's poissonSolver factorisation is to L, built when the grid is
+    // built (signed_heat_grid_solver.cpp:8-35, `rebuild`) -- so it is kept while n and h stay the same; S depends on the sources and is assembled per solve.
+    bool schur_wanted() const {
+        static const bool off = getenv("SHM_DUAL_NO_DENSE_S") != nullptr;   // A/B knob: apply S through the grid (five sparse sweeps) as before
+        static const int max_m = getenv("SHM_DENSE_S_MAX_M") ? atoi(getenv("SHM_DENSE_S_MAX_M")) : 16384;
+        if (off || total_slabs != 1 || !precond_available() || m <= 0 || m > max_m || n > 512) return false;
+        // the assembly (216 table reads per entry: ~3.1e-7 ms per m^2 on an idle device, measured 2.5 ms at m = 2842, 41 ms at m = 12 612) has to hide behind
+        // this rank's Step 1 like the rest of the set-up; where Step 1 is short (<= 128^3, or a thin slab of a multi-GPU run) the sweeps through the grid are
+        // cheap anyway (0.11 ms per iteration at 128^3) and the set-up is the critical path already
+        static const bool force = getenv("SHM_DUAL_DENSE_S_ALWAYS") != nullptr;
+        const double schur_est_ms = 3.1e-7 * (double)m * (double)m;
+        return force || conv_est_total_ms >= 3.0 * schur_est_ms;
+    }
+    void prepare_schur() {
+        hipStream_t st = stream2;
+        have_S = false;
+        if (!schur_wanted()) return;
+        const int P = n + 8;   // leading dimension of the last table index (rows stay 64-byte aligned)
+        const size_t n1 = (size_t)n + 1;
+        if (!(gs_n == n && gs_cell == cell)) {
+            gs_n = 0;   // (table invalid until enqueue_schur has queued its construction)
+            const double pi = 3.14159265358979323846;
+            h_gs_lam.resize(n);
+            h_gs_ctab.resize(2 * (size_t)n);
+            for (int k = 0; k < n; k++) h_gs_lam[k] = (2. - 2. * std::cos(pi * k / n)) / (cell * cell);   // the transforms' eigenvalues (setup_precond)
+            for (int r = 0; r < 2 * n; r++) h_gs_ctab[r] = std::cos(pi * r / n);
+            gs_lam.upload(h_gs_lam, st);
+            gs_ctab.upload(h_gs_ctab, st);
+            gs_T.alloc(n1 * n1 * P);
+        }
+        // rows in Morton order of their cells: the 16 x 16 tiles of the assembly then read neighbouring table entries
+        std::vector<std::pair<uint64_t, int>> key((size_t)m);
+        auto spread = [](uint64_t v) {
+            v &= 0x1fffff;
+            v = (v | v << 32) & 0x1f00000000ffffULL;
+            v = (v | v << 16) & 0x1f0000ff0000ffULL;
+            v = (v | v << 8) & 0x100f00f00f00f00fULL;
+            v = (v | v << 4) & 0x10c30c30c30c30c3ULL;
+            v = (v | v << 2) & 0x1249249249249249ULL;
+            return v;
+        };
+        for (int r = 0; r < m; r++) key[(size_t)r] = {spread((uint64_t)rows[r].cell[0]) | spread((uint64_t)rows[r].cell[1]) << 1 | spread((uint64_t)rows[r].cell[2]) << 2, r};
+        std::sort(key.begin(), key.end());
+        h_rowX.resize(4 * (size_t)m);
+        h_rowT.resize(3 * (size_t)m);
+        for (int q = 0; q < m; q++) {
+            const int r = key[(size_t)q].second;
+            for (int a = 0; a < 3; a++) {
+                h_rowX[4 * (size_t)q + a] = rows[r].cell[a];
+                h_rowT[3 * (size_t)q + a] = rows[r].t[a];
+            }
+            h_rowX[4 * (size_t)q + 3] = r;   // the row this sorted slot stands for
+        }
+        d_rowX.upload(h_rowX, st);
+        d_rowT.upload(h_rowT, st);
+        Sdense.alloc((size_t)mp * mp);
+        if (!stream3) {
+            int least = 0, greatest = 0;
+            HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIPCHK(hipStreamCreateWithPriority(&stream3, hipStreamNonBlocking, greatest));
+            e_sch_in.reset(new Event());
+            e_sch_done.reset(new Event());
+        }
+        e_sch_in->record(st);   // the tables are on the device
+    }
+    void enqueue_schur() {
+        if (!schur_wanted()) return;
+        // its own stream: the inversion of G on stream2 is a chain of ~135 short launches that each wait for a slot next to Step 1 (39 of Step 1's 40 ms at
+        // 256^3); queued behind it the assembly would start when Step 1 is almost over and be exposed, beside it it is done long before
+        hipStream_t st = stream3;
+        HIPCHK(hipStreamWaitEvent(st, e_sch_in->e, 0));
+        const int P = n + 8;
+        const size_t n1 = (size_t)n + 1;
+        if (!(gs_n == n && gs_cell == cell)) {
+            DevArray<double>&W0 = gs_W0, &W1 = gs_W1, &W2 = gs_W2;
+            gs_Cm.alloc(n1 * n);
+            gs_Ct.alloc((size_t)n * P);
+            W0.alloc((size_t)n * n * n);
+            W1.alloc((size_t)n * n * P);
+            W2.alloc((size_t)n * n1 * P);
+            HIPCHK(hipMemsetAsync(gs_Ct.p, 0, (size_t)n * P * sizeof(double), st));
+            hipLaunchKernelGGL(cosine_tables_kernel, dim3(grid_for(n1 * n, 1024)), dim3(kBlock), 0, st, n, P, gs_ctab.p, gs_Cm.p, gs_Ct.p);
+            hipLaunchKernelGGL(green_symbol_kernel, dim3(grid_for((size_t)n * n * n, 4096)), dim3(kBlock), 0, st, n, gs_lam.p, W0.p);
+            auto tiles = [](size_t v) { return (unsigned)((v + kGJ - 1) / kGJ); };
+            // W1[(k1,k2)][d3] = sum_k3 W0[(k1,k2)][k3] Ct[k3][d3]
+            hipLaunchKernelGGL(dgemm_rm_kernel, dim3(tiles(P), tiles((size_t)n * n), 1), dim3(kBlock), 0, st, n * n, P, n, W0.p, n, 0LL, gs_Ct.p, P, 0LL, W1.p, P, 0LL);
+            // W2[k1][d2][d3] = sum_k2 Cm[d2][k2] W1[k1][k2][d3]   (one product per k1)
+            hipLaunchKernelGGL(dgemm_rm_kernel, dim3(tiles(P), tiles(n1), (unsigned)n), dim3(kBlock), 0, st, (int)n1, P, n, gs_Cm.p, n, 0LL, W1.p, P, (long long)n * P, W2.p, P,
+                               (long long)(n1 * P));
+            // T[d1][(d2,d3)] = sum_k1 Cm[d1][k1] W2[k1][(d2,d3)]
+            hipLaunchKernelGGL(dgemm_rm_kernel, dim3(tiles(n1 * P), tiles(n1), 1), dim3(kBlock), 0, st, (int)n1, (int)(n1 * P), n, gs_Cm.p, n, 0LL, W2.p, (int)(n1 * P), 0LL,
+                               gs_T.p, (int)(n1 * P), 0LL);
+            HIPCHK(hipGetLastError());
+            gs_n = n;
+            gs_cell = cell;
+            schur_table_builds++;
+        }
+        HIPCHK(hipMemsetAsync(Sdense.p, 0, (size_t)mp * mp * sizeof(double), st));
+        const unsigned mt = (unsigned)((m + 15) / 16);
+        hipLaunchKernelGGL(schur_assemble_kernel, dim3(mt, mt), dim3(kBlock), 0, st, m, mp, n, P, d_rowX.p, d_rowT.p, gs_T.p, Sdense.p);
+        HIPCHK(hipGetLastError());
+        e_sch_done->record(st);
+        HIPCHK(hipStreamWaitEvent(stream2, e_sch_done->e, 0));   // "set-up done" on stream2 (what the solve waits for) now includes S
+        have_S = true;
     }
     void finish_invert_G() {
         hipStream_t stream = stream2;
@@ -1817,10 +1950,18 @@ struct Solver final : SolverBase {
         }
         // ---- r = Pm(g - S mu), z, p
         const bool sparse_ok = total_slabs == 1 && slabs[0].n_act_x > 0 && !getenv("SHM_DENSE_DCT");
-        scatter(V_MU, ARR_P, 0);
-        if (sparse_ok) launch_precond_sparse(ARR_P, ARR_Z);
-        else launch_precond(false, ARR_P, ARR_Z);
-        gather(ARR_Z);
+        const bool dense_S = have_S && total_slabs == 1 && !comm;   // explicit S (shm_schur.hip.h): one dense mat-vec instead of scatter, five sweeps, gather
+        auto apply_S = [&](int vec) {   // red[1..m] = S v
+            Slab<T>& sl = slabs[0];
+            hipLaunchKernelGGL(ginv_matvec_kernel<double>, dim3(m), dim3(kBlock), 0, stream, m, mp, Sdense.p, mv(sl, vec), sl.red.p + 1);
+        };
+        if (dense_S) apply_S(V_MU);
+        else {
+            scatter(V_MU, ARR_P, 0);
+            if (sparse_ok) launch_precond_sparse(ARR_P, ARR_Z);
+            else launch_precond(false, ARR_P, ARR_Z);
+            gather(ARR_Z);
+        }
         for (Slab<T>& sl : slabs)
             hipLaunchKernelGGL(dual_init_residual_kernel, dim3(1), dim3(kDualBlock), 0, stream, m, mv(sl, V_G), sl.red.p + 1, mv(sl, V_R), sl.sc.p);
         precondition(1);
@@ -1836,12 +1977,13 @@ struct Solver final : SolverBase {
             const int batch_end = std::min(o.max_iters, it + check_every);
             for (; it < batch_end; it++) {
                 const bool sample = st && nsamples < kMaxSamples;
-                scatter(V_P, ARR_P, 0);
+                if (!dense_S) scatter(V_P, ARR_P, 0);
                 if (sample) ev[3 * nsamples]->record(stream);
-                if (sparse_ok) launch_precond_sparse(ARR_P, ARR_Z);
+                if (dense_S) apply_S(V_P);
+                else if (sparse_ok) launch_precond_sparse(ARR_P, ARR_Z);
                 else launch_precond(false, ARR_P, ARR_Z);
                 if (sample) ev[3 * nsamples + 1]->record(stream);
-                gather(ARR_Z);
+                if (!dense_S) gather(ARR_Z);
                 for (Slab<T>& sl : slabs)
                     hipLaunchKernelGGL(dual_update_kernel, dim3(1), dim3(kDualBlock), 0, stream, m, sl.red.p + 1, mv(sl, V_P), mv(sl, V_MU), mv(sl, V_R), sl.sc.p);
                 precondition(0);
@@ -1906,7 +2048,9 @@ struct Solver final : SolverBase {
             st->kernel_samples = nsamples;
             st->preconditioner = SHM_PRECOND_DCT;
             st->solver = total_slabs > 1 ? SHM_SOLVER_DUAL_SLABS : SHM_SOLVER_DUAL;
-            if (sparse_ok) {  // bytes the five sparse sweeps actually move: active x tiles, active planes (y sweeps and the masked z sweep)
+            if (dense_S) {  // S (fp64) once, the single-precision G^-1 twice
+                st->bytes_per_iter = (double)m * m * (sizeof(double) + 2.0 * sizeof(float));
+            } else if (sparse_ok) {  // bytes the five sparse sweeps actually move: active x tiles, active planes (y sweeps and the masked z sweep)
                 const double L = dct_lines_for(log2n, (int)sizeof(TP)), tile_bytes = L * n * sizeof(TP);
                 const double planes_active = (double)slabs[0].n_act_y / (n / L);
                 st->bytes_per_iter = 4.0 * slabs[0].n_act_x * tile_bytes + 4.0 * slabs[0].n_act_y * tile_bytes + 2.0 * planes_active * n * n * sizeof(TP);
@@ -1930,6 +2074,7 @@ struct Solver final : SolverBase {
         Slab<T>& fs = F.slabs[0];
         Event c_s2a, c_s2b, e_gather, f_start, f_setup;
         c_s2a.record(F.stream2);
+        F.conv_est_total_ms = conv_est_total_ms;   // what the whole-grid solver's set-up can hide behind is this rank's share of Step 1
         F.build_constraints();  // on the whole-grid solver's set-up stream: overlaps this rank's Step-1 kernel
         c_s2b.record(F.stream2);
         F.setup_precond();
@@ -2410,6 +2555,17 @@ struct Solver final : SolverBase {
         *m_out = m;
     }
 
+    void get_schur(double* out, int32_t* m_out) override {   // test entry point: the explicit S = A K^+ A^T the dual solver would use (m x m, row-major)
+        need_problem();
+        if (cfg.world != 1) throw Error(SHM_ERR_INVALID, "get_schur is a single-process test entry point");
+        HIPCHK(hipSetDevice(cfg.device));
+        build_constraints();
+        *m_out = m;
+        if (!have_S) throw Error(SHM_ERR_STATE, "no explicit Schur complement for this problem (several slabs, n not a power of two or > 512, or too many rows)");
+        HIPCHK(hipMemcpy2DAsync(out, (size_t)m * sizeof(double), Sdense.p, (size_t)mp * sizeof(double), (size_t)m * sizeof(double), (size_t)m, hipMemcpyDeviceToHost, stream2));
+        HIPCHK(hipStreamSynchronize(stream2));
+    }
+
     void apply_projector(double* v) override {
         need_problem();
         if (cfg.world != 1) throw Error(SHM_ERR_INVALID, "apply_projector is a single-process test entry point");
@@ -2634,6 +2790,12 @@ shm_status shm_grid_get_constraints(shm_solver* s, int64_t* nodes, double* coeff
     return guard(s, [&] {
         if (!nodes || !coeffs || !m) throw shm::Error(SHM_ERR_INVALID, "null argument");
         s->impl->get_constraints(nodes, coeffs, m);
+    });
+}
+shm_status shm_grid_get_schur(shm_solver* s, double* out, int32_t* m) {
+    return guard(s, [&] {
+        if (!out || !m) throw shm::Error(SHM_ERR_INVALID, "null argument");
+        s->impl->get_schur(out, m);
     });
 }
 shm_status shm_grid_apply_projector(shm_solver* s, double* v) {

@@ -1,0 +1,147 @@
+// Explicit Schur complement S = A K^+ A^T of the dual solver (signed_heat_grid_solver.cpp:101-107 replaced by CG on S, see the block comment above
+// dual_init_mu_kernel) for moderate constraint counts.
+//
+// Applying S through the grid costs five transform sweeps per iteration (256^3: 0.1 ms, 512^3: 0.8 ms) although p and S p live on m ~ 3000 rows.
+// K^+ is the Neumann Green's function of the 7-point Laplacian, diagonal in the DCT-II basis, and the product formula
+// cos a cos b = (cos(a - b) + cos(a + b)) / 2 turns its kernel into a sum of eight images of ONE table on the integer lattice:
+//
+//     K^+(x, y) = sum_{sigma in {0,1}^3} T(d^sigma),   d_a^0 = |x_a - y_a|,   d_a^1 = x_a + y_a + 1  (folded: d -> 2n - d beyond n),
+//     T(d) = sum_{k != 0} prod_a [ gamma(k_a) cos(pi k_a d_a / n) ] / lambda_k,   gamma(0) = 1/(2n), gamma(k > 0) = 1/n,   d_a = 0 .. n.
+//
+// T is three dense cosine contractions of the symbol gamma gamma gamma / lambda (6 n^4 flop: fp64 matrix cores, dgemm_rm_kernel), built once per
+// solve on the set-up stream beside Step 1.  A constraint row is a trilinear stencil (cell X_i, weights (1 - t_a, t_a) per axis), so
+//
+//     S_ij = sum over the 6 x 6 x 6 combinations of per-axis (index, weight) pairs of  w_x w_y w_z T[i_x][i_y][i_z],
+//
+// three pairs per axis for the difference image (|X_i - X_j + {-1, 0, 1}|) and three for the sum image (X_i + X_j + 1 + {0, 1, 2}): 216 table
+// reads per entry, m (m + 1) / 2 entries (schur_assemble_kernel).  The dual iteration then needs one dense m x m mat-vec instead of scatter +
+// five sweeps + gather: 256^3 (m = 2842) 0.17 -> 0.07 ms, 512^3 0.96 -> 0.07 ms per iteration.  Same operator up to rounding: same iteration counts.
+#pragma once
+#include "shm_kernels.hip.h"
+
+namespace shm {
+
+// W0[k1][k2][k3] = gamma gamma gamma / lambda_k  (0 for k = 0);  lam1[k] = (2 - 2 cos(pi k / n)) / h^2 is the table the transforms use
+__global__ __launch_bounds__(kBlock) void green_symbol_kernel(int n, const double* __restrict__ lam1, double* __restrict__ W0) {
+    const size_t N = (size_t)n * n * n;
+    const double g0 = 0.5 / n, g1 = 1.0 / n;
+    for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < N; v += (size_t)gridDim.x * kBlock) {
+        const int k3 = (int)(v % n), k2 = (int)((v / n) % n), k1 = (int)(v / ((size_t)n * n));
+        const double lam = lam1[k1] + lam1[k2] + lam1[k3];
+        const double g = (k1 ? g1 : g0) * (k2 ? g1 : g0) * (k3 ? g1 : g0);
+        W0[v] = (k1 | k2 | k3) ? g / lam : 0.;
+    }
+}
+
+// Cm[d][k] = cos(pi k d / n)  ((n + 1) x n, leading dimension n)  and  Ct[k][d]  (n x (n + 1), leading dimension P) from the 2n values
+// ctab[r] = cos(pi r / n): the argument is reduced exactly in integers
+__global__ __launch_bounds__(kBlock) void cosine_tables_kernel(int n, int P, const double* __restrict__ ctab, double* __restrict__ Cm, double* __restrict__ Ct) {
+    const int total = (n + 1) * n;
+    for (int v = blockIdx.x * kBlock + threadIdx.x; v < total; v += gridDim.x * kBlock) {
+        const int d = v / n, k = v - d * n;
+        const double c = ctab[(int)(((long long)d * k) % (2 * n))];
+        Cm[(size_t)d * n + k] = c;
+        Ct[(size_t)k * P + d] = c;
+    }
+}
+
+// C (M x N, ldc) = A (M x K, lda) B (K x N, ldb), row-major, batched over blockIdx.z with element strides sA, sB, sC; any M, N, K (edges are
+// zero-filled / masked).  64 x 64 tile per workgroup, one 32 x 32 quadrant per wave as 2 x 2 v_mfma_f64_16x16x4_f64 accumulators, K in LDS chunks
+// of 32 (the operand layout of gj_update_kernel).
+__global__ __launch_bounds__(kBlock) void dgemm_rm_kernel(int M, int N, int K, const double* __restrict__ A, int lda, long long sA, const double* __restrict__ B, int ldb,
+                                                          long long sB, double* __restrict__ C, int ldc, long long sC) {
+    __shared__ double as[kGJ][kGJK + 1];   // A chunk [i][k]
+    __shared__ double bs[kGJK][kGJ + 1];   // B chunk [k][j]
+    A += (long long)blockIdx.z * sA;
+    B += (long long)blockIdx.z * sB;
+    C += (long long)blockIdx.z * sC;
+    const int i0 = blockIdx.y * kGJ, j0 = blockIdx.x * kGJ;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    gj_f64x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = gj_f64x4{0., 0., 0., 0.};
+    for (int kc = 0; kc < K; kc += kGJK) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < kGJ * kGJK; t += kBlock) {
+            const int k = t & (kGJK - 1), i = t >> 5;   // 32 consecutive k of one row of A
+            as[i][k] = (i0 + i < M && kc + k < K) ? A[(size_t)(i0 + i) * lda + kc + k] : 0.;
+            const int j = t & (kGJ - 1), k2 = t >> 6;   // 64 consecutive columns of one row of B
+            bs[k2][j] = (kc + k2 < K && j0 + j < N) ? B[(size_t)(kc + k2) * ldb + j0 + j] : 0.;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < kGJK; kk += 4) {
+            double af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; a++) af[a] = as[wr * 32 + a * 16 + l15][kk + l4];
+#pragma unroll
+            for (int b = 0; b < 2; b++) bf[b] = bs[kk + l4][wc * 32 + b * 16 + l15];
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = i0 + wr * 32 + a * 16 + l4 + 4 * r, col = j0 + wc * 32 + b * 16 + l15;
+                if (row < M && col < N) C[(size_t)row * ldc + col] = acc[a][b][r];
+            }
+}
+
+// S[i][j] = S[j][i] = sum_{p, q, r < 6} w_x[p] w_y[q] w_z[r] T[i_x[p]][i_y[q]][i_z[r]]   (T: (n + 1) x (n + 1) x P, last index fastest).
+// One thread per entry of a 16 x 16 tile of the Morton-sorted rows (neighbouring cells: neighbouring table entries); tiles below the diagonal are
+// left to their mirror images.
+__global__ __launch_bounds__(kBlock) void schur_assemble_kernel(int m, int ld, int n, int P, const int* __restrict__ rowX /* [m][4]: cell i, j, k and the row index, in Morton order of the cells */,
+                                                                const double* __restrict__ rowT /* [m][3] */, const double* __restrict__ T, double* __restrict__ S) {
+    if (blockIdx.x < blockIdx.y) return;
+    const int i = blockIdx.y * 16 + (threadIdx.x >> 4), j = blockIdx.x * 16 + (threadIdx.x & 15);
+    if (i >= m || j >= m || j < i) return;   // (diagonal tiles: the upper entry writes its mirror image too, so S is exactly symmetric)
+    int idx[3][6];
+    double wt[3][6];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const int Xi = rowX[4 * i + a], Xj = rowX[4 * j + a];
+        const double ti = rowT[3 * i + a], tj = rowT[3 * j + a];
+        const double wi0 = 1. - ti, wi1 = ti, wj0 = 1. - tj, wj1 = tj;
+        const int D = Xi - Xj, E = Xi + Xj + 1;
+        idx[a][0] = abs(D - 1);
+        idx[a][1] = abs(D);
+        idx[a][2] = abs(D + 1);
+#pragma unroll
+        for (int e = 0; e < 3; e++) idx[a][3 + e] = (E + e <= n) ? E + e : 2 * n - (E + e);
+        wt[a][0] = wi0 * wj1;
+        wt[a][1] = wi0 * wj0 + wi1 * wj1;
+        wt[a][2] = wi1 * wj0;
+        wt[a][3] = wi0 * wj0;
+        wt[a][4] = wi0 * wj1 + wi1 * wj0;
+        wt[a][5] = wi1 * wj1;
+    }
+    double acc = 0.;
+#pragma unroll
+    for (int p = 0; p < 6; p++) {
+        double sp = 0.;
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const double* row = T + ((size_t)idx[0][p] * (n + 1) + idx[1][q]) * P;
+            double sq = 0.;
+#pragma unroll
+            for (int r = 0; r < 6; r++) sq += wt[2][r] * row[idx[2][r]];
+            sp += wt[1][q] * sq;
+        }
+        acc += wt[0][p] * sp;
+    }
+    const int ri = rowX[4 * i + 3], rj = rowX[4 * j + 3];
+    S[(size_t)ri * ld + rj] = acc;
+    S[(size_t)rj * ld + ri] = acc;
+}
+
+}  // namespace shm

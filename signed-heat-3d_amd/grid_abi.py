@@ -19,7 +19,7 @@ STATUS_NAMES = {0: "SHM_OK", 1: "SHM_ERR_INVALID", 2: "SHM_ERR_HIP", 3: "SHM_ERR
 # every symbol include/shm_grid.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = ["shm_grid_create", "shm_grid_destroy", "shm_grid_last_error", "shm_grid_abi_version", "shm_grid_set_problem",
                "shm_grid_solve", "shm_grid_get_phi", "shm_grid_compute_distance", "shm_grid_run_conv", "shm_grid_run_divergence",
-               "shm_grid_get_field", "shm_grid_apply_laplacian", "shm_grid_get_constraints", "shm_grid_apply_projector", "shm_grid_apply_preconditioner", "shm_grid_isosurface", "shm_grid_get_isosurface",
+               "shm_grid_get_field", "shm_grid_apply_laplacian", "shm_grid_get_constraints", "shm_grid_get_schur", "shm_grid_apply_projector", "shm_grid_apply_preconditioner", "shm_grid_isosurface", "shm_grid_get_isosurface",
                "shm_comm_unique_id", "shm_plan_slab"]
 
 
@@ -91,6 +91,7 @@ def load_library():
     lib.shm_grid_get_field.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.shm_grid_apply_laplacian.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.shm_grid_get_constraints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+    lib.shm_grid_get_schur.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
     lib.shm_grid_apply_projector.argtypes = [C.c_void_p, C.c_void_p]
     lib.shm_grid_apply_preconditioner.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.shm_grid_isosurface.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
@@ -214,6 +215,15 @@ class GridSolver:
         m = C.c_int32()
         self._chk(self._lib.shm_grid_get_constraints(self._h, nodes.ctypes.data, coeffs.ctypes.data, C.byref(m)))
         return nodes[:8 * m.value].reshape(-1, 8).copy(), coeffs[:8 * m.value].reshape(-1, 8).copy()
+
+    def get_schur(self):
+        """The explicit m x m Schur complement A K^+ A^T of the dual solver (ShmError SHM_ERR_STATE when the problem does not qualify)."""
+        m = len(self.get_constraints()[0])
+        out = np.empty((m, m), dtype=np.float64)
+        mm = C.c_int32(0)
+        self._chk(self._lib.shm_grid_get_schur(self._h, out.ctypes.data, C.byref(mm)))
+        assert mm.value == m
+        return out
 
     def apply_projector(self, v):
         v = _f64(v).reshape(-1).copy()

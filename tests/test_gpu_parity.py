@@ -971,3 +971,63 @@ def test_bench_py_multi_rank_flow_on_one_gpu(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["grid"] == "64^3" and d["value"] > 0 and d["scaling"] == "strong"
     assert "roofline" in d and "cpu_baseline" not in d     # the CPU baseline is an N=1 leg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,scrub", [("bunny_small_n16", True), ("bunny_small_n32", True), ("bunny_pc_n32", False), ("bunny_small_n64", True)])
+def test_explicit_schur_complement_is_A_Kplus_AT(case, scrub, tmp_path):
+    """The dual solver's explicit S (image-sum Green's table + trilinear stencils, csrc/shm_schur.hip.h) against the operator it replaces, applied through
+    the public entry points: column j of A K^+ A^T = gather(apply_preconditioner(scatter(e_j))).  Then the solve itself with S explicit and with S applied
+    through the grid (SHM_DUAL_NO_DENSE_S=1, a fresh process: the knob is read once): same LU-golden phi, same iteration count."""
+    import os
+    import subprocess
+    import sys
+    from conftest import GOLDEN, ROOT
+    if not os.path.exists(os.path.join(GOLDEN, case + ".npz")):
+        pytest.skip("fixture not generated")
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import shm_import
+shm = shm_import.load()
+d = np.load(%r)
+s = shm.GridSolver()
+n = int(d["n"])
+s.set_problem(d["pos"], d["wnormal"], d["area"], float(d["lam"]), n, d["bbox_min"], float(d["cell"]))
+out = {}
+try:
+    S = s.get_schur()
+    nodes, coeffs = s.get_constraints()
+    m = len(nodes)
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for j in list(rng.integers(0, m, 6)) + [0, m - 1]:
+        v = np.zeros(n ** 3)
+        np.add.at(v, nodes[j], coeffs[j])
+        z = s.apply_preconditioner(v)
+        col = (coeffs * z[nodes]).sum(axis=1)
+        worst = max(worst, float(np.abs(col - S[:, j]).max() / np.abs(S[:, j]).max()))
+    out["S_rel_err"] = worst
+    out["S_sym"] = float(np.abs(S - S.T).max())
+except shm.ShmError as e:
+    out["no_S"] = str(e)
+st = s.solve(tol=1e-10, scrub=%r, solver="dual")
+phi, _ = s.get_phi()
+out["phi_err"] = float(np.abs(phi - d["phi"]).max())
+out["iters"] = int(st.iters)
+print(repr(out))
+""" % (ROOT, os.path.join(GOLDEN, case + ".npz"), scrub)
+    res = {}
+    for knob in (None, "1"):
+        env = dict(os.environ, SHM_DUAL_DENSE_S_ALWAYS="1")   # (by default grids this small apply S through the grid: their Step 1 is too short to hide the assembly)
+        env.pop("SHM_DUAL_NO_DENSE_S", None)
+        if knob:
+            env["SHM_DUAL_NO_DENSE_S"] = knob
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout + p.stderr
+        res[knob] = eval(p.stdout.strip().splitlines()[-1])
+    a, b = res[None], res["1"]
+    assert "no_S" in b and "no_S" not in a, (a, b)
+    assert a["S_rel_err"] < 1e-10 and a["S_sym"] == 0.0, a          # the transforms are fp64: agreement to their rounding
+    assert a["phi_err"] < 1e-7 and b["phi_err"] < 1e-7, (a, b)
+    assert abs(a["iters"] - b["iters"]) <= 2, (a, b)
