@@ -624,21 +624,37 @@ struct Solver final : SolverBase {
                 static const bool no_reserve = getenv("SHM_CONV_NO_RESERVE") != nullptr;  // A/B knob
                 if (!no_reserve && !o_fast_hint && conv_est_ms < 4.0 * setup_est_ms && grid > resident - resident / 8) grid = resident - resident / 8;
             }
-            bool launched = false;
-            if constexpr (sizeof(T) == 4) {
-                if (npt8) {
-                    hipLaunchKernelGGL((conv_normalize_kernel<float, 8>), dim3(grid), dim3(kBlock), 0, stream, P, d_src.p, d_src32.p, d_clusters.p, d_exptab.p,
-                                       sl.Y0.p, sl.Y1.p, sl.Y2.p);
-                    launched = true;
+            // Several launches over z chunks instead of one: the set-up stream's kernels are dispatched only where a Step-1 launch has no workgroups left to
+            // hand out -- its tail -- so one long launch makes the ~135 dependent launches of the constraint set-up finish with Step 1 whatever their own
+            // length (512^3: 251 ms for 6 ms of work; split in 8: 42 ms, Step 1 itself +1 %).  Chunks of ~2.5 ms of Step 1 give the set-up a window that often.
+            // Only where the tiles cost about the same (the kernel spans the grid: lambda * side < 100, nothing is culled) -- with culling the persistent
+            // workgroups of ONE launch balance the uneven tiles, and every extra launch adds an uneven tail (rocker 512^3 fp32, 16 launches: +10 %) -- and
+            // where Step 1 is long enough to matter (>= 10 ms); at most 8 chunks.
+            static const int split_env = getenv("SHM_CONV_SPLIT") ? atoi(getenv("SHM_CONV_SPLIT")) : 0;   // A/B knob (1: one launch)
+            const bool uniform_tiles = lambda * cell * n < 100.;
+            const int want_chunks = split_env > 0 ? split_env : (uniform_tiles && conv_est_total_ms >= 10. ? std::min(8, (int)std::lround(conv_est_total_ms / 2.5)) : 1);
+            const int nchunks = std::max(1, std::min(tiles_z, want_chunks));
+            const int chunk_planes = ((tiles_z + nchunks - 1) / nchunks) * tile_z;
+            for (int b0 = 0; b0 < planes; b0 += chunk_planes) {
+                ConvParams Pc = P;
+                Pc.kk_begin = 1 + b0;
+                Pc.kk_end = std::min(sl.nzl + 1, 1 + b0 + chunk_planes);
+                Pc.n_tiles = P.tiles_x * P.tiles_y * ((Pc.kk_end - Pc.kk_begin + tile_z - 1) / tile_z);
+                const dim3 g((unsigned)std::min<long long>(Pc.n_tiles, grid));
+                bool launched = false;
+                if constexpr (sizeof(T) == 4) {
+                    if (npt8) {
+                        hipLaunchKernelGGL((conv_normalize_kernel<float, 8>), g, dim3(kBlock), 0, stream, Pc, d_src.p, d_src32.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p,
+                                           sl.Y2.p);
+                        launched = true;
+                    }
                 }
+                if (launched) {
+                } else if (npt4)
+                    hipLaunchKernelGGL((conv_normalize_kernel<T, 4>), g, dim3(kBlock), 0, stream, Pc, d_src.p, d_src32.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p, sl.Y2.p);
+                else
+                    hipLaunchKernelGGL((conv_normalize_kernel<T, 2>), g, dim3(kBlock), 0, stream, Pc, d_src.p, d_src32.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p, sl.Y2.p);
             }
-            if (launched) {
-            } else if (npt4)
-                hipLaunchKernelGGL((conv_normalize_kernel<T, 4>), dim3(grid), dim3(kBlock), 0, stream, P, d_src.p, d_src32.p, d_clusters.p, d_exptab.p, sl.Y0.p,
-                                   sl.Y1.p, sl.Y2.p);
-            else
-                hipLaunchKernelGGL((conv_normalize_kernel<T, 2>), dim3(grid), dim3(kBlock), 0, stream, P, d_src.p, d_src32.p, d_clusters.p, d_exptab.p, sl.Y0.p,
-                                   sl.Y1.p, sl.Y2.p);
         }
         HIPCHK(hipGetLastError());
         exchange_Y_halos();
