@@ -134,6 +134,11 @@ def kernel_table(avg, n_local, T, world, gathered):
         # the dual solver has no N-sized CG sweeps (its vectors are m-dimensional); on one GPU its five sweeps per iteration are
         # sparse (active x tiles, active z-planes, masked z I/O) and the library reports the bytes they actually move
         kernels = {"dct_lines_kernel": (avg["bytes_per_iter"] / (1 if gathered else world) / 5.0, avg["ms_precond_avg"] / 5.0, 5)}
+        if int(avg.get("cg_form", 0)) in (2, 3):
+            # explicit Schur complement (csrc/shm_schur.hip.h): the iteration's grid part is one dense m x m mat-vec (cg_form 3: S p in the CG;
+            # cg_form 2, direct solve: S^-1 r per pass, the residual check S mu is in ms_project_avg)
+            m = float(avg["m"])
+            kernels = {"ginv_matvec_kernel<double>": (m * m * 8.0, avg["ms_precond_avg"], 1)}
     kinfo = {k: {"algorithmic_bytes_per_launch": b, "avg_ms_per_launch": ms, "launches_per_iter": cnt,
                  "achieved_GBps": (b / (ms * 1e-3) / 1e9 if ms > 0 else None),
                  "frac_of_hbm_peak": (b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None)}
@@ -308,11 +313,17 @@ def main():
             "config": {"workload": args.workload, "grid": "%d^3" % n, "sources": int(pre["S"]), "constraint_rows": int(avg["m"]),
                        "tol": args.tol if args.tol > 0 else (1e-8 if precision == 64 else 1e-5), "cg_iters": int(avg["iters"]),
                        "rel_residual": avg["rel_residual"], "partition": "z-slabs x%d" % world,
-                       "solver": ("dual: CG on the Schur complement A K^+ A^T, K^+ = DCT fast Poisson solve"
+                       "solver": (("dual, direct: the Schur complement S = A K^+ A^T is assembled explicitly (image-sum Green's table) and inverted beside Step 1; "
+                                   "after Step 1: g = A K^+ b, mu = S^-1-solve of the bordered system, x = K^+ (A^T mu - b); cg_iters = passes (the first is "
+                                   "the solve, further ones iterative refinement); K^+ = DCT fast Poisson solve"
+                                   if int(avg.get("cg_form", 0)) == 2 else
+                                   "dual: CG on the explicit Schur complement A K^+ A^T (dense mat-vec), K^+ = DCT fast Poisson solve"
+                                   if int(avg.get("cg_form", 0)) == 3 else
+                                   "dual: CG on the Schur complement A K^+ A^T, K^+ = DCT fast Poisson solve")
                                   + ("; Steps 1-2 on z-slabs, D^T Y gathered over RCCL, whole-grid solve on every rank" if gathered else
                                      "; z-slab DCT with two all-to-alls per application" if int(avg["solver"]) == 3 else "")) if is_dual
                        else "primal: projected stencil CG",
-                       "preconditioner": ("G^-1 (A K A^T) G^-1" if is_dual else "dct (exact fast Poisson, sandwiched P M^-1 P)") if has_pre else "none"},
+                       "preconditioner": (("none (direct)" if int(avg.get("cg_form", 0)) == 2 else "G^-1 (A K A^T) G^-1") if is_dual else "dct (exact fast Poisson, sandwiched P M^-1 P)") if has_pre else "none"},
             "phases_ms": {k: avg[k] for k in ("ms_conv", "ms_div", "ms_setup", "ms_wait_setup", "ms_pcg", "ms_shift", "ms_total")},
             "pcg": {"ms_per_iter": avg["ms_pcg"] / max(1.0, avg["iters"]), "algorithmic_bytes_per_iter": avg["bytes_per_iter"] / (1 if gathered else world),
                     "achieved_GBps": avg["bytes_per_iter"] / (1 if gathered else world) / (avg["ms_pcg"] / max(1.0, avg["iters"]) * 1e-3) / 1e9,

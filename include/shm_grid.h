@@ -129,7 +129,9 @@ typedef struct {
     int32_t preconditioner;   /* SHM_PRECOND_NONE or SHM_PRECOND_DCT: what actually ran */
     int32_t solver;           /* SHM_SOLVER_PRIMAL, SHM_SOLVER_DUAL or SHM_SOLVER_DUAL_SLABS: what actually ran */
     double bytes_per_iter;    /* algorithmic HBM bytes per CG iteration of the decomposition launched */
-    int32_t cg_form;          /* PRIMAL only.  0: four N-sized kernels per iteration (11NT; the per-kernel fields above mean what they say).
+    int32_t cg_form;          /* DUAL: 0: S = A K^+ A^T applied through the grid (five sweeps per iteration); 3: CG on the explicit S (one dense mat-vec,
+                               *    timed in ms_precond_avg); 2: direct solve with the explicit S^-1 (iters = passes, ms_precond_avg = S^-1 mat-vec).
+                               * PRIMAL: 0: four N-sized kernels per iteration (11NT; the per-kernel fields above mean what they say).
                                * 1: fused sweeps (8NT): ms_stencil_avg = DIR sweep (p' = -z + beta p, partial p'.Kp'; 3NT),
                                *    ms_update_xr_avg = RES sweep (r += alpha K p', partial ||r||^2; 3NT),
                                *    ms_update_p_avg = x += a0 p0 + a1 p1 (4NT per launch, launched every other iteration) */

@@ -281,6 +281,8 @@ struct Solver final : SolverBase {
     std::vector<double> h_gs_lam, h_gs_ctab, h_rowT;   // host staging outlives the asynchronous uploads
     std::vector<int> h_rowX;
     bool have_S = false;
+    bool dual_direct_requested = false, dual_direct = false;   // direct dual solve: S^-1 (Sinv) instead of G^-1; requested by solve(), decided in build_constraints()
+    DevArray<double> Sinv;
     double conv_est_total_ms = 1e30;   // estimate of this rank's last Step-1 launch (1e30: none was launched -- stand-alone set-up, test entry points)
     int gs_n = 0, schur_table_builds = 0;   // grid the Green's table in gs_T was built for (0: none)
     double gs_cell = 0.;
@@ -838,6 +840,11 @@ struct Solver final : SolverBase {
                 accv[(size_t)col] += v;
             }
         };
+        // Direct dual solve (moderate m, explicit S): S itself is inverted on the set-up stream instead of G, and the dual system is solved with two dense
+        // mat-vecs after Step 1 -- no G, no B, no iteration (see solve_dual).
+        static const bool no_direct = getenv("SHM_DUAL_NO_DIRECT") != nullptr;   // A/B knob
+        static const int direct_max_m = getenv("SHM_DUAL_DIRECT_MAX_M") ? atoi(getenv("SHM_DUAL_DIRECT_MAX_M")) : 4096;   // single-level Gauss-Jordan range
+        dual_direct = dual_direct_requested && !no_direct && m <= direct_max_m && schur_wanted();
         // G = A A^T in CSR on the host (rows sharing a node with row r), then either scattered into the dense m x m matrix that the blocked
         // Gauss-Jordan inverts in place, or -- large m -- split into boxes and a separator (two-level inverse, shm_twolevel.hip.h)
         std::vector<int> gptr((size_t)m + 1, 0), gcol;
@@ -845,7 +852,7 @@ struct Solver final : SolverBase {
         gcol.reserve((size_t)m * 32);
         gval.reserve((size_t)m * 32);
         std::vector<int> ugs((size_t)8 * m);
-        for (int r = 0; r < m; r++) {
+        for (int r = 0; r < m && !dual_direct; r++) {
             cols.clear();
             for (int e = 0; e < 8; e++) {
                 const int ug = group_of(rows[r].nodes[e]);
@@ -862,10 +869,10 @@ struct Solver final : SolverBase {
         DevArray<uint64_t> d_tidx;  // alive until the final synchronisation below
         DevArray<double> d_tval;
         static const int tl_min_m = getenv("SHM_TL_MIN_M") ? atoi(getenv("SHM_TL_MIN_M")) : 6144;  // dense inverse up to here (m^2 fp32 = 150 MB: L2 / MALL friendly, 3 launches)
-        tl.on = m > tl_min_m && build_two_level(gptr, gcol, gval, d_tidx, d_tval);
+        tl.on = !dual_direct && m > tl_min_m && build_two_level(gptr, gcol, gval, d_tidx, d_tval);
         std::vector<uint64_t> tidx;  // alive (like d_tidx / d_tval) until the final synchronisation below
         std::vector<double> tval;
-        if (!tl.on) {
+        if (!tl.on && !dual_direct) {
             tidx.reserve(gcol.size() + (size_t)(mp - m));
             tval.reserve(gcol.size() + (size_t)(mp - m));
             for (int r = 0; r < m; r++)
@@ -888,10 +895,15 @@ struct Solver final : SolverBase {
             HIPCHK(hipGetLastError());
         }
         prepare_schur();
-        enqueue_invert_G();
-        lap("G uploaded, inversion enqueued");
-        enqueue_schur();
-        lap("explicit S enqueued");
+        if (dual_direct) {
+            enqueue_schur();
+            lap("explicit S and its inversion enqueued");
+        } else {
+            enqueue_invert_G();
+            lap("G uploaded, inversion enqueued");
+            enqueue_schur();
+            lap("explicit S enqueued");
+        }
 
         // ---- host work that the inversion does not need, while the GPU inverts
         std::vector<int> bptr(m + 1, 0), bcol;
@@ -901,7 +913,7 @@ struct Solver final : SolverBase {
         {
             const double ih2 = 1. / (cell * cell);
             const int64_t nn = n, pl = (int64_t)n * n;
-            for (int r = 0; r < m; r++) {  // B = A K A^T: K a_r lives on the 8 corners and their in-grid neighbours
+            for (int r = 0; r < m && !dual_direct; r++) {  // B = A K A^T: K a_r lives on the 8 corners and their in-grid neighbours
                 cols.clear();
                 for (int e = 0; e < 8; e++) {
                     const int64_t c = rows[r].nodes[e];
@@ -987,7 +999,7 @@ struct Solver final : SolverBase {
         Bptr.upload(bptr, stream);
         Bcol.upload(bcol, stream);
         Bval.upload(bval, stream);
-        have_B = true;
+        have_B = !dual_direct;
         lap("B uploaded");
         upload_red_tables(stream);
         lap("B, reduction tables uploaded");
@@ -1188,7 +1200,7 @@ struct Solver final : SolverBase {
         HIPCHK(hipStreamSynchronize(stream));  // host vectors above are locals
         int flag = 0;
         HIPCHK(hipMemcpy(&flag, gjFlag.p, sizeof(int), hipMemcpyDeviceToHost));
-        if (flag) throw Error(SHM_ERR_SINGULAR, "A A^T is not positive definite (duplicate or degenerate constraint rows)");
+        if (flag) throw Error(SHM_ERR_SINGULAR, "A A^T (or A K^+ A^T) is not positive definite (duplicate or degenerate constraint rows)");
         log("[shm] two-level inverse of A A^T: box %d, %d boxes (%d interior rows), separator %d rows", tl.box, P, tl.nI, nS);
         return true;
     }
@@ -1214,9 +1226,9 @@ struct Solver final : SolverBase {
         else hipLaunchKernelGGL((tl_finish_kernel<double>), dim3(gfin), dim3(kBlock), 0, st, V, tl.P, tl.nS, tl.sepRow.p, tl.Tm.p, tl.tbuf.p, tl.uS.p, u);
     }
 
-    void enqueue_invert_G() {
+    // in-place inverse of the SPD matrix M (mp x mp, mp a multiple of 64, identity tail) on the set-up stream: blocked Gauss-Jordan (shm_kernels.hip.h)
+    void enqueue_gj_invert(double* M, int mp) {
         hipStream_t stream = stream2;
-        const int mp = ginv_ld;  // dense inverse: the padded m; two-level: the padded separator size
         const int nb = mp / kGJ;
         static const int outer_env = getenv("SHM_GJ_OUTER") ? atoi(getenv("SHM_GJ_OUTER")) : 0;   // experiment knob: pivot blocks per outer block
         const int outer = outer_env > 0 ? std::min(outer_env, 8) : (nb >= 64 ? 4 : 1);
@@ -1224,14 +1236,13 @@ struct Solver final : SolverBase {
         gjR.alloc((size_t)outer * kGJ * mp);   // [outer * 64][mp]
         gjC.alloc((size_t)mp * outer * kGJ);   // [mp][outer * 64]
         gjFlag.alloc(1);
-        Ginv32.alloc((size_t)mp * mp);
         HIPCHK(hipMemsetAsync(gjFlag.p, 0, sizeof(int), stream));
         const int c_ld = outer * kGJ;
         if (outer == 1) {
             for (int kb = 0; kb < nb; kb++) {
-                hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjP.p, gjFlag.p);
-                hipLaunchKernelGGL(gj_panels_kernel, dim3(nb), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjP.p, gjR.p, 0, gjC.p, c_ld, 0);
-                hipLaunchKernelGGL((gj_update_kernel<GJ_ALL>), dim3((unsigned)((size_t)nb * (nb + 1) / 2)), dim3(kBlock), 0, stream, Ginv.p, mp, nb, kb, 0, 1,
+                hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(kBlock), 0, stream, M, mp, kb, gjP.p, gjFlag.p);
+                hipLaunchKernelGGL(gj_panels_kernel, dim3(nb), dim3(kBlock), 0, stream, M, mp, kb, gjP.p, gjR.p, 0, gjC.p, c_ld, 0);
+                hipLaunchKernelGGL((gj_update_kernel<GJ_ALL>), dim3((unsigned)((size_t)nb * (nb + 1) / 2)), dim3(kBlock), 0, stream, M, mp, nb, kb, 0, 1,
                                    gjR.p, 0, gjC.p, c_ld, 0, kGJ);
             }
         } else {
@@ -1239,19 +1250,25 @@ struct Solver final : SolverBase {
                 const int nO = std::min(outer, nb - k0);
                 for (int t = 0; t < nO; t++) {
                     const int kb = k0 + t;
-                    hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjP.p, gjFlag.p);
-                    hipLaunchKernelGGL(gj_panels_kernel, dim3(nb), dim3(kBlock), 0, stream, Ginv.p, mp, kb, gjP.p, gjR.p, t * kGJ, gjC.p, c_ld, t * kGJ);
-                    hipLaunchKernelGGL((gj_update_kernel<GJ_CROSS>), dim3((unsigned)(nO * nb + nO * k0)), dim3(kBlock), 0, stream, Ginv.p, mp, nb, kb, k0, nO,
+                    hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(kBlock), 0, stream, M, mp, kb, gjP.p, gjFlag.p);
+                    hipLaunchKernelGGL(gj_panels_kernel, dim3(nb), dim3(kBlock), 0, stream, M, mp, kb, gjP.p, gjR.p, t * kGJ, gjC.p, c_ld, t * kGJ);
+                    hipLaunchKernelGGL((gj_update_kernel<GJ_CROSS>), dim3((unsigned)(nO * nb + nO * k0)), dim3(kBlock), 0, stream, M, mp, nb, kb, k0, nO,
                                        gjR.p, t * kGJ, gjC.p, c_ld, t * kGJ, kGJ);
                 }
                 const size_t nr = (size_t)(nb - nO);
                 if (nr > 0)
-                    hipLaunchKernelGGL((gj_update_kernel<GJ_REST>), dim3((unsigned)(nr * (nr + 1) / 2)), dim3(kBlock), 0, stream, Ginv.p, mp, nb, -1, k0, nO,
+                    hipLaunchKernelGGL((gj_update_kernel<GJ_REST>), dim3((unsigned)(nr * (nr + 1) / 2)), dim3(kBlock), 0, stream, M, mp, nb, -1, k0, nO,
                                        gjR.p, 0, gjC.p, c_ld, 0, nO * kGJ);
             }
         }
-        if (nb > 1) hipLaunchKernelGGL(gj_mirror_kernel, dim3((unsigned)((size_t)nb * (nb - 1) / 2)), dim3(kBlock), 0, stream, Ginv.p, mp);
-        hipLaunchKernelGGL((convert_kernel<double, float>), dim3(grid_for((size_t)mp * mp, 4096)), dim3(kBlock), 0, stream, (size_t)mp * mp, Ginv.p, Ginv32.p);
+        if (nb > 1) hipLaunchKernelGGL(gj_mirror_kernel, dim3((unsigned)((size_t)nb * (nb - 1) / 2)), dim3(kBlock), 0, stream, M, mp);
+        HIPCHK(hipGetLastError());
+    }
+    void enqueue_invert_G() {
+        const int mp = ginv_ld;  // dense inverse: the padded m; two-level: the padded separator size
+        enqueue_gj_invert(Ginv.p, mp);
+        Ginv32.alloc((size_t)mp * mp);
+        hipLaunchKernelGGL((convert_kernel<double, float>), dim3(grid_for((size_t)mp * mp, 4096)), dim3(kBlock), 0, stream2, (size_t)mp * mp, Ginv.p, Ginv32.p);
         HIPCHK(hipGetLastError());
     }
     // S = A K^+ A^T explicitly (shm_schur.hip.h), on the set-up stream.  For one slab, a DCT-sized grid and a moderate number of rows.
@@ -1326,8 +1343,9 @@ struct Solver final : SolverBase {
     void enqueue_schur() {
         if (!schur_wanted()) return;
         // its own stream: the inversion of G on stream2 is a chain of ~135 short launches that each wait for a slot next to Step 1 (39 of Step 1's 40 ms at
-        // 256^3); queued behind it the assembly would start when Step 1 is almost over and be exposed, beside it it is done long before
-        hipStream_t st = stream3;
+        // 256^3); queued behind it the assembly would start when Step 1 is almost over and be exposed, beside it it is done long before.  (Direct dual solve:
+        // there is no inversion of G; S is assembled and then inverted itself, all on stream2.)
+        hipStream_t st = dual_direct ? stream2 : stream3;
         HIPCHK(hipStreamWaitEvent(st, e_sch_in->e, 0));
         const int P = n + 8;
         const size_t n1 = (size_t)n + 1;
@@ -1359,8 +1377,15 @@ struct Solver final : SolverBase {
         const unsigned mt = (unsigned)((m + 15) / 16);
         hipLaunchKernelGGL(schur_assemble_kernel, dim3(mt, mt), dim3(kBlock), 0, st, m, mp, n, P, d_rowX.p, d_rowT.p, gs_T.p, Sdense.p);
         HIPCHK(hipGetLastError());
-        e_sch_done->record(st);
-        HIPCHK(hipStreamWaitEvent(stream2, e_sch_done->e, 0));   // "set-up done" on stream2 (what the solve waits for) now includes S
+        if (dual_direct) {
+            Sinv.alloc((size_t)mp * mp);
+            HIPCHK(hipMemcpyAsync(Sinv.p, Sdense.p, (size_t)mp * mp * sizeof(double), hipMemcpyDeviceToDevice, st));
+            if (mp > m) hipLaunchKernelGGL(set_diagonal_kernel, dim3((unsigned)((mp - m + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, Sinv.p, mp, m, mp, 1.0);   // identity tail
+            enqueue_gj_invert(Sinv.p, mp);
+        } else {
+            e_sch_done->record(st);
+            HIPCHK(hipStreamWaitEvent(stream2, e_sch_done->e, 0));   // "set-up done" on stream2 (what the solve waits for) now includes S
+        }
         have_S = true;
     }
     void finish_invert_G() {
@@ -1979,8 +2004,9 @@ struct Solver final : SolverBase {
             gather(ARR_Z);
         }
         for (Slab<T>& sl : slabs)
-            hipLaunchKernelGGL(dual_init_residual_kernel, dim3(1), dim3(kDualBlock), 0, stream, m, mv(sl, V_G), sl.red.p + 1, mv(sl, V_R), sl.sc.p);
-        precondition(1);
+            hipLaunchKernelGGL(dual_init_residual_kernel, dim3(1), dim3(kDualBlock), 0, stream, m, mv(sl, V_G), sl.red.p + 1, mv(sl, V_R), sl.sc.p, 1);
+        const bool direct = dual_direct && dense_S;   // S^-1 is resident (build_constraints): no CG, no G^-1, no B
+        if (!direct) precondition(1);
         HIPCHK(hipGetLastError());
 
         const int kMaxSamples = 32;
@@ -1989,7 +2015,40 @@ struct Solver final : SolverBase {
         int nsamples = 0, it = 0;
         double rr0 = 0., rr = 0.;
         bool converged = false, breakdown = false;
-        while (it < o.max_iters && !converged && !breakdown) {
+        if (direct) {
+            // Direct solve of the bordered system [[S, 1], [1^T, 0]] [delta; c] = [r; 0] for the correction of mu_0 (whose sum is already sum(b)):
+            // u = S^-1 r, v = S^-1 1, delta = u - (1^T u / 1^T v) v;  then r = Pm(g - S mu) again with the explicit S.  The first pass IS the solution
+            // (cond(S) ~ 5e2 ... 7e4 on the bunny grids: 1e-12 and better); further passes are iterative refinement, taken only while the residual
+            // test of the CG path -- the same one -- is not met.
+            Slab<T>& sl = slabs[0];
+            auto apply_Sinv = [&](const double* w, double* u) { hipLaunchKernelGGL(ginv_matvec_kernel<double>, dim3(m), dim3(kBlock), 0, stream, m, mp, Sinv.p, w, u); };
+            hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, mv(sl, V_T2), m, 1.0);
+            apply_Sinv(mv(sl, V_T2), mv(sl, V_Z));
+            const int max_passes = std::min(o.max_iters, 6);
+            while (it < max_passes && !converged && !breakdown) {
+                const bool sample = st && nsamples < kMaxSamples;
+                if (sample) ev[3 * nsamples]->record(stream);
+                apply_Sinv(mv(sl, V_R), mv(sl, V_T1));
+                hipLaunchKernelGGL(dual_bordered_kernel, dim3(1), dim3(kDualBlock), 0, stream, m, mv(sl, V_T1), mv(sl, V_Z), (const double*)nullptr, 1, mv(sl, V_MU));
+                if (sample) ev[3 * nsamples + 1]->record(stream);
+                apply_S(V_MU);
+                hipLaunchKernelGGL(dual_init_residual_kernel, dim3(1), dim3(kDualBlock), 0, stream, m, mv(sl, V_G), sl.red.p + 1, mv(sl, V_R), sl.sc.p, 0);
+                if (sample) {
+                    ev[3 * nsamples + 2]->record(stream);
+                    nsamples++;
+                }
+                it++;
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipMemcpyAsync(h_pinned, sl.sc.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+                rr0 = h_pinned[SC_RR0];
+                rr = h_pinned[SC_RR];
+                if (!std::isfinite(rr) || !std::isfinite(rr0)) breakdown = true;
+                else if (rr <= o.tol * o.tol * rr0) converged = true;
+                log("[shm] dual (direct) pass=%d rel_res=%.3e", it, rr0 > 0. ? std::sqrt(std::fabs(rr / rr0)) : 0.);
+            }
+        }
+        while (!direct && it < o.max_iters && !converged && !breakdown) {
             const int batch_end = std::min(o.max_iters, it + check_every);
             for (; it < batch_end; it++) {
                 const bool sample = st && nsamples < kMaxSamples;
@@ -2064,8 +2123,12 @@ struct Solver final : SolverBase {
             st->kernel_samples = nsamples;
             st->preconditioner = SHM_PRECOND_DCT;
             st->solver = total_slabs > 1 ? SHM_SOLVER_DUAL_SLABS : SHM_SOLVER_DUAL;
-            if (dense_S) {  // S (fp64) once, the single-precision G^-1 twice
+            if (direct) {   // S^-1 and S once per pass (plus S^-1 1 once per solve)
+                st->bytes_per_iter = 2.0 * (double)m * m * sizeof(double);
+                st->cg_form = 2;
+            } else if (dense_S) {  // S (fp64) once, the single-precision G^-1 twice
                 st->bytes_per_iter = (double)m * m * (sizeof(double) + 2.0 * sizeof(float));
+                st->cg_form = 3;
             } else if (sparse_ok) {  // bytes the five sparse sweeps actually move: active x tiles, active planes (y sweeps and the masked z sweep)
                 const double L = dct_lines_for(log2n, (int)sizeof(TP)), tile_bytes = L * n * sizeof(TP);
                 const double planes_active = (double)slabs[0].n_act_y / (n / L);
@@ -2091,7 +2154,9 @@ struct Solver final : SolverBase {
         Event c_s2a, c_s2b, e_gather, f_start, f_setup;
         c_s2a.record(F.stream2);
         F.conv_est_total_ms = conv_est_total_ms;   // what the whole-grid solver's set-up can hide behind is this rank's share of Step 1
-        F.build_constraints();  // on the whole-grid solver's set-up stream: overlaps this rank's Step-1 kernel
+        F.dual_direct_requested = true;
+        F.build_constraints();
+        F.dual_direct_requested = false;  // on the whole-grid solver's set-up stream: overlaps this rank's Step-1 kernel
         c_s2b.record(F.stream2);
         F.setup_precond();
         const size_t plane = (size_t)n * n;
@@ -2343,7 +2408,9 @@ struct Solver final : SolverBase {
         static const bool setup_alone = getenv("SHM_SETUP_ALONE") != nullptr;  // measurement knob: wait for Step 1 first, so that shm_stats.ms_setup is
         if (setup_alone) HIPCHK(hipStreamSynchronize(stream));                  // the set-up's time on an otherwise idle GPU (tools/scaling_model.py)
         e_s2a.record(stream2);
-        build_constraints();  // on stream2: overlaps the Step-1 kernel; returns once (A A^T)^-1 is ready
+        dual_direct_requested = (o.solver == SHM_SOLVER_DUAL || (o.solver == SHM_SOLVER_AUTO && o.preconditioner != SHM_PRECOND_NONE)) && precond_available() && !comm;
+        build_constraints();  // on stream2: overlaps the Step-1 kernel; returns once (A A^T)^-1 (or S^-1, for the direct dual solve) is ready
+        dual_direct_requested = false;
         e_s2b.record(stream2);
         bool dual = false;
         if (o.solver == SHM_SOLVER_DUAL || o.solver == SHM_SOLVER_DUAL_SLABS) {

@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(kDualBlock) void dual_init_mu_kernel(int m, const d
 
 // r = Pm(g - S mu)  with Smu given;  rr0 = r.r
 __global__ __launch_bounds__(kDualBlock) void dual_init_residual_kernel(int m, const double* __restrict__ g, const double* __restrict__ Smu,
-                                                                        double* __restrict__ r, double* __restrict__ sc) {
+                                                                        double* __restrict__ r, double* __restrict__ sc, int set_rr0 = 1) {
     __shared__ double lds[17];
     double s = 0.;
     for (int a = threadIdx.x; a < m; a += kDualBlock) s += g[a] - Smu[a];
@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(kDualBlock) void dual_init_residual_kernel(int m, c
     rr = block_sum_1024(rr, lds);
     if (threadIdx.x == 0) {
         sc[SC_RR] = rr;
-        sc[SC_RR0] = rr;
+        if (set_rr0) sc[SC_RR0] = rr;
     }
 }
 

@@ -144,4 +144,31 @@ __global__ __launch_bounds__(kBlock) void schur_assemble_kernel(int m, int ld, i
     S[(size_t)rj * ld + ri] = acc;
 }
 
+// M[i][i] = v for i in [i0, i1)  (identity tail of a padded SPD matrix)
+__global__ __launch_bounds__(kBlock) void set_diagonal_kernel(double* __restrict__ M, int ld, int i0, int i1, double v) {
+    const int i = i0 + blockIdx.x * kBlock + threadIdx.x;
+    if (i < i1) M[(size_t)i * ld + i] = v;
+}
+
+// Direct dual solve, bordered system [[S, 1], [1^T, 0]] [mu; c] = [rhs; sigma]:  with u = S^-1 rhs and v = S^-1 1,  c = (1^T u - sigma) / (1^T v),
+// mu (+)= u - c v.  sigma = *sigma_ptr (nullptr: 0).  One workgroup.
+__global__ __launch_bounds__(kDualBlock) void dual_bordered_kernel(int m, const double* __restrict__ u, const double* __restrict__ v, const double* __restrict__ sigma_ptr,
+                                                                  int accumulate, double* __restrict__ mu) {
+    __shared__ double lds[17];
+    double su = 0., sv = 0.;
+    for (int a = threadIdx.x; a < m; a += kDualBlock) {
+        su += u[a];
+        sv += v[a];
+    }
+    su = block_sum_1024(su, lds);
+    sv = block_sum_1024(sv, lds);
+    const double c = (su - (sigma_ptr ? *sigma_ptr : 0.)) / sv;
+    for (int a = threadIdx.x; a < m; a += kDualBlock) mu[a] = (accumulate ? mu[a] : 0.) + u[a] - c * v[a];
+}
+
+__global__ __launch_bounds__(kBlock) void fill_kernel(double* __restrict__ x, int count, double v) {
+    const int a = blockIdx.x * kBlock + threadIdx.x;
+    if (a < count) x[a] = v;
+}
+
 }  // namespace shm

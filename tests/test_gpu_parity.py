@@ -977,8 +977,9 @@ def test_bench_py_multi_rank_flow_on_one_gpu(tmp_path):
 @pytest.mark.parametrize("case,scrub", [("bunny_small_n16", True), ("bunny_small_n32", True), ("bunny_pc_n32", False), ("bunny_small_n64", True)])
 def test_explicit_schur_complement_is_A_Kplus_AT(case, scrub, tmp_path):
     """The dual solver's explicit S (image-sum Green's table + trilinear stencils, csrc/shm_schur.hip.h) against the operator it replaces, applied through
-    the public entry points: column j of A K^+ A^T = gather(apply_preconditioner(scatter(e_j))).  Then the solve itself with S explicit and with S applied
-    through the grid (SHM_DUAL_NO_DENSE_S=1, a fresh process: the knob is read once): same LU-golden phi, same iteration count."""
+    the public entry points: column j of A K^+ A^T = gather(apply_preconditioner(scatter(e_j))).  Then the solve itself three ways (fresh processes: the
+    knobs are read once): direct (S inverted beside Step 1), CG on the explicit S (SHM_DUAL_NO_DIRECT=1), CG with S applied through the grid
+    (SHM_DUAL_NO_DENSE_S=1): same LU-golden phi; the two CGs take the same iterations, the direct solve one or two passes."""
     import os
     import subprocess
     import sys
@@ -1018,16 +1019,18 @@ out["iters"] = int(st.iters)
 print(repr(out))
 """ % (ROOT, os.path.join(GOLDEN, case + ".npz"), scrub)
     res = {}
-    for knob in (None, "1"):
+    for name, knobs in (("direct", {}), ("cg_dense", {"SHM_DUAL_NO_DIRECT": "1"}), ("cg_sweeps", {"SHM_DUAL_NO_DENSE_S": "1"})):
         env = dict(os.environ, SHM_DUAL_DENSE_S_ALWAYS="1")   # (by default grids this small apply S through the grid: their Step 1 is too short to hide the assembly)
-        env.pop("SHM_DUAL_NO_DENSE_S", None)
-        if knob:
-            env["SHM_DUAL_NO_DENSE_S"] = knob
+        for k in ("SHM_DUAL_NO_DENSE_S", "SHM_DUAL_NO_DIRECT"):
+            env.pop(k, None)
+        env.update(knobs)
         p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stdout + p.stderr
-        res[knob] = eval(p.stdout.strip().splitlines()[-1])
-    a, b = res[None], res["1"]
-    assert "no_S" in b and "no_S" not in a, (a, b)
-    assert a["S_rel_err"] < 1e-10 and a["S_sym"] == 0.0, a          # the transforms are fp64: agreement to their rounding
-    assert a["phi_err"] < 1e-7 and b["phi_err"] < 1e-7, (a, b)
-    assert abs(a["iters"] - b["iters"]) <= 2, (a, b)
+        res[name] = eval(p.stdout.strip().splitlines()[-1])
+    d, a, b = res["direct"], res["cg_dense"], res["cg_sweeps"]
+    assert "no_S" in b and "no_S" not in a and "no_S" not in d, res
+    for r in (d, a):
+        assert r["S_rel_err"] < 1e-10 and r["S_sym"] == 0.0, r          # the transforms are fp64: agreement to their rounding
+    assert d["phi_err"] < 1e-7 and a["phi_err"] < 1e-7 and b["phi_err"] < 1e-7, res
+    assert abs(a["iters"] - b["iters"]) <= 2, res                       # same operator: same CG
+    assert d["iters"] <= 2, d                                           # the direct solve: one pass, at most one of refinement
