@@ -842,9 +842,10 @@ struct Solver final : SolverBase {
         };
         // Direct dual solve (moderate m, explicit S): S itself is inverted on the set-up stream instead of G, and the dual system is solved with two dense
         // mat-vecs after Step 1 -- no G, no B, no iteration (see solve_dual).
-        static const bool no_direct = getenv("SHM_DUAL_NO_DIRECT") != nullptr;   // A/B knob
+        const bool no_direct = getenv("SHM_DUAL_NO_DIRECT") != nullptr;   // A/B knob, read per solve (tests of the iterative path flip it inside one process)
         static const int direct_max_m = getenv("SHM_DUAL_DIRECT_MAX_M") ? atoi(getenv("SHM_DUAL_DIRECT_MAX_M")) : 4096;   // single-level Gauss-Jordan range
-        dual_direct = dual_direct_requested && !no_direct && m <= direct_max_m && schur_wanted();
+        dual_direct = dual_direct_requested && !no_direct && m <= direct_max_m;
+        dual_direct = dual_direct && schur_wanted();   // (schur_wanted() reads dual_direct: with it set only the structural conditions remain)
         // G = A A^T in CSR on the host (rows sharing a node with row r), then either scattered into the dense m x m matrix that the blocked
         // Gauss-Jordan inverts in place, or -- large m -- split into boxes and a separator (two-level inverse, shm_twolevel.hip.h)
         std::vector<int> gptr((size_t)m + 1, 0), gcol;
@@ -1284,9 +1285,11 @@ struct Solver final : SolverBase {
         // the assembly (216 table reads per entry: ~3.1e-7 ms per m^2 on an idle device, measured 2.5 ms at m = 2842, 41 ms at m = 12 612) has to hide behind
         // this rank's Step 1 like the rest of the set-up; where Step 1 is short (<= 128^3, or a thin slab of a multi-GPU run) the sweeps through the grid are
         // cheap anyway (0.11 ms per iteration at 128^3) and the set-up is the critical path already
+        // (the direct dual solve replaces the inversion of G, the host's B rows and the whole iteration by the assembly and the inversion of S: a gain at
+        // every size it applies to -- 128^3: 12.0 -> 9.6 ms, 64^3: 4.5 -> 3.4 ms per solve -- so it is not subject to this test)
         static const bool force = getenv("SHM_DUAL_DENSE_S_ALWAYS") != nullptr;
         const double schur_est_ms = 3.1e-7 * (double)m * (double)m;
-        return force || conv_est_total_ms >= 3.0 * schur_est_ms;
+        return force || dual_direct || conv_est_total_ms >= 3.0 * schur_est_ms;
     }
     void prepare_schur() {
         hipStream_t st = stream2;

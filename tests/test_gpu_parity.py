@@ -220,7 +220,12 @@ def test_local_slabs_with_preconditioner(shm, slabs, mode):
     assert np.abs(phi - d["phi"]).max() < 1e-7
     s1 = make_solver(shm, d)
     st1 = s1.solve(tol=1e-10, **MODES[mode])
-    assert abs(st.iters - st1.iters) <= 4
+    if st1.cg_form == 2:   # one slab, dual: the direct solve (explicit S^-1) -- one or two passes instead of a CG; the slabs iterate
+        assert st1.iters <= 2 and st.iters > 4, (st.iters, st1.iters)
+        phi1, _ = s1.get_phi()
+        assert np.abs(phi1 - phi).max() < 1e-8
+    else:
+        assert abs(st.iters - st1.iters) <= 4
 
 
 @pytest.mark.parametrize("slabs", [2, 3, 5])
@@ -890,9 +895,11 @@ def test_multiprocess_ranks_on_one_gpu(shm, tmp_path, world, mode):
         assert np.abs(phi - ref).max() < 1e-9
 
 
-def test_multiprocess_noconv_still_returns_phi(shm, tmp_path):
+def test_multiprocess_noconv_still_returns_phi(shm, tmp_path, monkeypatch):
     """Two ranks, default (gathered dual) solver stopped after 4 iterations: every rank gets SHM_ERR_NOCONV *and* its planes of the
-    unconverged phi plus filled statistics (the single-rank contract of include/shm_grid.h), not SHM_ERR_STATE from get_phi."""
+    unconverged phi plus filled statistics (the single-rank contract of include/shm_grid.h), not SHM_ERR_STATE from get_phi.
+    (SHM_DUAL_NO_DIRECT: the iterative dual solver -- the direct one cannot run out of iterations.)"""
+    monkeypatch.setenv("SHM_DUAL_NO_DIRECT", "1")
     import os
     import subprocess
     import sys
