@@ -1282,13 +1282,13 @@ struct Solver final : SolverBase {
         static const bool off = getenv("SHM_DUAL_NO_DENSE_S") != nullptr;   // A/B knob: apply S through the grid (five sparse sweeps) as before
         static const int max_m = getenv("SHM_DENSE_S_MAX_M") ? atoi(getenv("SHM_DENSE_S_MAX_M")) : 16384;
         if (off || total_slabs != 1 || !precond_available() || m <= 0 || m > max_m || n > 512) return false;
-        // the assembly (216 table reads per entry: ~3.1e-7 ms per m^2 on an idle device, measured 2.5 ms at m = 2842, 41 ms at m = 12 612) has to hide behind
+        // the assembly (216 table reads per entry: ~2.2e-7 ms per m^2 on an idle device, measured 1.8 ms at m = 2842, 29 ms at m = 12 612) has to hide behind
         // this rank's Step 1 like the rest of the set-up; where Step 1 is short (<= 128^3, or a thin slab of a multi-GPU run) the sweeps through the grid are
         // cheap anyway (0.11 ms per iteration at 128^3) and the set-up is the critical path already
         // (the direct dual solve replaces the inversion of G, the host's B rows and the whole iteration by the assembly and the inversion of S: a gain at
         // every size it applies to -- 128^3: 12.0 -> 9.6 ms, 64^3: 4.5 -> 3.4 ms per solve -- so it is not subject to this test)
         static const bool force = getenv("SHM_DUAL_DENSE_S_ALWAYS") != nullptr;
-        const double schur_est_ms = 3.1e-7 * (double)m * (double)m;
+        const double schur_est_ms = 2.2e-7 * (double)m * (double)m;
         return force || dual_direct || conv_est_total_ms >= 3.0 * schur_est_ms;
     }
     void prepare_schur() {

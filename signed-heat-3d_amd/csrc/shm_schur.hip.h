@@ -97,27 +97,25 @@ __global__ __launch_bounds__(kBlock) void dgemm_rm_kernel(int M, int N, int K, c
             }
 }
 
-// S[i][j] = S[j][i] = sum_{p, q, r < 6} w_x[p] w_y[q] w_z[r] T[i_x[p]][i_y[q]][i_z[r]]   (T: (n + 1) x (n + 1) x P, last index fastest).
-// One thread per entry of a 16 x 16 tile of the Morton-sorted rows (neighbouring cells: neighbouring table entries); tiles below the diagonal are
-// left to their mirror images.
+// S[i][j] = S[j][i] = sum over the eight images (difference or sum window per axis) of sum_{p, q, r < 3} w_x w_y w_z T[i_x[p]][i_y[q]][i_z[r]]
+// (T: (n + 1) x (n + 1) x P, last index fastest).  One thread per entry of a 16 x 16 tile of the Morton-sorted rows (neighbouring cells: neighbouring
+// table entries, served by L1 / L2 -- staging a tile's index windows in LDS first was measured and is no faster: 1.79 against 1.76 ms at m = 2842);
+// tiles below the diagonal are left to their mirror images.
+__device__ __forceinline__ int schur_fold(int e, int n) { return e <= n ? e : 2 * n - e; }
 __global__ __launch_bounds__(kBlock) void schur_assemble_kernel(int m, int ld, int n, int P, const int* __restrict__ rowX /* [m][4]: cell i, j, k and the row index, in Morton order of the cells */,
                                                                 const double* __restrict__ rowT /* [m][3] */, const double* __restrict__ T, double* __restrict__ S) {
     if (blockIdx.x < blockIdx.y) return;
     const int i = blockIdx.y * 16 + (threadIdx.x >> 4), j = blockIdx.x * 16 + (threadIdx.x & 15);
     if (i >= m || j >= m || j < i) return;   // (diagonal tiles: the upper entry writes its mirror image too, so S is exactly symmetric)
-    int idx[3][6];
+    int D[3], E[3];
     double wt[3][6];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         const int Xi = rowX[4 * i + a], Xj = rowX[4 * j + a];
         const double ti = rowT[3 * i + a], tj = rowT[3 * j + a];
         const double wi0 = 1. - ti, wi1 = ti, wj0 = 1. - tj, wj1 = tj;
-        const int D = Xi - Xj, E = Xi + Xj + 1;
-        idx[a][0] = abs(D - 1);
-        idx[a][1] = abs(D);
-        idx[a][2] = abs(D + 1);
-#pragma unroll
-        for (int e = 0; e < 3; e++) idx[a][3 + e] = (E + e <= n) ? E + e : 2 * n - (E + e);
+        D[a] = Xi - Xj;
+        E[a] = Xi + Xj + 1;
         wt[a][0] = wi0 * wj1;
         wt[a][1] = wi0 * wj0 + wi1 * wj1;
         wt[a][2] = wi1 * wj0;
@@ -126,18 +124,29 @@ __global__ __launch_bounds__(kBlock) void schur_assemble_kernel(int m, int ld, i
         wt[a][5] = wi1 * wj1;
     }
     double acc = 0.;
+#pragma unroll 1
+    for (int combo = 0; combo < 8; combo++) {   // image (sigma_x, sigma_y, sigma_z): 27 terms each
+        const int sg[3] = {combo & 1, (combo >> 1) & 1, combo >> 2};
+        int pos[3][3];
 #pragma unroll
-    for (int p = 0; p < 6; p++) {
-        double sp = 0.;
+        for (int a = 0; a < 3; a++)
 #pragma unroll
-        for (int q = 0; q < 6; q++) {
-            const double* row = T + ((size_t)idx[0][p] * (n + 1) + idx[1][q]) * P;
-            double sq = 0.;
+            for (int e = 0; e < 3; e++) pos[a][e] = sg[a] ? schur_fold(E[a] + e, n) : abs(D[a] - 1 + e);
+        double sc = 0.;
 #pragma unroll
-            for (int r = 0; r < 6; r++) sq += wt[2][r] * row[idx[2][r]];
-            sp += wt[1][q] * sq;
+        for (int p = 0; p < 3; p++) {
+            double sp = 0.;
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const double* row = T + ((size_t)pos[0][p] * (n + 1) + pos[1][q]) * P;
+                double sq = 0.;
+#pragma unroll
+                for (int r = 0; r < 3; r++) sq += wt[2][3 * sg[2] + r] * row[pos[2][r]];
+                sp += wt[1][3 * sg[1] + q] * sq;
+            }
+            sc += wt[0][3 * sg[0] + p] * sp;
         }
-        acc += wt[0][p] * sp;
+        acc += sc;
     }
     const int ri = rowX[4 * i + 3], rj = rowX[4 * j + 3];
     S[(size_t)ri * ld + rj] = acc;
