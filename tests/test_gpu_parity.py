@@ -740,12 +740,18 @@ def test_full_size_constraints_and_shift(full_size):
     assert abs((pre["area"] * v).sum() / pre["area"].sum()) < 1e-10
 
 
-def test_full_size_solvers_agree_and_are_deterministic(full_size):
+def test_full_size_solvers_agree_and_are_deterministic(full_size, monkeypatch):
     f = full_size
     s, phi = f["solver"], f["phi"]
+    assert f["stats"].cg_form == 2 and f["stats"].iters <= 2 and f["stats"].rel_residual < 1e-10   # the direct dual solve (explicit S^-1), one pass
     st2 = s.solve()
     phi2, _ = s.get_phi()
     assert np.array_equal(phi, phi2)                        # fixed-order reductions: bit-identical reruns
+    monkeypatch.setenv("SHM_DUAL_NO_DIRECT", "1")           # the iterative dual solver (CG on the explicit S), read per solve
+    st_it = s.solve()
+    phi_it, _ = s.get_phi()
+    monkeypatch.delenv("SHM_DUAL_NO_DIRECT")
+    assert st_it.cg_form == 3 and st_it.iters >= 30 and np.abs(phi_it - phi).max() < 1e-8, (st_it.cg_form, st_it.iters)
     st3 = s.solve(solver="primal", precond="dct")
     phi3, _ = s.get_phi()
     assert np.abs(phi3 - phi).max() < 1e-7, (st2.iters, st3.iters)
