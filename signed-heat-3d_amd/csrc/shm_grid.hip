@@ -1297,6 +1297,8 @@ struct Solver final : SolverBase {
         if (!schur_wanted()) return;
         const int P = n + 8;   // leading dimension of the last table index (rows stay 64-byte aligned)
         const size_t n1 = (size_t)n + 1;
+        static const bool rebuild_table = getenv("SHM_SCHUR_REBUILD_TABLE") != nullptr;   // measurement knob: what the solve costs with T rebuilt every time
+        if (rebuild_table) gs_n = 0;
         if (!(gs_n == n && gs_cell == cell)) {
             gs_n = 0;   // (table invalid until enqueue_schur has queued its construction)
             const double pi = 3.14159265358979323846;
