@@ -1364,7 +1364,7 @@ struct Solver final : SolverBase {
             HIPCHK(hipMemsetAsync(gs_Ct.p, 0, (size_t)n * P * sizeof(double), st));
             hipLaunchKernelGGL(cosine_tables_kernel, dim3(grid_for(n1 * n, 1024)), dim3(kBlock), 0, st, n, P, gs_ctab.p, gs_Cm.p, gs_Ct.p);
             hipLaunchKernelGGL(green_symbol_kernel, dim3(grid_for((size_t)n * n * n, 4096)), dim3(kBlock), 0, st, n, gs_lam.p, W0.p);
-            auto tiles = [](size_t v) { return (unsigned)((v + kGJ - 1) / kGJ); };
+            auto tiles = [](size_t v) { return (unsigned)((v + kGemmT - 1) / kGemmT); };
             // W1[(k1,k2)][d3] = sum_k3 W0[(k1,k2)][k3] Ct[k3][d3]
             hipLaunchKernelGGL(dgemm_rm_kernel, dim3(tiles(P), tiles((size_t)n * n), 1), dim3(kBlock), 0, st, n * n, P, n, W0.p, n, 0LL, gs_Ct.p, P, 0LL, W1.p, P, 0LL);
             // W2[k1][d2][d3] = sum_k2 Cm[d2][k2] W1[k1][k2][d3]   (one product per k1)
