@@ -1277,7 +1277,8 @@ struct Solver final : SolverBase {
     //   enqueue_schur(): the launches -- AFTER it (the inversion is a chain of short dependent kernels; these few throughput-bound ones fill the slots it
     //                    leaves idle)
     // The Green's table T depends on the grid alone (n, h) -- it is to K what the reference's poissonSolver factorisation is to L, built when the grid is
-    // built (signed_heat_grid_solver.cpp:8-35, `rebuild`) -- so it is kept while n and h stay the same; S depends on the sources and is assembled per solve.
+    // built (signed_heat_grid_solver.cpp:8-35, `rebuild`) -- but it is cheap enough to be rebuilt with every solve (see prepare_schur); S depends on the
+    // sources and is assembled per solve.
     bool schur_wanted() const {
         static const bool off = getenv("SHM_DUAL_NO_DENSE_S") != nullptr;   // A/B knob: apply S through the grid (five sparse sweeps) as before
         static const int max_m = getenv("SHM_DENSE_S_MAX_M") ? atoi(getenv("SHM_DENSE_S_MAX_M")) : 16384;
@@ -1297,8 +1298,10 @@ struct Solver final : SolverBase {
         if (!schur_wanted()) return;
         const int P = n + 8;   // leading dimension of the last table index (rows stay 64-byte aligned)
         const size_t n1 = (size_t)n + 1;
-        static const bool rebuild_table = getenv("SHM_SCHUR_REBUILD_TABLE") != nullptr;   // measurement knob: what the solve costs with T rebuilt every time
-        if (rebuild_table) gs_n = 0;
+        // T is rebuilt with every solve (0.85 ms at 256^3, 10 ms at 512^3, beside Step 1: +1 % / +2.5 % of a solve), so that a timed solve contains all of
+        // its own work; SHM_SCHUR_KEEP_TABLE=1 keeps it while n and h stay the same (it depends on nothing else)
+        static const bool keep_table = getenv("SHM_SCHUR_KEEP_TABLE") != nullptr;
+        if (!keep_table) gs_n = 0;
         if (!(gs_n == n && gs_cell == cell)) {
             gs_n = 0;   // (table invalid until enqueue_schur has queued its construction)
             const double pi = 3.14159265358979323846;
