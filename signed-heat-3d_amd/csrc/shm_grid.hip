@@ -631,10 +631,10 @@ struct Solver final : SolverBase {
             // length (512^3: 251 ms for 6 ms of work; split in 8: 42 ms, Step 1 itself +1 %).  Chunks of ~2.5 ms of Step 1 give the set-up a window that often.
             // Only where the tiles cost about the same (the kernel spans the grid: lambda * side < 100, nothing is culled) -- with culling the persistent
             // workgroups of ONE launch balance the uneven tiles, and every extra launch adds an uneven tail (rocker 512^3 fp32, 16 launches: +10 %) -- and
-            // where Step 1 is long enough to matter (>= 10 ms); at most 8 chunks.
+            // where Step 1 is long enough to matter (>= 10 ms); at most 16 chunks (256^3: set-up done at 38 instead of 42.7 ms with 8, Step 1 unchanged).
             static const int split_env = getenv("SHM_CONV_SPLIT") ? atoi(getenv("SHM_CONV_SPLIT")) : 0;   // A/B knob (1: one launch)
             const bool uniform_tiles = lambda * cell * n < 100.;
-            const int want_chunks = split_env > 0 ? split_env : (uniform_tiles && conv_est_total_ms >= 10. ? std::min(8, (int)std::lround(conv_est_total_ms / 2.5)) : 1);
+            const int want_chunks = split_env > 0 ? split_env : (uniform_tiles && conv_est_total_ms >= 10. ? std::min(16, (int)std::lround(conv_est_total_ms / 2.5)) : 1);
             const int nchunks = std::max(1, std::min(tiles_z, want_chunks));
             const int chunk_planes = ((tiles_z + nchunks - 1) / nchunks) * tile_z;
             for (int b0 = 0; b0 < planes; b0 += chunk_planes) {
