@@ -163,6 +163,7 @@ constexpr int kConvClusterRec = 5;  // floats per cluster record: bounding spher
 //     distance that exceeds the nearest one by at most the tile diameter, so exp(-lambda (r - d0)) of the nearest source never
 //     underflows (SURVEY trap #4); the common factor exp(lambda d0) cancels in X/|X|.  Coarse grids (lambda * tile
 //     diameter > 30) take one extra sweep for exact per-node offsets.
+template <int NPT> struct ConvSrcUnroll { static constexpr int value = NPT == 8 ? 4 : 2; };   // sources in flight per lane in the packed fp32 loop
 template <typename T, int NPT>
 __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, const T* __restrict__ src /* [S][6]: pos xyz, wn xyz */,
                                                                 const float* __restrict__ src32, const float* __restrict__ clusters,
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
                 static_assert(NPT % 2 == 0, "packed fp32 path handles the lane's nodes in pairs");
                 auto sweep = [&](auto e_begin, auto e_end) {   // nodes [e_begin, e_end) of every lane against cluster c
                     constexpr int E0 = decltype(e_begin)::value, E1 = decltype(e_end)::value;
-#pragma unroll(NPT == 8 ? 4 : 2)   // four sources in flight: 228 registers, two waves per SIMD, rocker 512^3 474 -> 455 ms (8: 480, 6: 460)
+#pragma unroll ConvSrcUnroll<NPT>::value   // four sources in flight at 8 nodes per lane: 228 registers, two waves per SIMD, rocker 512^3 474 -> 455 ms (8: 480, 6: 460)
                     for (int s = c * kConvCluster; s < (c + 1) * kConvCluster; s++) {
                         const float sz = tile[6 * s + 2];
                         const float wx = tile[6 * s + 3], wy = tile[6 * s + 4], wz = tile[6 * s + 5];
