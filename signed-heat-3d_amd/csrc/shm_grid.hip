@@ -1510,20 +1510,25 @@ struct Solver final : SolverBase {
         const int lanes = (n + vec - 1) / vec;
         c.wx = 1;
         while (c.wx * 64 < lanes) c.wx <<= 1;
-        static const int nw_env = getenv("SHM_FUSED_WAVES") ? atoi(getenv("SHM_FUSED_WAVES")) : 0;  // experiment knob: 4 waves per workgroup instead of 8
-        c.nw = (nw_env == 4 && c.wx <= 4) ? 4 : 8;
-        const int wy = c.nw / c.wx;
+        // waves per workgroup: 8 (two 512-thread workgroups per CU, out of phase), 16 where a row needs 4 or more waves side by side -- with 8 the
+        // workgroup would own only 4 rows (wx = 4) or 2 (wx = 8) and re-read as many border rows from L2 as it owns: 512^3 fp64 (wx = 4), 8 -> 16 waves:
+        // DIR 5.33 -> 5.60 TB/s, RES 5.57 -> 5.88, 1.558 -> 1.50 ms per iteration; where wy is already >= 4 (256^3, 512^3 fp32) 16 waves are no better
+        static const int nw_env = getenv("SHM_FUSED_WAVES") ? atoi(getenv("SHM_FUSED_WAVES")) : 0;  // A/B knob: 4, 8 or 16 waves per workgroup
         static const int ry_env = getenv("SHM_FUSED_RY") ? atoi(getenv("SHM_FUSED_RY")) : 0;
+        c.ry = (vec == 1) ? 4 : 2;
+        if (ry_env == 4 || (ry_env == 2 && vec != 1)) c.ry = ry_env;   // (1 row per lane measured no better than 2)
+        c.nw = (nw_env == 4 && c.wx <= 4) ? 4 : (c.ry <= 2 && (nw_env == 16 || (nw_env == 0 && c.wx >= 4))) ? 16 : 8;   // (16-wave kernels exist for <= 2 rows per lane)
+        const int wy = c.nw / c.wx;
         static const int zc_env = getenv("SHM_FUSED_ZC") ? atoi(getenv("SHM_FUSED_ZC")) : 0;
         // rows per workgroup wy * ry: 8 rows per lane unless that leaves too few workgroups along y to fill the chip with deep z chunks
         // rows per lane.  The bordering rows / planes a workgroup re-reads are served by L2 (PMC: HBM traffic of both sweeps = 3.0 N T, the
         // algorithmic figure), so small row blocks cost nothing in HBM bytes and what matters is memory-level parallelism: 2 rows per lane keep
         // the kernel under 128 VGPRs = two workgroups per CU running out of phase (512^3 fp64: DIR 0.70 -> 0.60 ms, RES 0.64 -> 0.58 ms against
         // 4 rows per lane / one workgroup per CU; 8 rows per lane spill)
-        c.ry = (vec == 1) ? 4 : 2;
-        if (ry_env == 4 || (ry_env == 2 && vec != 1)) c.ry = ry_env;   // (1 row per lane measured no better than 2)
         c.yblocks = (n + wy * c.ry - 1) / (wy * c.ry);
-        const int want = std::max(1, (4 * num_cus + c.yblocks - 1) / c.yblocks);  // z chunks for ~4 workgroups per CU (two resident, two rounds)
+        // z chunks for two rounds of resident workgroups: ~4 workgroups per CU with 8 waves (two resident), ~2 with 16 (one resident; 512^3 fp64: 64
+        // instead of 32 planes per workgroup, DIR 5.65 -> 5.79 TB/s)
+        const int want = std::max(1, ((c.nw == 16 ? 2 : 4) * num_cus + c.yblocks - 1) / c.yblocks);
         c.zc = std::min(64, std::max(8, sl.nzl / want));
         if (zc_env > 0) c.zc = zc_env;
         c.zc = std::max(1, std::min(c.zc, sl.nzl));
@@ -1546,6 +1551,13 @@ struct Solver final : SolverBase {
         if constexpr (WX <= 4) {
             if (c.nw == 4) {
                 hipLaunchKernelGGL((cg_fused_kernel<T, VEC, RY, WX, 4 / WX, MODE>), dim3((unsigned)(c.yblocks * c.zchunks)), dim3(256), 0, stream, F, sl.sc.p, slot_old,
+                                   slot_new, sl.red.p, sl.pq.p, init, use_uw, alpha_slot, zsrc, pin, pout, sl.r.p, sl.partials.p);
+                return;
+            }
+        }
+        if constexpr (RY <= 2) {
+            if (c.nw == 16) {   // 16-wave workgroups: twice the rows per workgroup, half the re-read border rows (see fused_cfg)
+                hipLaunchKernelGGL((cg_fused_kernel<T, VEC, RY, WX, 16 / WX, MODE>), dim3((unsigned)(c.yblocks * c.zchunks)), dim3(1024), 0, stream, F, sl.sc.p, slot_old,
                                    slot_new, sl.red.p, sl.pq.p, init, use_uw, alpha_slot, zsrc, pin, pout, sl.r.p, sl.partials.p);
                 return;
             }
