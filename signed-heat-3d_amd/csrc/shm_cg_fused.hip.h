@@ -16,7 +16,8 @@
 // buffered); only the two rows bordering the workgroup's row block and the two planes bordering its chunk are read a second time (a
 // factor 1 + 2 / (WY RY) in y, 1 + 2 / ZC in z of loads) -- and those re-reads are L2 hits: the PMC-measured HBM traffic of both sweeps
 // is 3.0 N T, the algorithmic figure (profiles/r02_pmc_traffic.json).  The raw loads of plane k+2 are in flight while plane k is computed
-// (software prefetch in registers).  Shipped shape: RY = 2 rows per lane (103-117 VGPRs: two 512-thread workgroups per CU, out of phase),
+// (software prefetch in registers).  Shipped shape: RY = 2 rows per lane (103-117 VGPRs), 8 waves per workgroup (two 512-thread workgroups per CU, out of
+// phase) where a row needs one or two waves, 16 waves where it needs four or more (512^3 fp64, 1024^3 fp32: 8 rows per workgroup instead of 4),
 // chunks of ~64 planes, ~4 workgroups per CU in the grid; measured alternatives in DESIGN.md 4c / 6.
 // K = -L with the reference's Neumann convention (laplacian(): :278-334): an out-of-grid neighbour is the node itself.
 #pragma once
