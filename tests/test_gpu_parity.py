@@ -1047,3 +1047,38 @@ print(repr(out))
     assert d["phi_err"] < 1e-7 and a["phi_err"] < 1e-7 and b["phi_err"] < 1e-7, res
     assert abs(a["iters"] - b["iters"]) <= 2, res                       # same operator: same CG
     assert d["iters"] <= 2, d                                           # the direct solve: one pass, at most one of refinement
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("waves", ["4", "16"])
+def test_fused_sweeps_other_workgroup_shapes_match_lu_golden(waves):
+    """The fused stencil-CG sweeps ship with 8 waves per workgroup where a grid row needs one or two waves and with 16 where it needs four or more
+    (512^3 fp64, 1024^3 fp32) -- sizes the small fixtures never reach.  SHM_FUSED_WAVES forces the 4- / 16-wave kernels onto the fixtures
+    (a fresh process: the knob is read once): same LU-golden phi from the plain and the DCT-preconditioned primal solvers, fp64 and fp32 transforms."""
+    import os
+    import subprocess
+    import sys
+    from conftest import GOLDEN, ROOT
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import shm_import
+shm = shm_import.load()
+out = {}
+for case in ("bunny_small_n32", "bunny_small_n64", "bunny_pc_n32"):
+    d = np.load(%r + "/" + case + ".npz")
+    for mode, kw in (("plain", dict(solver="primal", precond="none")), ("dct", dict(solver="primal", precond="dct"))):
+        s = shm.GridSolver()
+        s.set_problem(d["pos"], d["wnormal"], d["area"], float(d["lam"]), int(d["n"]), d["bbox_min"], float(d["cell"]))
+        st = s.solve(tol=1e-10, scrub=not case.startswith("bunny_pc"), **kw)
+        phi, _ = s.get_phi()
+        out[case + "/" + mode] = (float(np.abs(phi - d["phi"]).max()), int(st.iters), int(st.cg_form))
+        s.close()
+print(repr(out))
+""" % (ROOT, GOLDEN)
+    env = dict(os.environ, SHM_FUSED_WAVES=waves)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout + p.stderr
+    res = eval(p.stdout.strip().splitlines()[-1])
+    for k, (err, iters, form) in res.items():
+        assert form == 1 and err < 1e-7, (k, err, iters, form)
