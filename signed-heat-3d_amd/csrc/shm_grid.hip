@@ -1281,7 +1281,9 @@ struct Solver final : SolverBase {
     // sources and is assembled per solve.
     bool schur_wanted() const {
         static const bool off = getenv("SHM_DUAL_NO_DENSE_S") != nullptr;   // A/B knob: apply S through the grid (five sparse sweeps) as before
-        static const int max_m = getenv("SHM_DENSE_S_MAX_M") ? atoi(getenv("SHM_DENSE_S_MAX_M")) : 16384;
+        // (beyond ~8000 rows the assembly costs Step 1 more time than the dense mat-vec saves the CG: rocker 512^3 fp32, m = 12 612: 29 ms of assembly for
+        // 36 x 0.37 ms -- 493-508 against 491-501 ms per solve with S applied through the grid)
+        static const int max_m = getenv("SHM_DENSE_S_MAX_M") ? atoi(getenv("SHM_DENSE_S_MAX_M")) : 8192;
         if (off || total_slabs != 1 || !precond_available() || m <= 0 || m > max_m || n > 512) return false;
         // the assembly (216 table reads per entry: ~2.2e-7 ms per m^2 on an idle device, measured 1.8 ms at m = 2842, 29 ms at m = 12 612) has to hide behind
         // this rank's Step 1 like the rest of the set-up; where Step 1 is short (<= 128^3, or a thin slab of a multi-GPU run) the sweeps through the grid are

@@ -41,9 +41,9 @@ def main():
     m = cfg["constraint_rows"]
     host_ms = 0.6e-3 * m + 0.3
     # set-up on an otherwise idle GPU, measured with SHM_SETUP_ALONE=1 (MI355X).  Direct dual solve (m <= 4096: S assembled and inverted): m = 1129: 2.3 ms,
-    # 1430: 4.4, 2496: 5.6, 2842: 8.4;  CG on the explicit S + two-level G^-1 (m = 12 612): 75 ms incl. the S assembly;  through the grid + two-level G^-1
-    # (m = 48 893): 145 ms; in between by the launch-bound Gauss-Jordan step count
-    measured = {1129: 2.3, 1430: 4.4, 2496: 5.6, 2842: 8.4, 2856: 8.4, 12612: 75.0, 48893: 145.0}
+    # 1430: 4.4, 2496: 5.6, 2842: 8.4;  through the grid + two-level G^-1: 26 ms at m = 12 612,
+    # 145 ms at m = 48 893; in between by the launch-bound Gauss-Jordan step count
+    measured = {1129: 2.3, 1430: 4.4, 2496: 5.6, 2842: 8.4, 2856: 8.4, 12612: 26.0, 48893: 145.0}
     setup = measured.get(m, setup_alone_ms(m, host_ms) if m <= 6144 else 3.0e-3 * m)
     print("workload %s  n=%d  m=%d  single-GPU: conv %.1f  pcg %.2f ms (%d iterations)  set-up alone ~%.1f ms" % (cfg["workload"], n, m, ph["ms_conv"], ph["ms_pcg"], cfg["cg_iters"], setup))
     print("%-28s %10s %10s %10s %10s" % ("gathered dual (AUTO)", "P=1", "P=2", "P=4", "P=8"))
