@@ -790,11 +790,19 @@ struct Solver final : SolverBase {
         build_rows();
         lap("rows");
         const size_t plane = (size_t)n * n;
+        // Direct dual solve (moderate m, explicit S): S itself is inverted on the set-up stream instead of G, and the dual system is solved with two dense
+        // mat-vecs after Step 1 -- no G, no B, no iteration (see solve_dual), and none of the host tables
+        // below that only they and the sparse sweeps of the iterative dual solver need (entries sorted by node, node -> rows hash, active tiles).
+        const bool no_direct = getenv("SHM_DUAL_NO_DIRECT") != nullptr;   // A/B knob, read per solve (tests of the iterative path flip it inside one process)
+        static const int direct_max_m = getenv("SHM_DUAL_DIRECT_MAX_M") ? atoi(getenv("SHM_DUAL_DIRECT_MAX_M")) : 4096;   // single-level Gauss-Jordan range
+        dual_direct = dual_direct_requested && !no_direct && m <= direct_max_m;
+        dual_direct = dual_direct && schur_wanted();   // (schur_wanted() reads dual_direct: with it set only the structural conditions remain)
+        const bool need_node_tables = !dual_direct;
         // ---- G = A A^T and B = A K A^T from the (node, row, coef) entries sorted by node: rows meet exactly at shared nodes.
         //      Sorted vectors instead of hash maps: the host part of the set-up is on the critical path of small / multi-GPU runs.
         struct Ent { int64_t node; int row; double coef; };
-        std::vector<Ent> ents((size_t)8 * m);
-        for (int r = 0; r < m; r++)
+        std::vector<Ent> ents(need_node_tables ? (size_t)8 * m : 0);
+        for (int r = 0; r < m && need_node_tables; r++)
             for (int e = 0; e < 8; e++) ents[(size_t)8 * r + e] = {rows[r].nodes[e], r, rows[r].coeffs[e]};
         std::sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.node != y.node ? x.node < y.node : x.row < y.row; });
         std::vector<int64_t> unode;       // distinct touched nodes, ascending
@@ -840,12 +848,6 @@ struct Solver final : SolverBase {
                 accv[(size_t)col] += v;
             }
         };
-        // Direct dual solve (moderate m, explicit S): S itself is inverted on the set-up stream instead of G, and the dual system is solved with two dense
-        // mat-vecs after Step 1 -- no G, no B, no iteration (see solve_dual).
-        const bool no_direct = getenv("SHM_DUAL_NO_DIRECT") != nullptr;   // A/B knob, read per solve (tests of the iterative path flip it inside one process)
-        static const int direct_max_m = getenv("SHM_DUAL_DIRECT_MAX_M") ? atoi(getenv("SHM_DUAL_DIRECT_MAX_M")) : 4096;   // single-level Gauss-Jordan range
-        dual_direct = dual_direct_requested && !no_direct && m <= direct_max_m;
-        dual_direct = dual_direct && schur_wanted();   // (schur_wanted() reads dual_direct: with it set only the structural conditions remain)
         // G = A A^T in CSR on the host (rows sharing a node with row r), then either scattered into the dense m x m matrix that the blocked
         // Gauss-Jordan inverts in place, or -- large m -- split into boxes and a separator (two-level inverse, shm_twolevel.hip.h)
         std::vector<int> gptr((size_t)m + 1, 0), gcol;
@@ -995,7 +997,7 @@ struct Solver final : SolverBase {
             sl.dv.alloc((size_t)7 * std::max(mp, 64));
         }
         lap("slab uploads");
-        if (total_slabs == 1 && precond_available()) build_active_tiles(unode);
+        if (total_slabs == 1 && precond_available() && need_node_tables) build_active_tiles(unode);
         lap("active tiles");
         Bptr.upload(bptr, stream);
         Bcol.upload(bcol, stream);
