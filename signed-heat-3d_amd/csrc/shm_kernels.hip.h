@@ -1141,7 +1141,11 @@ __global__ __launch_bounds__(kBlock) void gj_pivot_kernel(double* __restrict__ G
         __syncthreads();
         const double piv = rowk[pb][k];
         if (threadIdx.x == 0 && !(piv > 0.)) *flag = 1;
-        const double ip = 1. / piv;
+        // 1 / piv sits on the critical path of all 64 elimination steps: hardware reciprocal + two Newton steps (full precision for a positive,
+        // normal pivot) instead of the IEEE division sequence
+        double ip = __builtin_amdgcn_rcp(piv);
+        ip = fma(fma(-piv, ip, 1.0), ip, ip);
+        ip = fma(fma(-piv, ip, 1.0), ip, ip);
         double rv[4], cv[4];
 #pragma unroll
         for (int b = 0; b < 4; b++) rv[b] = rowk[pb][tx * 4 + b];
