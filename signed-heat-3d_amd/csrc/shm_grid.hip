@@ -415,6 +415,7 @@ struct Solver final : SolverBase {
                 order[(size_t)s] = {code, s};
             }
             std::sort(order.begin(), order.end());
+            constexpr int kConvCluster = conv_cluster<T>();
             n_clusters = (int)((S + kConvCluster - 1) / kConvCluster);
             const int64_t Spad = (int64_t)n_clusters * kConvCluster;
             std::vector<T> packed((size_t)Spad * 6, (T)0);
@@ -482,7 +483,7 @@ struct Solver final : SolverBase {
             d_src32.upload(packed32, stream);
             {   // one more level: bounding sphere / largest weight of every LDS fill's worth of clusters (kernel: kChunk = 4 in fp64, 16 in fp32), appended
                 // to the cluster records -- a node tile tests the whole fill first and only then its clusters
-                const int per = sizeof(T) == 8 ? kConvChunk : 4 * kConvChunk;
+                const int per = conv_chunk<T>();
                 const int nchunks = (n_clusters + per - 1) / per;
                 for (int g = 0; g < nchunks; g++) {
                     const int a = g * per, b = std::min(n_clusters, a + per);
@@ -586,7 +587,7 @@ struct Solver final : SolverBase {
             P.cell = cell;
             P.lambda = lambda;
             P.cexp = -lambda * 2954.639443740597;  // 2048 / ln 2
-            P.S = n_clusters * kConvCluster;
+            P.S = n_clusters * conv_cluster<T>();
             P.n_clusters = n_clusters;
             P.far_gap = (float)conv_far_gap;
             P.skip_base = (float)std::min(conv_skip_base, 3.0e38);

@@ -149,8 +149,11 @@ struct ConvParams {
 
 typedef float float2v __attribute__((ext_vector_type(2)));
 constexpr int kConvTile = 8;      // 8x8x8 nodes per workgroup, 2 per lane
-constexpr int kConvCluster = 64;  // sources per cluster (Morton-sorted on the host)
-constexpr int kConvChunk = kSrcTile / kConvCluster;  // clusters per LDS fill
+// sources per cluster (Morton-sorted on the host): 64 in the fp64 solve, 32 in the fp32 solve.  Smaller clusters have tighter bounding spheres -- 10 % fewer
+// (tile, source) pairs survive the culling at SprayBottle 1024^3 (5.38 -> 5.21 s) -- but twice the per-cluster bookkeeping, which the fp64 kernel on the
+// bunny (nothing to cull) pays with +1.2 % (42.0 -> 42.5 ms); the culled configurations are the fp32 ones
+template <typename T> constexpr int conv_cluster() { return sizeof(T) == 8 ? 64 : 32; }
+template <typename T> constexpr int conv_chunk() { return (sizeof(T) == 8 ? kSrcTile : 4 * kSrcTile) / conv_cluster<T>(); }  // clusters per LDS fill (256 / 1024 sources)
 constexpr int kConvClusterRec = 5;  // floats per cluster record: bounding sphere (centre, radius), ln of its largest source weight
 
 // Workgroup = one compact 8x8x8 tile of nodes (2 per lane); sources arrive as Morton-sorted clusters of 64 with bounding
@@ -182,7 +185,8 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
     constexpr int kHalfPlanes = kTileZ / kHalves;
     // sources per LDS fill: 256 (4 clusters) in fp64, where the fill shares the LDS with the exponential table and the fp32 copy; 1024 (16 clusters,
     // 24 KB) in fp32, whose LDS is otherwise empty -- a quarter of the fills and barriers (rocker 512^3: 54 -> 14 per tile)
-    constexpr int kChunk = kMixed ? kConvChunk : 4 * kConvChunk;
+    constexpr int kConvCluster = conv_cluster<T>();
+    constexpr int kChunk = conv_chunk<T>();
     constexpr int kFill = kChunk * kConvCluster;
     __shared__ T tile[kFill * 6];
     __shared__ float tile32[kMixed ? kFill * 6 : 1];
