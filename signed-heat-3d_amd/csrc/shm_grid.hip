@@ -284,7 +284,7 @@ struct Solver final : SolverBase {
     bool dual_direct_requested = false, dual_direct = false;   // direct dual solve: S^-1 (Sinv) instead of G^-1; requested by solve(), decided in build_constraints()
     DevArray<double> Sinv;
     double conv_est_total_ms = 1e30;   // estimate of this rank's last Step-1 launch (1e30: none was launched -- stand-alone set-up, test entry points)
-    int gs_n = 0, schur_table_builds = 0;   // grid the Green's table in gs_T was built for (0: none)
+    int gs_n = 0;   // grid the Green's table in gs_T was built for (0: none)
     double gs_cell = 0.;
     int log2n = 0;
     bool precond_ready = false;
@@ -1292,7 +1292,7 @@ struct Solver final : SolverBase {
         // this rank's Step 1 like the rest of the set-up; where Step 1 is short (<= 128^3, or a thin slab of a multi-GPU run) the sweeps through the grid are
         // cheap anyway (0.11 ms per iteration at 128^3) and the set-up is the critical path already
         // (the direct dual solve replaces the inversion of G, the host's B rows and the whole iteration by the assembly and the inversion of S: a gain at
-        // every size it applies to -- 128^3: 12.0 -> 9.6 ms, 64^3: 4.5 -> 3.4 ms per solve -- so it is not subject to this test)
+        // every size it applies to -- 128^3: 12.1 -> 9.6 ms, 64^3: 4.5 -> 2.7 ms per solve -- so it is not subject to this test)
         static const bool force = getenv("SHM_DUAL_DENSE_S_ALWAYS") != nullptr;
         const double schur_est_ms = 2.2e-7 * (double)m * (double)m;
         return force || dual_direct || conv_est_total_ms >= 3.0 * schur_est_ms;
@@ -1384,7 +1384,6 @@ struct Solver final : SolverBase {
             HIPCHK(hipGetLastError());
             gs_n = n;
             gs_cell = cell;
-            schur_table_builds++;
         }
         HIPCHK(hipMemsetAsync(Sdense.p, 0, (size_t)mp * mp * sizeof(double), st));
         const unsigned mt = (unsigned)((m + 15) / 16);
