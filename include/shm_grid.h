@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SHM_GRID_ABI_VERSION 2 /* 2: shm_stats grew by cg_form (round 2); callers allocate shm_stats by this header */
+#define SHM_GRID_ABI_VERSION 3 /* 2: shm_stats grew by cg_form (round 2); 3: by pairs_fp64 / pairs_fp32 (round 3); callers allocate shm_stats by this header */
 
 typedef struct shm_solver shm_solver; /* opaque */
 
@@ -135,6 +135,9 @@ typedef struct {
                                * 1: fused sweeps (8NT): ms_stencil_avg = DIR sweep (p' = -z + beta p, partial p'.Kp'; 3NT),
                                *    ms_update_xr_avg = RES sweep (r += alpha K p', partial ||r||^2; 3NT),
                                *    ms_update_p_avg = x += a0 p0 + a1 p1 (4NT per launch, launched every other iteration) */
+    double pairs_fp64;        /* (node, source) pairs Step 1 actually evaluated on this rank in the last solve, in fp64 arithmetic ... */
+    double pairs_fp32;        /* ... and in (packed) fp32: the tiers of shm_conv_tiered.hip.h; culled / dropped pairs are in neither.
+                               * Nominal work is N*S; the Step-1 roofline fraction is computed from these, not from N*S. */
 } shm_stats;
 
 /* --- life cycle -------------------------------------------------------------------------------- */

@@ -1,0 +1,331 @@
+// Step 1 + 2 of the fp64 solve with error-budgeted precision tiers (gfx950, wave64).
+//   reference: signed_heat_grid_solver.cpp:48-65 (mesh), :157-174 (points); yukawaPotential signed_heat_3d.cpp:45-49.
+//
+// X(x) = sum_s w_s e^{-lambda r}/r is dominated, at every node, by the handful of sources nearest to it: a source whose term is a factor
+// e^-G below the node's largest term needs a relative accuracy of only budget * e^G.  So the pairs are evaluated in two tiers:
+//   near  (fp64, division-free, 2^(k/2048) table + short polynomial: relative error ~1e-12 per term), and
+//   far   (packed fp32 with the sub-tile's exponent offset, two nodes per v_pk_*_f32 instruction, ~3e-6 per term),
+// classified per (wave sub-tile, SOURCE) -- not per (workgroup tile, cluster of 64) as the e^-25 branch of conv_normalize_kernel was: a
+// wave owns a compact 8 x 8 x NPT block of nodes and each of its 64 lanes tests one source of a 64-source cluster against that block's
+// bounds, a ballot turns the 64 answers into two scalar masks, and the wave then walks the near mask through the fp64 body and the far
+// mask through the packed fp32 body (scalar bit scans: no divergence, no per-cluster bounding sphere in the bound).
+//   far(s)  <=>  lambda (|c_w - b_s| - rt_w - r_hi_w) > G + ln(|w_s| / |w_near|)
+// with c_w / rt_w the sub-tile's centre / circumscribed radius, r_hi_w = dmin(c_w) + rt_w an upper bound of every node's distance to its
+// nearest source and w_near that source's weight: every term of s is then below e^-G of the dominant term of every node of the block.
+// The same lane-parallel test with the skip threshold drops sources whose terms vanish against the budget altogether.
+// What the far tier contributes to Y is bounded by eps32 * sum_far |term| / |X|; `tools/tier_budget.py` evaluates that on the host
+// and the GPU tests hold Y to the stated budget against the all-fp64 kernel (SHM_CONV_EXACT=1).
+#pragma once
+#include "shm_kernels.hip.h"
+
+namespace shm {
+
+// e^{-lambda r}/r from x = r^2 for the near tier: hardware v_rsq_f64 seed (2^-24) + one second-order step (relative error 3/8 e^2 ~ 1e-15 in r
+// and 1/r), exponent remainder with a single rounding against the 2048-entry table of 2^(j/2048), degree-2 polynomial of 2^(f/2048)
+// (truncation (ln2/4096)^3/6 = 8e-13).  13 fp64 VALU + v_rsq_f64 + v_ldexp_f64 + 3 integer instructions.
+__device__ __forceinline__ double yukawa_near(double x, double c, const double* __restrict__ tab) {
+    const double y0 = __builtin_amdgcn_rsq(x);
+    const double t = x * y0;
+    const double h = 0.5 * y0;
+    const double e = fma(-t, h, 0.5);            // (1 - x y0^2) / 2
+    const double r = fma(t, e, t);
+    const double rinv = fma(y0, e, y0);
+    const double tm = fma(r, c, 6755399441055744.0);   // 1.5 * 2^52: round(r c) lands in the low mantissa bits
+    const double kf = tm - 6755399441055744.0;
+    const int ki = (int)(unsigned)__double_as_longlong(tm);
+    const double f = fma(r, c, -kf);
+    double p = 5.727446245172041e-08;                   // (ln2/2048)^2 / 2
+    p = fma(p, f, 3.384507717577858e-04);               // ln2/2048
+    p = fma(p, f, 1.0);
+    return __builtin_amdgcn_ldexp(tab[ki & 2047] * p * rinv, ki >> 11);   // r = 0 -> NaN (0 * inf), like exp(0)/0 -> inf -> NaN after normalise
+}
+
+// the same for B values at once, stage by stage (breadth-first): the source order the scheduler starts from interleaves the B dependent chains
+template <int B>
+__device__ __forceinline__ void yukawa_near_batch(const double* __restrict__ x, double c, const double* __restrict__ tab, double* __restrict__ g) {
+    double y0[B], t[B], e[B], r[B], rinv[B], tm[B], f[B], p[B], tv[B];
+    int ki[B];
+#pragma unroll
+    for (int b = 0; b < B; b++) y0[b] = __builtin_amdgcn_rsq(x[b]);
+#pragma unroll
+    for (int b = 0; b < B; b++) t[b] = x[b] * y0[b];
+#pragma unroll
+    for (int b = 0; b < B; b++) e[b] = fma(-t[b], 0.5 * y0[b], 0.5);
+#pragma unroll
+    for (int b = 0; b < B; b++) r[b] = fma(t[b], e[b], t[b]);
+#pragma unroll
+    for (int b = 0; b < B; b++) tm[b] = fma(r[b], c, 6755399441055744.0);
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        ki[b] = (int)(unsigned)__double_as_longlong(tm[b]);
+        tv[b] = tab[ki[b] & 2047];
+    }
+#pragma unroll
+    for (int b = 0; b < B; b++) f[b] = fma(r[b], c, -(tm[b] - 6755399441055744.0));
+#pragma unroll
+    for (int b = 0; b < B; b++) rinv[b] = fma(y0[b], e[b], y0[b]);
+#pragma unroll
+    for (int b = 0; b < B; b++) p[b] = fma(fma(5.727446245172041e-08, f[b], 3.384507717577858e-04), f[b], 1.0);
+#pragma unroll
+    for (int b = 0; b < B; b++) g[b] = __builtin_amdgcn_ldexp(tv[b] * p[b] * rinv[b], ki[b] >> 11);
+}
+
+// a wave-uniform float as a scalar register (the builtin is integer-typed: pass the bits, not the value)
+__device__ __forceinline__ float uniform_f32(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+constexpr int kTierCluster = 64;                    // sources per cluster = lanes per wave: one source per lane in the classification
+constexpr int kTierChunk = 4;                       // clusters per LDS fill
+constexpr int kTierFill = kTierCluster * kTierChunk;
+
+// counters (optional, may be null): [0] (node, source) pairs evaluated in fp64, [1] in packed fp32 -- what `roofline.frac` is computed from.
+//
+// Work distribution: the unit of work is one wave's sub-tile (8 x 8 x NPT nodes).  Waves are independent -- each pulls the next unit from a global
+// counter (one atomic per ~1 ms of work), scans the sources for its own bounds, stages 64 sources at a time into its own LDS region (lane l loads
+// source l: the staging needs no workgroup barrier, a wave's LDS accesses execute in order) and walks its own masks.  The workgroup shares only the
+// read-only exponential table.  Units cost between ~0.3 and 1 of the all-fp64 cost depending on how much of the object is near, so static
+// assignment (and a barrier per LDS fill across four differently loaded waves) would leave the SIMDs idle for a fifth of the kernel.
+#ifndef SHM_TIER_NEAR_UNROLL
+#define SHM_TIER_NEAR_UNROLL 1
+#endif
+#ifndef SHM_TIER_FAR_UNROLL
+#define SHM_TIER_FAR_UNROLL 4
+#endif
+#ifndef SHM_TIER_NEAR_BFS
+#define SHM_TIER_NEAR_BFS 1
+#endif
+#ifndef SHM_TIER_WAVES_PER_EU
+#define SHM_TIER_WAVES_PER_EU 2
+#endif
+template <int NPT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER_WAVES_PER_EU, SHM_TIER_WAVES_PER_EU))) void conv_tiered_kernel(
+    ConvParams P, const double* __restrict__ src /* [S][6]: pos xyz, wn xyz */, const float* __restrict__ clusters,
+    const double* __restrict__ exp_tab_g /* [2048]: 2^(j/2048) */, double* __restrict__ Y0, double* __restrict__ Y1, double* __restrict__ Y2,
+    unsigned long long* __restrict__ counters, unsigned* __restrict__ next_unit /* zeroed before the launch */) {
+    static_assert(NPT % 2 == 0, "the far tier handles a lane's nodes in packed pairs");
+    constexpr int kWaves = kBlock / kWave;
+    constexpr int kNearUnroll = SHM_TIER_NEAR_UNROLL, kFarUnroll = SHM_TIER_FAR_UNROLL;
+    constexpr int kDummy = kTierCluster;   // one more staged entry: zero weight, far away -- pads the masks to whole groups of sources in flight
+    __shared__ double stage64[kWaves][(kTierCluster + 1) * 6];
+    __shared__ float stage32[kWaves][(kTierCluster + 1) * 6];
+    __shared__ double exp_tab[2048];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
+    double* const tile = stage64[wave];
+    float* const tile32 = stage32[wave];
+    for (int a = threadIdx.x; a < 2048; a += kBlock) exp_tab[a] = exp_tab_g[a];
+    if (lane < 6) {
+        const double far_away = lane < 3 ? P.bbox_min[lane] - (double)P.n * P.cell : 0.0;   // >= one grid side from every node
+        tile[kDummy * 6 + lane] = far_away;
+        tile32[kDummy * 6 + lane] = (float)far_away;
+    }
+    __syncthreads();   // the only workgroup barrier: the table
+    const int n = P.n;
+    const size_t plane = (size_t)n * n;
+    const float lam_l2 = (float)(P.lambda * 1.4426950408889634);     // lambda in powers of two per unit length
+    const float cexp32 = -lam_l2;
+    const float g_l2 = P.tier_log * 1.4426950408889634f, skip_l2 = P.skip_base * 1.4426950408889634f;
+    constexpr double kHalfZ = 0.5 * (NPT - 1);
+    const float rt_w = (float)(sqrt(3.5 * 3.5 * 2 + kHalfZ * kHalfZ) * P.cell) * 1.000001f;
+    unsigned long long cnt_near = 0, cnt_far = 0;
+    for (;;) {
+        unsigned unit = 0;
+        if (lane == 0) unit = atomicAdd(next_unit, 1u);
+        unit = (unsigned)__builtin_amdgcn_readfirstlane((int)unit);
+        if (unit >= (unsigned)P.n_tiles) break;   // n_tiles counts sub-tiles here
+        // units ordered z-sub-tile fastest inside an 8 x 8 column of tiles_zs sub-tiles?  No: x fastest, then y, then z, like the node order -- consecutive units
+        // write neighbouring rows
+        const int tz = (int)(unit / (unsigned)(P.tiles_x * P.tiles_y)), trem = (int)unit - tz * (P.tiles_x * P.tiles_y);
+        const int ty = trem / P.tiles_x, tx = trem - ty * P.tiles_x;
+        const int i0 = tx * kConvTile, j0 = ty * kConvTile, kk0 = P.kk_begin + tz * NPT;
+
+        double pz[NPT], ax[NPT], ay[NPT], az[NPT];
+        float qz[NPT], fx[NPT], fy[NPT], fz[NPT];
+        bool live[NPT];
+        size_t vidx[NPT];
+        const int li = i0 + (lane & 7), lj = j0 + (lane >> 3);
+        const int ci = min(li, n - 1), cj = min(lj, n - 1);
+        // indicesToNodePosition: (i,j,k)*cellSize + bboxMin, evaluated in double like the reference (:510-514)
+        const double px = ci * P.cell + P.bbox_min[0], py = cj * P.cell + P.bbox_min[1];
+        const float qx = (float)px, qy = (float)py;
+#pragma unroll
+        for (int e = 0; e < NPT; e++) {
+            int kk = kk0 + e;   // the wave's nodes form a compact 8 x 8 x NPT block
+            live[e] = li < n && lj < n && kk < P.kk_end;
+            kk = min(kk, P.kk_end - 1);
+            vidx[e] = (size_t)kk * plane + (size_t)cj * n + ci;
+            const double z = (P.k0 + kk - 1) * P.cell + P.bbox_min[2];
+            pz[e] = z;
+            qz[e] = (float)z;
+            ax[e] = ay[e] = az[e] = 0.;
+            fx[e] = fy[e] = fz[e] = 0.f;
+        }
+        // nearest source of the block's centre (and its weight): one source per lane and step, butterfly minimum
+        const float cx = (float)((i0 + 3.5) * P.cell + P.bbox_min[0]), cy = (float)((j0 + 3.5) * P.cell + P.bbox_min[1]);
+        const float cz = (float)((P.k0 + kk0 - 1 + kHalfZ) * P.cell + P.bbox_min[2]);
+        float dmin = 3.0e38f, wnear = 0.f;
+        for (int s = lane; s < P.S; s += kWave) {
+            const double* q = src + (size_t)s * 6;
+            const float dx = cx - (float)q[0], dy = cy - (float)q[1], dz = cz - (float)q[2];
+            const float w0 = (float)q[3], w1 = (float)q[4], w2c = (float)q[5];
+            const float d2 = dx * dx + dy * dy + dz * dz, w2 = w0 * w0 + w1 * w1 + w2c * w2c;
+            if (d2 < dmin || (d2 == dmin && w2 > wnear)) {   // ties (the zero-weight padding repeats a source) go to the larger weight
+                dmin = d2;
+                wnear = w2;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float od = __shfl_xor(dmin, off, kWave), ow = __shfl_xor(wnear, off, kWave);
+            if (od < dmin || (od == dmin && ow > wnear)) {
+                dmin = od;
+                wnear = ow;
+            }
+        }
+        dmin = sqrtf(dmin);
+        const float r_hi_w = uniform_f32(dmin * 1.000001f + rt_w);                                // every node of the block has a source at most this far
+        const float lnear_w = uniform_f32(0.5f * __log2f(fmaxf(wnear, 1e-37f)) - 1e-5f);         // log2 of that source's weight, rounded down
+        const float d0_w = uniform_f32(fmaxf(0.f, dmin * 0.999999f - rt_w));                      // no source is closer than this to any node of the block
+        const float coff = lam_l2 * d0_w;   // far tier: e^{-lambda (r - d0)} = 2^(r cexp32 + coff), folded back in by e^{-lambda d0} at the end
+
+        // the lane's source of the next cluster, loaded one cluster ahead
+        double nq[6];
+        {
+            const double* q = src + (size_t)lane * 6;
+#pragma unroll
+            for (int a = 0; a < 6; a++) nq[a] = q[a];
+        }
+#pragma unroll 1
+        for (int c = 0; c < P.n_clusters; c++) {
+            double q[6];
+#pragma unroll
+            for (int a = 0; a < 6; a++) q[a] = nq[a];
+            if (c + 1 < P.n_clusters) {
+                const double* qn = src + ((size_t)(c + 1) * kTierCluster + lane) * 6;
+#pragma unroll
+                for (int a = 0; a < 6; a++) nq[a] = qn[a];
+            }
+            {   // the whole cluster against the block (bounding sphere, scalar loads): dropped before anything is staged
+                const float* rec = clusters + (size_t)c * kConvClusterRec;
+                const float gdx = cx - rec[0], gdy = cy - rec[1], gdz = cz - rec[2];
+                const float gap = sqrtf(gdx * gdx + gdy * gdy + gdz * gdz) * 0.999999f - rt_w - rec[3] - r_hi_w;
+                if (gap * lam_l2 > skip_l2 + rec[4] * 1.4426950408889634f - lnear_w) continue;
+            }
+            // one source per lane: near / far / dropped for this wave's block of nodes
+            unsigned long long nearmask, farmask;
+            {
+                float q32[6];
+#pragma unroll
+                for (int a = 0; a < 6; a++) q32[a] = (float)q[a];
+                const float dx = cx - q32[0], dy = cy - q32[1], dz = cz - q32[2];
+                const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+                const float w2 = q32[3] * q32[3] + q32[4] * q32[4] + q32[5] * q32[5];
+                const float rel = 0.5f * __log2f(w2) + 1e-5f - lnear_w;                    // log2(|w_s| / |w_near|), rounded up (w = 0: -inf)
+                const float lhs = (dist * 0.999999f - rt_w - r_hi_w) * lam_l2;             // lower bound of lambda (r(x, s) - r_near(x)) / ln 2
+                const bool valid = w2 > 0.f;                                              // the zero-weight padding is never evaluated
+                const bool far = lhs > g_l2 + rel;
+                const bool drop = lhs > skip_l2 + rel;
+                nearmask = __ballot(valid && !far);
+                farmask = __ballot(valid && far && !drop);
+                // stage the cluster for the broadcast reads below (wave-private region: no barrier)
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+                    tile[lane * 6 + a] = q[a];
+                    tile32[lane * 6 + a] = q32[a];
+                }
+            }
+            cnt_near += (unsigned)__builtin_popcountll(nearmask);
+            cnt_far += (unsigned)__builtin_popcountll(farmask);
+            // next set bit of a scalar mask as a staged source index; an exhausted mask yields the zero-weight dummy entry
+            auto pop = [&](unsigned long long& m) {
+                const int s = m ? __builtin_ctzll(m) : kDummy;
+                m &= m - 1;
+                return s;
+            };
+            // ---- near tier: fp64, kNearUnroll sources in flight ----
+            while (nearmask) {
+                int sidx[kNearUnroll];
+#pragma unroll
+                for (int u = 0; u < kNearUnroll; u++) sidx[u] = pop(nearmask);
+                // breadth-first over the kNearUnroll x NPT pairs in flight: every stage of e^{-lambda r}/r for all of them before the next stage, so that
+                // the dependent chain of one pair (rsq -> Newton -> exponent -> table -> ldexp) is covered by the others' independent work
+                double wx[kNearUnroll], wy[kNearUnroll], wz[kNearUnroll], x[kNearUnroll][NPT];
+#pragma unroll
+                for (int u = 0; u < kNearUnroll; u++) {
+                    const int s = sidx[u];
+                    const double sz = tile[6 * s + 2];
+                    wx[u] = tile[6 * s + 3];
+                    wy[u] = tile[6 * s + 4];
+                    wz[u] = tile[6 * s + 5];
+                    const double dx = px - tile[6 * s], dy = py - tile[6 * s + 1];
+                    const double dxy2 = dx * dx + dy * dy;
+#pragma unroll
+                    for (int e = 0; e < NPT; e++) {
+                        const double dz = pz[e] - sz;
+                        x[u][e] = fma(dz, dz, dxy2);
+                    }
+                }
+                double g[kNearUnroll][NPT];
+#if SHM_TIER_NEAR_BFS
+                yukawa_near_batch<kNearUnroll * NPT>(&x[0][0], P.cexp, exp_tab, &g[0][0]);
+#else
+#pragma unroll
+                for (int u = 0; u < kNearUnroll; u++)
+#pragma unroll
+                    for (int e = 0; e < NPT; e++) g[u][e] = yukawa_near(x[u][e], P.cexp, exp_tab);
+#endif
+#pragma unroll
+                for (int u = 0; u < kNearUnroll; u++)
+#pragma unroll
+                    for (int e = 0; e < NPT; e++) {
+                        ax[e] = fma(wx[u], g[u][e], ax[e]);
+                        ay[e] = fma(wy[u], g[u][e], ay[e]);
+                        az[e] = fma(wz[u], g[u][e], az[e]);
+                    }
+            }
+            // ---- far tier: packed fp32 (two nodes per instruction), kFarUnroll sources in flight (the transcendentals' results arrive late) ----
+            while (farmask) {
+                int sidx[kFarUnroll];
+#pragma unroll
+                for (int u = 0; u < kFarUnroll; u++) sidx[u] = pop(farmask);
+#pragma unroll
+                for (int u = 0; u < kFarUnroll; u++) {
+                    const int s = sidx[u];
+                    const float sz = tile32[6 * s + 2];
+                    const float wx = tile32[6 * s + 3], wy = tile32[6 * s + 4], wz = tile32[6 * s + 5];
+                    const float dx = qx - tile32[6 * s], dy = qy - tile32[6 * s + 1];
+                    const float dxy2 = dx * dx + dy * dy;
+#pragma unroll
+                    for (int e = 0; e < NPT; e += 2) {
+                        const float2v z2 = {qz[e], qz[e + 1]};
+                        const float2v dz = z2 - sz;
+                        const float2v d2 = __builtin_elementwise_fma(dz, dz, float2v{dxy2, dxy2});
+                        const float2v rinv = {__builtin_amdgcn_rsqf(d2.x), __builtin_amdgcn_rsqf(d2.y)};
+                        const float2v r = d2 * rinv;
+                        const float2v arg = __builtin_elementwise_fma(r, float2v{cexp32, cexp32}, float2v{coff, coff});
+                        const float2v ex = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+                        const float2v g = ex * rinv;
+                        float2v a;
+                        a = __builtin_elementwise_fma(float2v{wx, wx}, g, float2v{fx[e], fx[e + 1]}); fx[e] = a.x; fx[e + 1] = a.y;
+                        a = __builtin_elementwise_fma(float2v{wy, wy}, g, float2v{fy[e], fy[e + 1]}); fy[e] = a.x; fy[e + 1] = a.y;
+                        a = __builtin_elementwise_fma(float2v{wz, wz}, g, float2v{fz[e], fz[e + 1]}); fz[e] = a.x; fz[e + 1] = a.y;
+                    }
+                }
+            }
+        }
+        const double e0 = YukawaMath<double>::exp_neg(-P.lambda * (double)d0_w);
+#pragma unroll
+        for (int e = 0; e < NPT; e++) {
+            if (!live[e]) continue;
+            const double x0 = ax[e] + (double)fx[e] * e0, x1 = ay[e] + (double)fy[e] * e0, x2 = az[e] + (double)fz[e] * e0;
+            const double nrm = sqrt(x0 * x0 + x1 * x1 + x2 * x2);
+            Y0[vidx[e]] = x0 / nrm;  // 0/0 -> NaN exactly like X /= X.norm() (:61)
+            Y1[vidx[e]] = x1 / nrm;
+            Y2[vidx[e]] = x2 / nrm;
+        }
+    }  // unit loop
+    if (counters && lane == 0) {
+        atomicAdd(&counters[0], cnt_near * (unsigned long long)(64 * NPT));
+        atomicAdd(&counters[1], cnt_far * (unsigned long long)(64 * NPT));
+    }
+}
+
+}  // namespace shm

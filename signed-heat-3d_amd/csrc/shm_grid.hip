@@ -29,6 +29,7 @@
 
 #include "../../include/shm_grid.h"
 #include "shm_kernels.hip.h"
+#include "shm_conv_tiered.hip.h"
 #include "shm_cg_fused.hip.h"
 #include "shm_twolevel.hip.h"
 #include "shm_schur.hip.h"
@@ -233,6 +234,12 @@ struct Solver final : SolverBase {
     int64_t S = 0;
     std::vector<double> h_pos, h_wn, h_area;
     double area_sum = 0., conv_far_gap = 0., conv_skip_base = 3.0e38, last_host_setup_ms = 0., last_setup_wall_ms = 0.;
+    double conv_tier_log = 0., conv_tier_skip_base = 3.0e38;   // tiered fp64 Step 1: far threshold G (nats) and its drop threshold
+    bool conv_tiered = false;                                  // fp64 only; SHM_CONV_EXACT=1 selects the all-fp64 kernel
+    DevArray<unsigned long long> d_pair_counters;              // [0] fp64 pairs, [1] fp32 pairs evaluated by the last Step 1
+    DevArray<unsigned> d_unit_counters;                        // tiered Step 1: one work-queue head per launch (zeroed at the start of every Step 1)
+    static constexpr int kMaxConvLaunches = 1024;
+    int conv_launch_index = 0;
     int n_clusters = 0;
     int conv_grid_cap = 1 << 30;
     bool o_fast_hint = false;  // the running solve is a fast-integration one: no constraint set-up beside Step 1
@@ -478,6 +485,14 @@ struct Solver final : SolverBase {
                 const double eps = sizeof(T) == 8 ? 1.1e-16 : 6.0e-8;
                 const char* sk = getenv("SHM_CONV_NO_SKIP");
                 conv_skip_base = sk ? 3.0e38 : std::log(64.0 * (double)S / eps);
+                // Tiered fp64 Step 1 (shm_conv_tiered.hip.h; default for SHM_F64): per (wave sub-tile, source), terms below e^-G of the sub-tile's dominant
+                // terms go through packed fp32.  G from the error budget on Y (1e-9, a decade inside the 1e-8 the stage test holds and
+                // two inside the 1e-7 gate on phi); sources whose terms all together stay below a tenth of that budget are dropped.
+                // SHM_CONV_EXACT=1: every pair in the reference's fp64 arithmetic (conv_normalize_kernel<double>; Y to 1e-11 of the C oracle).
+                const char* tl = getenv("SHM_CONV_TIER_LOG");
+                conv_tier_log = tl ? atof(tl) : 8.0;
+                conv_tier_skip_base = sk ? 3.0e38 : std::log(64.0 * (double)S / 1e-11);
+                conv_tiered = sizeof(T) == 8 && getenv("SHM_CONV_EXACT") == nullptr;
             }
             d_src.upload(packed, stream);
             d_src32.upload(packed32, stream);
@@ -590,7 +605,8 @@ struct Solver final : SolverBase {
             P.S = n_clusters * conv_cluster<T>();
             P.n_clusters = n_clusters;
             P.far_gap = (float)conv_far_gap;
-            P.skip_base = (float)std::min(conv_skip_base, 3.0e38);
+            P.tier_log = (float)conv_tier_log;
+            P.skip_base = (float)std::min(conv_tiered ? conv_tier_skip_base : conv_skip_base, 3.0e38);
             P.inv_lambda = (float)(1.0 / lambda);
             P.tiles_x = (n + kConvTile - 1) / kConvTile;
             P.tiles_y = P.tiles_x;
@@ -618,6 +634,7 @@ struct Solver final : SolverBase {
                 const void* kfn = npt4 ? reinterpret_cast<const void*>(conv_normalize_kernel<T, 4>) : reinterpret_cast<const void*>(conv_normalize_kernel<T, 2>);
                 if constexpr (sizeof(T) == 4)
                     if (npt8) kfn = reinterpret_cast<const void*>(conv_normalize_kernel<float, 8>);
+                if (conv_tiered) kfn = npt4 ? reinterpret_cast<const void*>(conv_tiered_kernel<4>) : reinterpret_cast<const void*>(conv_tiered_kernel<2>);
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, kBlock, 0) != hipSuccess || occ < 1) occ = 2;
                 const unsigned resident = (unsigned)(occ * num_cus);
                 const double pairs = (double)sl.nown * (double)S;
@@ -625,6 +642,7 @@ struct Solver final : SolverBase {
                 conv_est_total_ms = (&sl == &slabs[0] ? 0. : conv_est_total_ms) + conv_est_ms;
                 const double setup_est_ms = 2.2e-3 * (double)std::min<int64_t>(S, (int64_t)8 * n * n);
                 static const bool no_reserve = getenv("SHM_CONV_NO_RESERVE") != nullptr;  // A/B knob
+                if (conv_tiered) grid = std::min(grid, resident);   // its waves pull work from a queue: exactly the resident workgroups, nothing left to hand out
                 if (!no_reserve && !o_fast_hint && conv_est_ms < 4.0 * setup_est_ms && grid > resident - resident / 8) grid = resident - resident / 8;
             }
             // Several launches over z chunks instead of one: the set-up stream's kernels are dispatched only where a Step-1 launch has no workgroups left to
@@ -635,9 +653,19 @@ struct Solver final : SolverBase {
             // where Step 1 is long enough to matter (>= 10 ms); at most 16 chunks (256^3: set-up done at 38 instead of 42.7 ms with 8, Step 1 unchanged).
             static const int split_env = getenv("SHM_CONV_SPLIT") ? atoi(getenv("SHM_CONV_SPLIT")) : 0;   // A/B knob (1: one launch)
             const bool uniform_tiles = lambda * cell * n < 100.;
-            const int want_chunks = split_env > 0 ? split_env : (uniform_tiles && conv_est_total_ms >= 10. ? std::min(16, (int)std::lround(conv_est_total_ms / 2.5)) : 1);
+            // (The tiered fp64 kernel needs none of this: its grid is exactly the resident workgroups -- nothing left to hand out -- and its 176 registers leave room on
+            // every SIMD for a wave of the set-up kernels, which therefore run WHILE Step 1 runs; one launch, balanced by its work queue.)
+            const int want_chunks = split_env > 0 ? split_env : conv_tiered ? 1 : (uniform_tiles && conv_est_total_ms >= 10. ? std::min(16, (int)std::lround(conv_est_total_ms / 2.5)) : 1);
             const int nchunks = std::max(1, std::min(tiles_z, want_chunks));
             const int chunk_planes = ((tiles_z + nchunks - 1) / nchunks) * tile_z;
+            if (!d_pair_counters.p) d_pair_counters.alloc(2);
+            if (!d_unit_counters.p) d_unit_counters.alloc(kMaxConvLaunches);
+            if (&sl == &slabs[0]) {
+                HIPCHK(hipMemsetAsync(d_pair_counters.p, 0, 2 * sizeof(unsigned long long), stream));
+                if (conv_tiered) HIPCHK(hipMemsetAsync(d_unit_counters.p, 0, kMaxConvLaunches * sizeof(unsigned), stream));
+                conv_launch_index = 0;
+            }
+            unsigned long long* const cnt = d_pair_counters.p;
             for (int b0 = 0; b0 < planes; b0 += chunk_planes) {
                 ConvParams Pc = P;
                 Pc.kk_begin = 1 + b0;
@@ -648,15 +676,27 @@ struct Solver final : SolverBase {
                 if constexpr (sizeof(T) == 4) {
                     if (npt8) {
                         hipLaunchKernelGGL((conv_normalize_kernel<float, 8>), g, dim3(kBlock), 0, stream, Pc, d_src.p, d_src32.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p,
-                                           sl.Y2.p);
+                                           sl.Y2.p, cnt);
                         launched = true;
                     }
+                } else if (conv_tiered) {
+                    // the unit of work is a wave's sub-tile (8 x 8 x NPT nodes), pulled from a per-launch queue head by the waves of a grid no larger than what is resident
+                    if (conv_launch_index >= kMaxConvLaunches) throw Error(SHM_ERR_INVALID, "too many Step-1 launches");
+                    unsigned* const head = d_unit_counters.p + conv_launch_index++;
+                    const int npt = npt4 ? 4 : 2;
+                    Pc.n_tiles = P.tiles_x * P.tiles_y * ((Pc.kk_end - Pc.kk_begin + npt - 1) / npt);
+                    const dim3 gt((unsigned)std::min<long long>((Pc.n_tiles + 3) / 4, grid));
+                    if (npt4)
+                        hipLaunchKernelGGL((conv_tiered_kernel<4>), gt, dim3(kBlock), 0, stream, Pc, d_src.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p, sl.Y2.p, cnt, head);
+                    else
+                        hipLaunchKernelGGL((conv_tiered_kernel<2>), gt, dim3(kBlock), 0, stream, Pc, d_src.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p, sl.Y2.p, cnt, head);
+                    launched = true;
                 }
                 if (launched) {
                 } else if (npt4)
-                    hipLaunchKernelGGL((conv_normalize_kernel<T, 4>), g, dim3(kBlock), 0, stream, Pc, d_src.p, d_src32.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p, sl.Y2.p);
+                    hipLaunchKernelGGL((conv_normalize_kernel<T, 4>), g, dim3(kBlock), 0, stream, Pc, d_src.p, d_src32.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p, sl.Y2.p, cnt);
                 else
-                    hipLaunchKernelGGL((conv_normalize_kernel<T, 2>), g, dim3(kBlock), 0, stream, Pc, d_src.p, d_src32.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p, sl.Y2.p);
+                    hipLaunchKernelGGL((conv_normalize_kernel<T, 2>), g, dim3(kBlock), 0, stream, Pc, d_src.p, d_src32.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p, sl.Y2.p, cnt);
             }
         }
         HIPCHK(hipGetLastError());
@@ -1372,15 +1412,22 @@ struct Solver final : SolverBase {
             HIPCHK(hipMemsetAsync(gs_Ct.p, 0, (size_t)n * P * sizeof(double), st));
             hipLaunchKernelGGL(cosine_tables_kernel, dim3(grid_for(n1 * n, 1024)), dim3(kBlock), 0, st, n, P, gs_ctab.p, gs_Cm.p, gs_Ct.p);
             hipLaunchKernelGGL(green_symbol_kernel, dim3(grid_for((size_t)n * n * n, 4096)), dim3(kBlock), 0, st, n, gs_lam.p, W0.p);
+            // beside the tiered fp64 Step 1 (two 176-register waves per SIMD) only the narrow shape fits on a SIMD; otherwise the 128 x 128 tiles
+            static const bool gemm_wide_env = getenv("SHM_GREEN_WIDE") != nullptr;   // A/B knob
+            const bool narrow = conv_tiered && !gemm_wide_env;
             auto tiles = [](size_t v) { return (unsigned)((v + kGemmT - 1) / kGemmT); };
+            auto gemm = [&](unsigned batches, int M, int N, int K, const double* A, int lda, long long sA, const double* B, int ldb, long long sB, double* C, int ldc, long long sC) {
+                if (narrow)
+                    hipLaunchKernelGGL(dgemm_rm_kernel<2>, dim3((unsigned)((N + 63) / 64), tiles((size_t)M), batches), dim3(kBlock), 0, st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC);
+                else
+                    hipLaunchKernelGGL(dgemm_rm_kernel<4>, dim3(tiles((size_t)N), tiles((size_t)M), batches), dim3(kBlock), 0, st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC);
+            };
             // W1[(k1,k2)][d3] = sum_k3 W0[(k1,k2)][k3] Ct[k3][d3]
-            hipLaunchKernelGGL(dgemm_rm_kernel, dim3(tiles(P), tiles((size_t)n * n), 1), dim3(kBlock), 0, st, n * n, P, n, W0.p, n, 0LL, gs_Ct.p, P, 0LL, W1.p, P, 0LL);
+            gemm(1, n * n, P, n, W0.p, n, 0LL, gs_Ct.p, P, 0LL, W1.p, P, 0LL);
             // W2[k1][d2][d3] = sum_k2 Cm[d2][k2] W1[k1][k2][d3]   (one product per k1)
-            hipLaunchKernelGGL(dgemm_rm_kernel, dim3(tiles(P), tiles(n1), (unsigned)n), dim3(kBlock), 0, st, (int)n1, P, n, gs_Cm.p, n, 0LL, W1.p, P, (long long)n * P, W2.p, P,
-                               (long long)(n1 * P));
+            gemm((unsigned)n, (int)n1, P, n, gs_Cm.p, n, 0LL, W1.p, P, (long long)n * P, W2.p, P, (long long)(n1 * P));
             // T[d1][(d2,d3)] = sum_k1 Cm[d1][k1] W2[k1][(d2,d3)]
-            hipLaunchKernelGGL(dgemm_rm_kernel, dim3(tiles(n1 * P), tiles(n1), 1), dim3(kBlock), 0, st, (int)n1, (int)(n1 * P), n, gs_Cm.p, n, 0LL, W2.p, (int)(n1 * P), 0LL,
-                               gs_T.p, (int)(n1 * P), 0LL);
+            gemm(1, (int)n1, (int)(n1 * P), n, gs_Cm.p, n, 0LL, W2.p, (int)(n1 * P), 0LL, gs_T.p, (int)(n1 * P), 0LL);
             HIPCHK(hipGetLastError());
             gs_n = n;
             gs_cell = cell;
@@ -2396,7 +2443,23 @@ struct Solver final : SolverBase {
     }
 
     // ------------------------------------------------------------------------------------------
+    // (node, source) pairs Step 1 evaluated in the last solve, per arithmetic: what bench.py computes the Step-1 roofline fraction from
+    void report_pairs(shm_stats* st) noexcept {
+        if (!st || !d_pair_counters.p) return;
+        unsigned long long h[2] = {0, 0};
+        if (hipMemcpy(h, d_pair_counters.p, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return;
+        st->pairs_fp64 = (double)h[0];
+        st->pairs_fp32 = (double)h[1];
+    }
     void solve(const shm_opts& o_in, shm_stats* st) override {
+        struct Fin {
+            Solver* s;
+            shm_stats* st;
+            ~Fin() { s->report_pairs(st); }
+        } fin{this, st};
+        solve_impl(o_in, st);
+    }
+    void solve_impl(const shm_opts& o_in, shm_stats* st) {
         need_problem();
         HIPCHK(hipSetDevice(cfg.device));
         shm_opts o = o_in;

@@ -141,6 +141,7 @@ struct ConvParams {
     int S;              // padded to whole clusters
     int n_clusters;
     float far_gap;      // fp64 path: a cluster is "far" when d_lo(tile, cluster) - r_hi(tile) > far_gap
+    float tier_log;     // tiered fp64 path (shm_conv_tiered.hip.h): a source is "far" for a sub-tile when all its terms are below e^-tier_log of the sub-tile's dominant terms
     float skip_base;    // ln(64 S / eps): a cluster (largest weight A_c) is skipped when lambda gap > skip_base + ln(A_c / A_near)
     float inv_lambda;
     int exact_offset;   // fp32 path only: 1 = per-node nearest-source distance (coarse grids: lambda * tile diameter too large)
@@ -171,7 +172,8 @@ template <typename T, int NPT>
 __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, const T* __restrict__ src /* [S][6]: pos xyz, wn xyz */,
                                                                 const float* __restrict__ src32, const float* __restrict__ clusters,
                                                                 const double* __restrict__ exp_tab_g /* [2048]: 2^(j/2048) */,
-                                                                T* __restrict__ Y0, T* __restrict__ Y1, T* __restrict__ Y2) {
+                                                                T* __restrict__ Y0, T* __restrict__ Y1, T* __restrict__ Y2,
+                                                                unsigned long long* __restrict__ counters /* [0] fp64, [1] fp32 (node, source) pairs evaluated; may be null */) {
     // tile = 8 x 8 x (4 NPT) nodes; a lane owns the z-column (i, j, k0 + w + 4 e), e < NPT (w = its wave): the NPT nodes share
     // dx^2 + dy^2 of every source
     constexpr int kTileZ = (kBlock / 64) * NPT;
@@ -197,6 +199,7 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
         for (int a = threadIdx.x; a < kTab; a += kBlock) exp_tab[a] = exp_tab_g[a];
     const int n = P.n;
     const size_t plane = (size_t)n * n;
+    unsigned cnt_half64 = 0, cnt_half32 = 0;   // (cluster, half tile) pairs evaluated in fp64 / fp32 by this workgroup (uniform: scalar registers)
     for (int bt = blockIdx.x; bt < P.n_tiles; bt += gridDim.x) {
     __syncthreads();  // LDS reuse between consecutive tiles of this workgroup
     const int tz = bt / (P.tiles_x * P.tiles_y), trem = bt - tz * (P.tiles_x * P.tiles_y);
@@ -350,6 +353,8 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
             // (fp64: classified here, from the scalar record, not from a mask built above -- with the mask the compiler schedules the fp64 loop
             // below into 165 instead of 241 registers and Step 1 takes 44.0 instead of 40.8 ms at 256^3)
             const bool far = kMixed && record_gap(clusters + (size_t)(c0 + c) * kConvClusterRec, 0) > P.far_gap;
+            if (kMixed && !far) cnt_half64 += 1;
+            else cnt_half32 += (kHalves == 1 ? 1u : (unsigned)!sk0 + (unsigned)!sk1);
             if (far) {
 #pragma unroll 2
                 for (int s = c * kConvCluster; s < (c + 1) * kConvCluster; s++) {
@@ -440,6 +445,11 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
         Y2[vidx[e]] = x2 / nrm;
     }
     }  // tile loop
+    if (counters && threadIdx.x == 0) {
+        constexpr unsigned long long kPairsPerHalf = (unsigned long long)kConvCluster * (kBlock * kNH);
+        if (cnt_half64) atomicAdd(&counters[0], cnt_half64 * kPairsPerHalf);
+        if (cnt_half32) atomicAdd(&counters[1], cnt_half32 * kPairsPerHalf);
+    }
 }
 
 // =================================================================================================
@@ -1117,6 +1127,7 @@ constexpr int kGJ = 64;
 // per step).
 __global__ __launch_bounds__(kBlock) void gj_pivot_kernel(double* __restrict__ G, int ld, int kb, double* __restrict__ Pout, int* __restrict__ flag) {
     __shared__ double rowk[2][kGJ], colk[2][kGJ];
+    __builtin_amdgcn_s_setprio(3);   // (see gj_panels_kernel)
     const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
     const size_t o = (size_t)kb * kGJ;
     double r[4][4];
@@ -1179,29 +1190,31 @@ __global__ __launch_bounds__(kBlock) void gj_pivot_kernel(double* __restrict__ G
 __global__ __launch_bounds__(kBlock) void gj_panels_kernel(const double* __restrict__ G, int ld, int kb, const double* __restrict__ P,
                                                            double* __restrict__ R /* [..][ld]: rows r_row0 .. r_row0+63 */, int r_row0,
                                                            double* __restrict__ C /* [ld][c_ld]: columns c_col0 .. c_col0+63 */, int c_ld, int c_col0) {
-    __shared__ double p[kGJ][kGJ + 1];
+    // x alone in LDS (33 KB): the row of P a wave multiplies with is the same for all its lanes (i = t / 64) and comes through the scalar / L1 path.
+    // (With P staged as well the kernel needed 65 KB of LDS and could not be placed on a CU beside two workgroups of the tiered Step-1 kernel.)
     __shared__ double x[kGJ][kGJ + 1];
+    __builtin_amdgcn_s_setprio(3);   // set-up kernels share their SIMDs with Step-1 waves: they are short and on the critical path
     const int b = blockIdx.x;
     const size_t o = (size_t)kb * kGJ, ob = (size_t)b * kGJ;
     const bool below = b >= kb;
     for (int t = threadIdx.x; t < kGJ * kGJ; t += kBlock) {
         const int i = t / kGJ, j = t % kGJ;
-        p[i][j] = P[t];
         x[i][j] = below ? G[(ob + i) * ld + o + j] : G[(o + i) * ld + ob + j];
     }
     __syncthreads();
     for (int t = threadIdx.x; t < kGJ * kGJ; t += kBlock) {
         const int i = t / kGJ, j = t % kGJ;
         C[(ob + i) * c_ld + c_col0 + j] = below ? x[i][j] : -x[j][i];
+        const double* __restrict__ prow = P + i * kGJ;
         double s = 0.;
         if (b > kb) {
 #pragma unroll 8
-            for (int k = 0; k < kGJ; k++) s += p[i][k] * x[j][k];
+            for (int k = 0; k < kGJ; k++) s += prow[k] * x[j][k];
         } else {
 #pragma unroll 8
-            for (int k = 0; k < kGJ; k++) s += p[i][k] * x[k][j];
+            for (int k = 0; k < kGJ; k++) s += prow[k] * x[k][j];
         }
-        R[(size_t)(r_row0 + i) * ld + ob + j] = (b == kb) ? p[i][j] : s;  // the pivot block column of R carries P: G[:,kb] = -C P, G[kb,kb] = P
+        R[(size_t)(r_row0 + i) * ld + ob + j] = (b == kb) ? prow[j] : s;  // the pivot block column of R carries P: G[:,kb] = -C P, G[kb,kb] = P
     }
 }
 
@@ -1232,6 +1245,7 @@ __global__ __launch_bounds__(kBlock) void gj_update_kernel(double* __restrict__ 
                                                            const double* __restrict__ C /* [ld][c_ld] */, int c_ld, int c_col0, int K) {
     __shared__ double cs[kGJ][kGJK + 1];  // C chunk  [i][k]
     __shared__ double rs[kGJK][kGJ + 1];  // R chunk  [k][j]
+    __builtin_amdgcn_s_setprio(3);   // (see gj_panels_kernel)
     int bi, bj;
     if (TILES == GJ_ALL) {
         gj_tri_decode(blockIdx.x, bi, bj);

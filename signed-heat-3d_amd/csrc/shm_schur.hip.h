@@ -49,33 +49,43 @@ __global__ __launch_bounds__(kBlock) void cosine_tables_kernel(int n, int P, con
 // zero-filled / masked).  128 x 128 tile per workgroup, one 64 x 64 quadrant per wave as 4 x 4 v_mfma_f64_16x16x4_f64 accumulators, K in LDS chunks
 // of 16 (operand layout of gj_update_kernel), the next chunk's operands prefetched into registers under the matrix instructions: 41 TFLOP/s at n = 512
 // (a 64 x 64-tile version without the prefetch: 13).
+// WN = 4: the shape above.  WN = 2: 128 x 64 tiles, a 64 x 32 quadrant per wave -- half the accumulators (64 AGPRs; the whole kernel stays under 160 registers),
+// so that its workgroups fit on a SIMD beside two waves of the tiered fp64 Step-1 kernel (176 registers each) and the table is built WHILE Step 1 runs
+// rather than in the gaps between its launches.
 constexpr int kGemmT = 128, kGemmK = 16;
-__global__ __launch_bounds__(kBlock) void dgemm_rm_kernel(int M, int N, int K, const double* __restrict__ A, int lda, long long sA, const double* __restrict__ B, int ldb,
+template <int WN>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WN == 2 ? 3 : 2, WN == 2 ? 3 : 2))) void dgemm_rm_kernel(int M, int N, int K, const double* __restrict__ A, int lda, long long sA, const double* __restrict__ B, int ldb,
                                                           long long sB, double* __restrict__ C, int ldc, long long sC) {
+    constexpr int kTN = 32 * WN;                // columns of the workgroup tile
+    __builtin_amdgcn_s_setprio(3);              // (see gj_panels_kernel)
     __shared__ double as[kGemmT][kGemmK + 1];   // A chunk [i][k]
-    __shared__ double bs[kGemmK][kGemmT + 1];   // B chunk [k][j]
+    __shared__ double bs[kGemmK][kTN + 1];      // B chunk [k][j]
     A += (long long)blockIdx.z * sA;
     B += (long long)blockIdx.z * sB;
     C += (long long)blockIdx.z * sC;
-    const int i0 = blockIdx.y * kGemmT, j0 = blockIdx.x * kGemmT;
+    const int i0 = blockIdx.y * kGemmT, j0 = blockIdx.x * kTN;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wr = w >> 1, wc = w & 1;
     const int l15 = lane & 15, l4 = lane >> 4;
-    gj_f64x4 acc[4][4];
+    gj_f64x4 acc[4][WN];
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
-        for (int b = 0; b < 4; b++) acc[a][b] = gj_f64x4{0., 0., 0., 0.};
+        for (int b = 0; b < WN; b++) acc[a][b] = gj_f64x4{0., 0., 0., 0.};
     // the next chunk's operands travel from global memory into registers while the matrix cores work on the current one
-    constexpr int kPer = kGemmT * kGemmK / kBlock;   // elements of each operand per thread and chunk
-    double ra[kPer], rb[kPer];
+    constexpr int kPerA = kGemmT * kGemmK / kBlock, kPerB = kTN * kGemmK / kBlock;   // elements of each operand per thread and chunk
+    double ra[kPerA], rb[kPerB];
     auto fetch = [&](int kc) {
 #pragma unroll
-        for (int u = 0; u < kPer; u++) {
+        for (int u = 0; u < kPerA; u++) {
             const int t = threadIdx.x + u * kBlock;
             const int k = t & (kGemmK - 1), i = t >> 4;   // 16 consecutive k of one row of A
             ra[u] = (i0 + i < M && kc + k < K) ? A[(size_t)(i0 + i) * lda + kc + k] : 0.;
-            const int j = t & (kGemmT - 1), k2 = t >> 7;  // 128 consecutive columns of one row of B
+        }
+#pragma unroll
+        for (int u = 0; u < kPerB; u++) {
+            const int t = threadIdx.x + u * kBlock;
+            const int j = t & (kTN - 1), k2 = t / kTN;  // kTN consecutive columns of one row of B
             rb[u] = (kc + k2 < K && j0 + j < N) ? B[(size_t)(kc + k2) * ldb + j0 + j] : 0.;
         }
     };
@@ -83,33 +93,37 @@ __global__ __launch_bounds__(kBlock) void dgemm_rm_kernel(int M, int N, int K, c
     for (int kc = 0; kc < K; kc += kGemmK) {
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < kPer; u++) {
+        for (int u = 0; u < kPerA; u++) {
             const int t = threadIdx.x + u * kBlock;
             as[t >> 4][t & (kGemmK - 1)] = ra[u];
-            bs[t >> 7][t & (kGemmT - 1)] = rb[u];
+        }
+#pragma unroll
+        for (int u = 0; u < kPerB; u++) {
+            const int t = threadIdx.x + u * kBlock;
+            bs[t / kTN][t & (kTN - 1)] = rb[u];
         }
         __syncthreads();
         if (kc + kGemmK < K) fetch(kc + kGemmK);
 #pragma unroll
         for (int kk = 0; kk < kGemmK; kk += 4) {
-            double af[4], bf[4];
+            double af[4], bf[WN];
 #pragma unroll
             for (int a = 0; a < 4; a++) af[a] = as[wr * 64 + a * 16 + l15][kk + l4];
 #pragma unroll
-            for (int b = 0; b < 4; b++) bf[b] = bs[kk + l4][wc * 64 + b * 16 + l15];
+            for (int b = 0; b < WN; b++) bf[b] = bs[kk + l4][wc * 16 * WN + b * 16 + l15];
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
-                for (int b = 0; b < 4; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < WN; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
     }
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
-        for (int b = 0; b < 4; b++)
+        for (int b = 0; b < WN; b++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int row = i0 + wr * 64 + a * 16 + l4 + 4 * r, col = j0 + wc * 64 + b * 16 + l15;
+                const int row = i0 + wr * 64 + a * 16 + l4 + 4 * r, col = j0 + wc * 16 * WN + b * 16 + l15;
                 if (row < M && col < N) C[(size_t)row * ldc + col] = acc[a][b][r];
             }
 }
@@ -122,6 +136,7 @@ __device__ __forceinline__ int schur_fold(int e, int n) { return e <= n ? e : 2 
 __global__ __launch_bounds__(kBlock) void schur_assemble_kernel(int m, int ld, int n, int P, const int* __restrict__ rowX /* [m][4]: cell i, j, k and the row index, in Morton order of the cells */,
                                                                 const double* __restrict__ rowT /* [m][3] */, const double* __restrict__ T, double* __restrict__ S) {
     if (blockIdx.x < blockIdx.y) return;
+    __builtin_amdgcn_s_setprio(3);   // runs on the SIMDs Step 1 occupies (see gj_panels_kernel)
     const int i = blockIdx.y * 16 + (threadIdx.x >> 4), j = blockIdx.x * 16 + (threadIdx.x & 15);
     if (i >= m || j >= m || j < i) return;   // (diagonal tiles: the upper entry writes its mirror image too, so S is exactly symmetric)
     int D[3], E[3];

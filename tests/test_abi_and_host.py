@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol(shm):
     assert declared == set(ABI_SYMBOLS), declared ^ set(ABI_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.shm_grid_abi_version() == 2
+    assert lib.shm_grid_abi_version() == 3
 
 
 def test_no_cpu_fallback(shm):
@@ -194,6 +194,14 @@ def test_kernel_register_schedules():
     assert not spilled, spilled
     conv = by_name["void shm::conv_normalize_kernel<double, 4>"]
     assert conv["VGPRs"] >= 200 and conv["Occupancy"] == 2, conv
+    # the tiered fp64 Step 1 must leave room on every SIMD for a wave of the set-up kernels (two of its waves + one of theirs <= 512 registers, LDS likewise):
+    # that is what lets the constraint set-up run WHILE Step 1 runs instead of in the gaps between its launches
+    tier = by_name["void shm::conv_tiered_kernel<4>"]
+    assert tier["VGPRs"] <= 176 and tier["LDS Size"] <= 36 * 1024, tier
+    room = 512 - 2 * ((tier["VGPRs"] + 7) // 8 * 8)
+    for k in ("void shm::dgemm_rm_kernel<2>", "shm::gj_pivot_kernel", "shm::gj_panels_kernel", "void shm::gj_update_kernel<0>", "shm::schur_assemble_kernel", "shm::green_symbol_kernel"):
+        v = by_name[k]
+        assert v["VGPRs"] + v.get("AGPRs", 0) <= room and v["LDS Size"] <= 40 * 1024, (k, v, room)
     conv32 = by_name["void shm::conv_normalize_kernel<float, 8>"]   # four sources in flight
     assert conv32["VGPRs"] >= 200 and conv32["Occupancy"] == 2, conv32
     for k, v in by_name.items():   # the shipped shape of the fused stencil-CG sweeps: two rows per lane, four waves per SIMD
