@@ -39,6 +39,7 @@ WORKLOADS = {
     "bunny_pc_512_f64": ("data/bunny.pc", 5.0, 64),             # configs[3]
     "spraybottle_pc_1024_f32": ("data/SprayBottle.pc", 6.0, 32),  # configs[4] (.obj missing upstream -> .pc)
     "bunny_small_512_f64": ("data/bunny_small.obj", 5.0, 64),
+    "bunny_small_512_f32": ("data/bunny_small.obj", 5.0, 32),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured streaming ceiling
 
@@ -110,6 +111,26 @@ def cpu_baseline(pre, iters_cpu, tol, seconds_budget=25.0, threads=1):
                   % (threads, planes, n, t_conv_sample, t_conv, t_div, t_setup, cg_its, t_iter, iters_cpu, tol),
         "seconds_extrapolated": total,
     }
+
+
+def step1_roofline(avg, nominal_pairs, precision):
+    """Step 1+2 against the vector-ALU roofline, from the pairs the kernel evaluated (per rank)."""
+    p64, p32 = float(avg.get("pairs_fp64", 0.0)), float(avg.get("pairs_fp32", 0.0))
+    t = avg["ms_conv"] * 1e-3
+    ev = p64 + p32
+    t_at_peak = 18.0 * p64 / 78.6e12 + 18.0 * p32 / 157.3e12
+    tiered = precision == 64 and not os.environ.get("SHM_CONV_EXACT")
+    return {"kernel": "conv_tiered_kernel" if tiered else "conv_normalize_kernel", "bound": "valu",
+            "pairs_nominal": nominal_pairs, "pairs_fp64": p64, "pairs_fp32": p32,
+            "pairs_evaluated_over_nominal": ev / nominal_pairs if nominal_pairs else None,
+            "pairs_note": "pairs_fp64 / pairs_fp32 = (node, source) pairs the kernel evaluated in fp64 / packed fp32 (its own counters; shm_stats); nominal = N*S per rank. "
+                          "fp64 solve: terms below e^-8 of a node block's dominant terms take the packed-fp32 tier (error budget on Y: 1e-8, SHM_CONV_EXACT=1 = all fp64); "
+                          "sources whose terms vanish against the budget are dropped and count in neither",
+            "nominal_pairs_per_s": nominal_pairs / t, "evaluated_pairs_per_s": ev / t,
+            "achieved_TFLOPs_18_per_evaluated_pair": 18.0 * ev / t / 1e12,
+            "peak_TFLOPs_weighted": (18.0 * ev / t_at_peak / 1e12) if t_at_peak > 0 else None,
+            "frac": t_at_peak / t if t > 0 else None,
+            "launches_per_step": int(round(avg.get("conv_launches", 0)))}
 
 
 def kernel_table(avg, n_local, T, world, gathered):
@@ -333,16 +354,10 @@ def main():
                     "frac_of_hbm_peak": avg["bytes_per_iter"] / (1 if gathered else world) / (avg["ms_pcg"] / max(1.0, avg["iters"]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "ms_project_avg": avg["ms_project_avg"]},
             "kernels": kinfo,
-            # Step 1+2 is compute-bound on the vector ALU: 18 nominal flop per (node, source) pair against the
-            # fp64 / fp32 vector peak; the fp64 inner loop issues 28 fp64 VALU + 1 rsq + 1 ldexp + 3 int ops per pair (ISA count)
-            "step1": {"kernel": "conv_normalize_kernel", "bound": "valu", "pairs": float(N) * float(pre["S"]),
-                      "pairs_note": "nominal N*S; source clusters whose total contribution is below the rounding unit of a tile's dominant term are "
-                                    "skipped (bit-identical result): none on the bunny workloads, ~10% on rocker 512^3, ~70% on SprayBottle 1024^3, "
-                                    "where pairs_per_s and frac therefore overstate the arithmetic actually done",
-                      "pairs_per_s": float(N) * float(pre["S"]) / world / (avg["ms_conv"] * 1e-3),
-                      "achieved_TFLOPs_nominal_18_per_pair": 18.0 * float(N) * float(pre["S"]) / world / (avg["ms_conv"] * 1e-3) / 1e12,
-                      "peak_TFLOPs_vector": 78.6 if precision == 64 else 157.3,
-                      "frac": 18.0 * float(N) * float(pre["S"]) / world / (avg["ms_conv"] * 1e-3) / 1e12 / (78.6 if precision == 64 else 157.3)},
+            # Step 1+2 is compute-bound on the vector ALU: 18 nominal flop per (node, source) pair against the fp64 / fp32 vector
+            # peak.  Computed from the pairs the kernel actually EVALUATED (shm_stats.pairs_fp64 / pairs_fp32, counted by the kernel itself):
+            # culled / dropped pairs earn nothing, and a pair evaluated in packed fp32 is priced against the fp32 peak.
+            "step1": step1_roofline(avg, float(N) * float(pre["S"]) / world, precision),
             # the CG loop's dominant kernel against the HBM roofline (achieved = algorithmic bytes per launch / avg launch duration,
             # HIP events on the solver's stream)
             "roofline_pcg": {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -350,33 +365,30 @@ def main():
                              "note": "achieved = algorithmic bytes per launch / avg launch duration (HIP events on the solver stream, "
                                      "%d sampled launches per solve)" % int(avg["kernel_samples"])},
         }
-        # `roofline` is for the kernel that dominates the step.  Step 1+2 takes ~80% of it at 256^3 and is bound by vector-ALU
+        # `roofline` is for the kernel that dominates the step.  Step 1+2 takes > 90% of it at 256^3 and is bound by vector-ALU
         # issue (no GEMM shape, HBM traffic 3 words per node), so its roofline is the fp64/fp32 vector peak at the
-        # nominal 18 flop per pair; when the CG loop takes longer than Step 1 the HBM roofline of its dominant kernel is reported
+        # nominal 18 flop per EVALUATED pair; when the CG loop takes longer than Step 1 the HBM roofline of its dominant kernel is reported
         s1 = out["step1"]
-        conv_traffic = None   # PMC-measured HBM bytes of the Step-1 launch (profiles/r01_pmc_traffic.json): its 3 N T of output
-        if os.path.exists(tfile):
+        conv_traffic = None   # PMC-measured HBM bytes of Step 1 per step (all its launches), profiles/r03_pmc_traffic.json
+        tfile3 = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+        if os.path.exists(tfile3):
             try:
-                conv_traffic = json.load(open(tfile)).get(args.workload, {}).get("conv_normalize_kernel")
+                conv_traffic = json.load(open(tfile3)).get(args.workload, {}).get("step1_bytes_per_step")
             except Exception:
                 conv_traffic = None
         if avg["ms_conv"] >= avg["ms_pcg"]:
             # the kernel is bound by vector-ALU instruction issue -- neither of the contract's two labels ("hbm", "mfma") describes it, so it
-            # is called what it is; its peak is the fp64 / fp32 VECTOR peak (78.6 / 157.3 TFLOP/s on MI355X)
-            out["roofline"] = {"kernel": "conv_normalize_kernel", "bound": "valu",
-                               "bound_detail": "compute: vector-ALU issue (no matrix-core shape in the kernel, no MFMA instruction); peak = fp64 / fp32 "
-                                               "vector peak; SQ counters of this kernel: profiles/r02_sq_counters_conv.txt",
-                               "achieved": s1["achieved_TFLOPs_nominal_18_per_pair"],
-                               "peak": s1["peak_TFLOPs_vector"], "unit": "TFLOP/s", "frac": s1["frac"], "traffic": conv_traffic,
-                               # wave-instruction issue: slots per pair (ISA count of the inner loop, weighted by the measured issue cost of
-                               # each opcode, tools/valu_probe.hip) x pairs/s / 64 lanes, against 256 CUs x 4 SIMDs x one slot per 4 cycles at
-                               # the 2.4 GHz peak clock (the part sustains ~2.0 GHz under this fp64 load, where the same figure is ~0.98)
-                               "issue_slots_per_pair": 26.8 if precision == 64 else 9.1,
-                               "valu_issue_utilisation_at_peak_clock": (26.8 if precision == 64 else 9.1) * s1["pairs_per_s"] / 64.0 / (1024 * 2.4e9 / 4.0),
-                               "note": "one launch per step, duration = phases_ms.ms_conv (HIP events on the solver's stream); achieved = 18 nominal "
-                                       "flop x pairs / duration (SURVEY 8(d)); the fp64 loop issues 26.8 VALU slots per pair (20 fp64 ops, "
-                                       "v_rsq_f64 = 2.7 slots, 3 integer, shared dx/dy terms) = ~97% of the issue capacity at the 2.0 GHz the part "
-                                       "sustains under this load (tools/valu_probe.hip); traffic = PMC-measured HBM bytes of the launch (3 words per node written; irrelevant to the bound)"}
+            # is called what it is; its peak is the VECTOR peak (78.6 fp64 / 157.3 fp32 TFLOP/s on MI355X), weighted by the tiers' shares
+            out["roofline"] = {"kernel": s1["kernel"], "bound": "valu",
+                               "bound_detail": "compute: vector-ALU issue (no matrix-core shape in the kernel, no MFMA instruction); peak = the vector peaks of the two "
+                                               "arithmetic tiers (78.6 TFLOP/s fp64, 157.3 TFLOP/s fp32) weighted by the pairs each tier evaluated; SQ counters of this "
+                                               "kernel: profiles/r03_sq_counters_conv.txt",
+                               "achieved": s1["achieved_TFLOPs_18_per_evaluated_pair"], "peak": s1["peak_TFLOPs_weighted"], "unit": "TFLOP/s", "frac": s1["frac"],
+                               "traffic": conv_traffic,
+                               "note": "%d launch(es) per step, duration = phases_ms.ms_conv (HIP events on the solver's stream around all of them); achieved = 18 nominal "
+                                       "flop (SURVEY 8(d)) x pairs EVALUATED / duration, pairs counted by the kernel per arithmetic tier (step1.pairs_*); "
+                                       "frac = (18 pairs_fp64 / 78.6e12 + 18 pairs_fp32 / 157.3e12) / duration; traffic = PMC-measured HBM bytes of Step 1 per step, "
+                                       "summed over its launches (3 words per node written; irrelevant to the bound)" % s1["launches_per_step"]}
         else:
             out["roofline"] = dict(out["roofline_pcg"])
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only (the extra plain-CG solve below is a collective at N>1)

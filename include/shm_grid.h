@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SHM_GRID_ABI_VERSION 3 /* 2: shm_stats grew by cg_form (round 2); 3: by pairs_fp64 / pairs_fp32 (round 3); callers allocate shm_stats by this header */
+#define SHM_GRID_ABI_VERSION 3 /* 2: shm_stats grew by cg_form (round 2); 3: by pairs_fp64 / pairs_fp32 / conv_launches (round 3); callers allocate shm_stats by this header */
 
 typedef struct shm_solver shm_solver; /* opaque */
 
@@ -138,6 +138,7 @@ typedef struct {
     double pairs_fp64;        /* (node, source) pairs Step 1 actually evaluated on this rank in the last solve, in fp64 arithmetic ... */
     double pairs_fp32;        /* ... and in (packed) fp32: the tiers of shm_conv_tiered.hip.h; culled / dropped pairs are in neither.
                                * Nominal work is N*S; the Step-1 roofline fraction is computed from these, not from N*S. */
+    int32_t conv_launches;    /* kernel launches Step 1 took on this rank in the last solve (its duration ms_conv spans all of them) */
 } shm_stats;
 
 /* --- life cycle -------------------------------------------------------------------------------- */

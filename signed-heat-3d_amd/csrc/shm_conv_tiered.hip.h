@@ -73,6 +73,13 @@ __device__ __forceinline__ void yukawa_near_batch(const double* __restrict__ x, 
 // a wave-uniform float as a scalar register (the builtin is integer-typed: pass the bits, not the value)
 __device__ __forceinline__ float uniform_f32(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
+#ifndef SHM_TIER_NT
+#define SHM_TIER_NT 0
+#endif
+#ifndef SHM_TIER_TX
+#define SHM_TIER_TX 8
+#endif
+constexpr int kTierTX = SHM_TIER_TX, kTierTY = 64 / kTierTX;   // a wave's block of nodes is kTierTX x kTierTY x NPT (one z-column of NPT nodes per lane)
 constexpr int kTierCluster = 64;                    // sources per cluster = lanes per wave: one source per lane in the classification
 constexpr int kTierChunk = 4;                       // clusters per LDS fill
 constexpr int kTierFill = kTierCluster * kTierChunk;
@@ -100,7 +107,7 @@ template <int NPT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER_WAVES_PER_EU, SHM_TIER_WAVES_PER_EU))) void conv_tiered_kernel(
     ConvParams P, const double* __restrict__ src /* [S][6]: pos xyz, wn xyz */, const float* __restrict__ clusters,
     const double* __restrict__ exp_tab_g /* [2048]: 2^(j/2048) */, double* __restrict__ Y0, double* __restrict__ Y1, double* __restrict__ Y2,
-    unsigned long long* __restrict__ counters, unsigned* __restrict__ next_unit /* zeroed before the launch */) {
+    unsigned long long* __restrict__ counters, unsigned* __restrict__ next_unit /* [8] queue heads, zeroed before the launch */) {
     static_assert(NPT % 2 == 0, "the far tier handles a lane's nodes in packed pairs");
     constexpr int kWaves = kBlock / kWave;
     constexpr int kNearUnroll = SHM_TIER_NEAR_UNROLL, kFarUnroll = SHM_TIER_FAR_UNROLL;
@@ -124,31 +131,47 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
     const float cexp32 = -lam_l2;
     const float g_l2 = P.tier_log * 1.4426950408889634f, skip_l2 = P.skip_base * 1.4426950408889634f;
     constexpr double kHalfZ = 0.5 * (NPT - 1);
-    const float rt_w = (float)(sqrt(3.5 * 3.5 * 2 + kHalfZ * kHalfZ) * P.cell) * 1.000001f;
+    constexpr double kHalfX = 0.5 * (kTierTX - 1), kHalfY = 0.5 * (kTierTY - 1);
+    const float rt_w = (float)(sqrt(kHalfX * kHalfX + kHalfY * kHalfY + kHalfZ * kHalfZ) * P.cell) * 1.000001f;
     unsigned long long cnt_near = 0, cnt_far = 0;
+    // Eight queue heads, one per XCD (workgroup b runs on XCD b % 8): the units -- x fastest, then y, then z -- are cut into eight contiguous ranges, so
+    // that the two 64-byte halves of a 128-byte line of Y (x-adjacent blocks) are written through the same L2 and leave it as one line; an XCD
+    // whose range is exhausted takes units from the others' (work stealing keeps the end of the kernel balanced).
+    const unsigned n_units = (unsigned)P.n_tiles;   // n_tiles counts sub-tiles here
+    const unsigned per_q = (n_units + 7u) / 8u;
+    const unsigned my_q = blockIdx.x & 7u;
+    unsigned q_off = 0;   // queues tried so far: my_q, my_q + 1, ... (mod 8)
     for (;;) {
-        unsigned unit = 0;
-        if (lane == 0) unit = atomicAdd(next_unit, 1u);
-        unit = (unsigned)__builtin_amdgcn_readfirstlane((int)unit);
-        if (unit >= (unsigned)P.n_tiles) break;   // n_tiles counts sub-tiles here
-        // units ordered z-sub-tile fastest inside an 8 x 8 column of tiles_zs sub-tiles?  No: x fastest, then y, then z, like the node order -- consecutive units
-        // write neighbouring rows
+        unsigned unit = 0xffffffffu;
+        while (q_off < 8u) {
+            const unsigned q = (my_q + q_off) & 7u;
+            const unsigned lo = q * per_q, hi = min(n_units, lo + per_q);
+            unsigned t = 0;
+            if (lane == 0) t = atomicAdd(next_unit + q, 1u);
+            t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+            if (lo + t < hi) {
+                unit = lo + t;
+                break;
+            }
+            q_off++;
+        }
+        if (unit == 0xffffffffu) break;
         const int tz = (int)(unit / (unsigned)(P.tiles_x * P.tiles_y)), trem = (int)unit - tz * (P.tiles_x * P.tiles_y);
         const int ty = trem / P.tiles_x, tx = trem - ty * P.tiles_x;
-        const int i0 = tx * kConvTile, j0 = ty * kConvTile, kk0 = P.kk_begin + tz * NPT;
+        const int i0 = tx * kTierTX, j0 = ty * kTierTY, kk0 = P.kk_begin + tz * NPT;
 
         double pz[NPT], ax[NPT], ay[NPT], az[NPT];
         float qz[NPT], fx[NPT], fy[NPT], fz[NPT];
         bool live[NPT];
         size_t vidx[NPT];
-        const int li = i0 + (lane & 7), lj = j0 + (lane >> 3);
+        const int li = i0 + (lane % kTierTX), lj = j0 + (lane / kTierTX);
         const int ci = min(li, n - 1), cj = min(lj, n - 1);
         // indicesToNodePosition: (i,j,k)*cellSize + bboxMin, evaluated in double like the reference (:510-514)
         const double px = ci * P.cell + P.bbox_min[0], py = cj * P.cell + P.bbox_min[1];
         const float qx = (float)px, qy = (float)py;
 #pragma unroll
         for (int e = 0; e < NPT; e++) {
-            int kk = kk0 + e;   // the wave's nodes form a compact 8 x 8 x NPT block
+            int kk = kk0 + e;   // the wave's nodes form a compact kTierTX x kTierTY x NPT block
             live[e] = li < n && lj < n && kk < P.kk_end;
             kk = min(kk, P.kk_end - 1);
             vidx[e] = (size_t)kk * plane + (size_t)cj * n + ci;
@@ -159,7 +182,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
             fx[e] = fy[e] = fz[e] = 0.f;
         }
         // nearest source of the block's centre (and its weight): one source per lane and step, butterfly minimum
-        const float cx = (float)((i0 + 3.5) * P.cell + P.bbox_min[0]), cy = (float)((j0 + 3.5) * P.cell + P.bbox_min[1]);
+        const float cx = (float)((i0 + kHalfX) * P.cell + P.bbox_min[0]), cy = (float)((j0 + kHalfY) * P.cell + P.bbox_min[1]);
         const float cz = (float)((P.k0 + kk0 - 1 + kHalfZ) * P.cell + P.bbox_min[2]);
         float dmin = 3.0e38f, wnear = 0.f;
         for (int s = lane; s < P.S; s += kWave) {
@@ -317,9 +340,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
             if (!live[e]) continue;
             const double x0 = ax[e] + (double)fx[e] * e0, x1 = ay[e] + (double)fy[e] * e0, x2 = az[e] + (double)fz[e] * e0;
             const double nrm = sqrt(x0 * x0 + x1 * x1 + x2 * x2);
-            Y0[vidx[e]] = x0 / nrm;  // 0/0 -> NaN exactly like X /= X.norm() (:61)
+            // 0/0 -> NaN exactly like X /= X.norm() (:61).  A wave writes 64-byte row segments (8 nodes: half lines); the x-adjacent block is a neighbouring
+            // unit of the same XCD's queue, so the two halves meet in that XCD's L2: PMC, kernel alone (tools/conv_pmc.sh): 412 MB written for 384 MB of
+            // output (non-temporal stores: 497 MB; 16 x 4 x NPT blocks: 387 MB but 7 % slower -- the wider block classifies fewer sources as far)
+#if SHM_TIER_NT
+            __builtin_nontemporal_store(x0 / nrm, &Y0[vidx[e]]);
+            __builtin_nontemporal_store(x1 / nrm, &Y1[vidx[e]]);
+            __builtin_nontemporal_store(x2 / nrm, &Y2[vidx[e]]);
+#else
+            Y0[vidx[e]] = x0 / nrm;
             Y1[vidx[e]] = x1 / nrm;
             Y2[vidx[e]] = x2 / nrm;
+#endif
         }
     }  // unit loop
     if (counters && lane == 0) {

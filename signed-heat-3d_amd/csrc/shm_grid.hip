@@ -237,9 +237,10 @@ struct Solver final : SolverBase {
     double conv_tier_log = 0., conv_tier_skip_base = 3.0e38;   // tiered fp64 Step 1: far threshold G (nats) and its drop threshold
     bool conv_tiered = false;                                  // fp64 only; SHM_CONV_EXACT=1 selects the all-fp64 kernel
     DevArray<unsigned long long> d_pair_counters;              // [0] fp64 pairs, [1] fp32 pairs evaluated by the last Step 1
-    DevArray<unsigned> d_unit_counters;                        // tiered Step 1: one work-queue head per launch (zeroed at the start of every Step 1)
-    static constexpr int kMaxConvLaunches = 1024;
+    DevArray<unsigned> d_unit_counters;                        // tiered Step 1: eight work-queue heads (one per XCD) per launch (zeroed at the start of every Step 1)
+    static constexpr int kMaxConvLaunches = 256;
     int conv_launch_index = 0;
+    int conv_launches_last = 0;   // launches of the last Step 1 (all slabs of this rank)
     int n_clusters = 0;
     int conv_grid_cap = 1 << 30;
     bool o_fast_hint = false;  // the running solve is a fast-integration one: no constraint set-up beside Step 1
@@ -659,14 +660,16 @@ struct Solver final : SolverBase {
             const int nchunks = std::max(1, std::min(tiles_z, want_chunks));
             const int chunk_planes = ((tiles_z + nchunks - 1) / nchunks) * tile_z;
             if (!d_pair_counters.p) d_pair_counters.alloc(2);
-            if (!d_unit_counters.p) d_unit_counters.alloc(kMaxConvLaunches);
+            if (!d_unit_counters.p) d_unit_counters.alloc(8 * kMaxConvLaunches);
             if (&sl == &slabs[0]) {
                 HIPCHK(hipMemsetAsync(d_pair_counters.p, 0, 2 * sizeof(unsigned long long), stream));
-                if (conv_tiered) HIPCHK(hipMemsetAsync(d_unit_counters.p, 0, kMaxConvLaunches * sizeof(unsigned), stream));
+                if (conv_tiered) HIPCHK(hipMemsetAsync(d_unit_counters.p, 0, 8 * kMaxConvLaunches * sizeof(unsigned), stream));
                 conv_launch_index = 0;
+                conv_launches_last = 0;
             }
             unsigned long long* const cnt = d_pair_counters.p;
             for (int b0 = 0; b0 < planes; b0 += chunk_planes) {
+                conv_launches_last++;
                 ConvParams Pc = P;
                 Pc.kk_begin = 1 + b0;
                 Pc.kk_end = std::min(sl.nzl + 1, 1 + b0 + chunk_planes);
@@ -682,9 +685,11 @@ struct Solver final : SolverBase {
                 } else if (conv_tiered) {
                     // the unit of work is a wave's sub-tile (8 x 8 x NPT nodes), pulled from a per-launch queue head by the waves of a grid no larger than what is resident
                     if (conv_launch_index >= kMaxConvLaunches) throw Error(SHM_ERR_INVALID, "too many Step-1 launches");
-                    unsigned* const head = d_unit_counters.p + conv_launch_index++;
+                    unsigned* const head = d_unit_counters.p + 8 * conv_launch_index++;   // eight queue heads (one per XCD) per launch
                     const int npt = npt4 ? 4 : 2;
-                    Pc.n_tiles = P.tiles_x * P.tiles_y * ((Pc.kk_end - Pc.kk_begin + npt - 1) / npt);
+                    Pc.tiles_x = (n + kTierTX - 1) / kTierTX;
+                    Pc.tiles_y = (n + kTierTY - 1) / kTierTY;
+                    Pc.n_tiles = Pc.tiles_x * Pc.tiles_y * ((Pc.kk_end - Pc.kk_begin + npt - 1) / npt);
                     const dim3 gt((unsigned)std::min<long long>((Pc.n_tiles + 3) / 4, grid));
                     if (npt4)
                         hipLaunchKernelGGL((conv_tiered_kernel<4>), gt, dim3(kBlock), 0, stream, Pc, d_src.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p, sl.Y2.p, cnt, head);
@@ -2450,6 +2455,7 @@ struct Solver final : SolverBase {
         if (hipMemcpy(h, d_pair_counters.p, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return;
         st->pairs_fp64 = (double)h[0];
         st->pairs_fp32 = (double)h[1];
+        st->conv_launches = conv_launches_last;
     }
     void solve(const shm_opts& o_in, shm_stats* st) override {
         struct Fin {

@@ -4,9 +4,7 @@
 cd $(dirname $0)/../signed-heat-3d_amd/csrc
 mkdir -p ../lib/variants
 build() { name=$1; shift; /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-parameter "$@" -shared shm_grid.hip -o ../lib/variants/libshm_grid_$name.so -ldl 2>&1 | grep -E "error" ; echo built $name; }
-build w2bfs -DSHM_TIER_WAVES_PER_EU=2 &
-build w2dfs -DSHM_TIER_WAVES_PER_EU=2 -DSHM_TIER_NEAR_BFS=0 &
-build w2bfsf2 -DSHM_TIER_WAVES_PER_EU=2 -DSHM_TIER_FAR_UNROLL=2 &
-build w3dfsf2 -DSHM_TIER_WAVES_PER_EU=3 -DSHM_TIER_NEAR_BFS=0 -DSHM_TIER_FAR_UNROLL=2 &
+build nont -DSHM_TIER_NT=0 &
+build tx16nont -DSHM_TIER_TX=16 -DSHM_TIER_NT=0 &
 wait
 ls -la ../lib/variants
