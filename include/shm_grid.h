@@ -80,7 +80,11 @@ typedef struct {
                                * PRIMAL: ||P r|| <= tol * ||P b||, r the grid residual projected on null(A).
                                * DUAL / DUAL_SLABS: ||r_mu|| <= tol * ||r_mu,0||, r_mu = Pm(A K^+ b - S mu) the residual of the
                                * m-dimensional multiplier system (what that solver iterates on).  Both bound the error of phi; they
-                               * are not the same number (measured at 256^3: tol 1e-8 -> L_inf(phi) 4e-10..3e-9 for DUAL, 4e-8 PRIMAL). */
+                               * are not the same number (measured at 256^3: tol 1e-8 -> L_inf(phi) 4e-10..3e-9 for DUAL, 4e-8 PRIMAL).
+                               * DUAL with the explicit S^-1 (stats.cg_form == 2) is a direct solve plus iterative refinement: at most min(max_iters, 6)
+                               * passes; it lands at ~eps * cond(S) (1e-14 ... 1e-11) in the first.  A tol below that floor does not end in
+                               * SHM_ERR_NOCONV: once a pass stops reducing the residual and rel_residual < 1e-9 the solve is accepted as converged and
+                               * stats.rel_residual reports what was reached. */
     int32_t max_iters;        /* <=0 -> default 20*n */
     int32_t check_every;      /* residual is inspected on the host every this many iterations; <=0 -> 32 (4 with the preconditioner) */
     int32_t preconditioner;   /* SHM_PRECOND_AUTO | _NONE | _DCT  (primal solver only) */

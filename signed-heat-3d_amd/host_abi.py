@@ -21,7 +21,7 @@ def load_host_library():
     if _LIB is not None:
         return _LIB
     load_library()  # libshm_grid.so first (libshm_host.so links it through $ORIGIN)
-    path = os.path.join(_HERE, "lib", "libshm_host.so")
+    path = os.environ.get("SHM_HOST_LIB") or os.path.join(_HERE, "lib", "libshm_host.so")   # SHM_HOST_LIB: another build (tools/san_check.sh: the sanitizer build)
     if not os.path.exists(path):
         raise OSError("libshm_host.so not built (%s): run __graft_entry__.build()" % path)
     lib = C.CDLL(path)

@@ -28,7 +28,7 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def oracle_c():
     """ctypes handle of the C oracle (test infrastructure); built on demand with gcc."""
-    so = os.path.join(ROOT, "oracle", "_build", "libshm_oracle.so")
+    so = os.environ.get("SHM_ORACLE_LIB") or os.path.join(ROOT, "oracle", "_build", "libshm_oracle.so")   # SHM_ORACLE_LIB: the sanitizer build (tools/san_check.sh)
     if not os.path.exists(so):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
     lib = ctypes.CDLL(so)

@@ -801,6 +801,72 @@ def test_full_size_solvers_agree_and_are_deterministic(full_size, monkeypatch):
     assert phi.argmax() == 0 and abs(phi.max() - 4.474) < 2e-3 and abs(phi.min() + 0.5996) < 2e-3   # profiles/r01_parity_*.json
 
 
+@pytest.mark.parametrize("case", ["bunny_small_n32", "bunny_small_n64"])
+def test_direct_dual_solve_accepts_the_rounding_floor(shm, case):
+    """A tolerance below eps * cond(S) cannot be met; the direct dual solve (explicit S^-1 + iterative refinement, <= 6 passes) must notice that its passes
+    have stopped gaining and return the converged field with the residual it reached, not SHM_ERR_NOCONV (include/shm_grid.h, shm_opts.tol)."""
+    d = load_golden(case)
+    s = make_solver(shm, d)
+    st = s.solve(tol=1e-17)             # would raise on SHM_ERR_NOCONV
+    assert st.cg_form == 2 and 2 <= st.iters <= 6 and st.rel_residual < 1e-9, (st.cg_form, st.iters, st.rel_residual)
+    phi, _ = s.get_phi()
+    assert np.abs(phi - d["phi"]).max() < 1e-7
+
+
+def test_config3_bunny_pc_512_fp64_full_size(shm):
+    """BASELINE.json configs[3] on one GPU at its full size: data/bunny.pc (point overload: no divYt scrub, signed_heat_grid_solver.cpp:116-222, :179-180),
+    hCoef 5 = 512^3, fp64; areas / h from the build's estimator (inputs of the ABI).  Size-independent properties: KKT stationarity off the
+    constraint stencils (independent laplacian_kernel), equal rows of A phi, zero area-weighted source mean, bit-identical reruns, and L_inf against the
+    primal + DCT solver (a different algorithm on the same KKT system) <= 1e-7."""
+    import psutil
+    if psutil.virtual_memory().available < 12 * 2 ** 30:
+        pytest.skip("needs ~8 GB of host memory for the float64 copies of phi, b and L phi at 512^3")
+    pre = _preprocess("bunny.pc", 5.0)
+    n = pre["n"]
+    assert n == 512 and pre["S"] == 1430
+    s = shm.GridSolver()
+    s.set_problem(pre["pos"], pre["wnormal"], pre["area"], pre["lam"], n, pre["bbox_min"], pre["cell"])
+    s.run_conv()
+    s.run_divergence(False)                                   # point overload: non-finite entries are NOT zeroed (:180)
+    b = s.get_field(s.FIELD_DIV)
+    assert np.isfinite(b).all()
+    st = s.solve(scrub=False)                                 # library defaults: dual solver, tol 1e-8
+    phi, _ = s.get_phi()
+    assert np.isfinite(phi).all()
+    assert st.m == 1430 and st.cg_form == 2 and st.iters <= 2 and st.rel_residual < 1e-10
+    nodes, coeffs = s.get_constraints()
+    assert nodes.shape[0] == st.m
+    g = s.apply_laplacian(phi) + b
+    touched = np.zeros(phi.size, dtype=bool)
+    touched[nodes.ravel()] = True
+    scale = np.abs(b).max()
+    assert np.abs(g[~touched]).max() < 1e-6 * scale
+    assert np.abs(g[touched]).max() > 1e-3 * scale           # the multipliers are not trivially zero
+    del g, touched
+    rows = (coeffs * phi[nodes]).sum(axis=1)
+    assert rows.max() - rows.min() < 1e-8
+    h, b0 = pre["cell"], pre["bbox_min"]
+    ijk = np.floor((pre["pos"] - b0) / h).astype(np.int64)
+    tx, ty, tz = ((pre["pos"][:, a] - (ijk[:, a] * h + b0[a])) / h for a in range(3))
+    at = lambda di, dj, dk: phi[(ijk[:, 0] + di) + (ijk[:, 1] + dj) * n + (ijk[:, 2] + dk) * n * n]  # noqa: E731
+    v00 = at(0, 0, 0) * (1 - tx) + at(1, 0, 0) * tx
+    v01 = at(0, 0, 1) * (1 - tx) + at(1, 0, 1) * tx
+    v10 = at(0, 1, 0) * (1 - tx) + at(1, 1, 0) * tx
+    v11 = at(0, 1, 1) * (1 - tx) + at(1, 1, 1) * tx
+    v = (v00 * (1 - ty) + v10 * ty) * (1 - tz) + (v01 * (1 - ty) + v11 * ty) * tz
+    assert abs((pre["area"] * v).sum() / pre["area"].sum()) < 1e-10
+    s.solve(scrub=False)
+    phi2, _ = s.get_phi()
+    assert np.array_equal(phi, phi2)                          # fixed-order reductions and a deterministic work queue result: bit-identical reruns
+    del phi2
+    st3 = s.solve(scrub=False, solver="primal", precond="dct", tol=1e-10)
+    phi3, _ = s.get_phi()
+    e = float(np.abs(phi3 - phi).max())
+    print("\nconfigs[3] bunny.pc 512^3 fp64: m %d, direct dual passes %d, primal+dct iters %d, L_inf(dual - primal) = %.3e, max|phi| %.3f" % (st.m, st.iters, st3.iters, e, np.abs(phi).max()))
+    assert e < 1e-7, e
+    assert phi.argmax() == 0 and phi.min() < 0 < phi.max()
+
+
 def test_headless_cli_reproduces_golden(tmp_path):
     """shm_grid_cli = headless solve() (src/main.cpp:68-114): same flags, `min/max` line, phi written as raw float64."""
     import os
@@ -897,51 +963,99 @@ def test_preconditioner_1024_property(shm):
 
 
 # ---- several PROCESSES (ranks) on one GPU through a shared-memory double of librccl --------------------------------------
-@pytest.mark.parametrize("world,mode", [(2, "dual"), (4, "dual"), (8, "dual"), (2, "dual-slabs"), (4, "dual-slabs"), (2, "primal-plain"), (8, "primal-plain"),
-                                        (2, "primal-dct"), (8, "primal-dct"), (4, "fast"), (8, "fast"),
-                                        (2, "primal-plain+overlap"), (4, "primal-dct+overlap")])
-def test_multiprocess_ranks_on_one_gpu(shm, tmp_path, world, mode):
-    """The real multi-rank code path (rank-major z-slabs, halo send/recv, all-reduces, the gather of D^T Y in front of the whole-grid
-    dual solve ("dual"), the all-to-all transposes of the distributed DCT ("dual-slabs", "primal-dct"), the slab-chained fast
-    integration) with one process per rank.  RCCL refuses two ranks on one device, so its nine entry
-    points are replaced by tests/native/rccl_mock.c (SHM_RCCL_LIB) -- everything above the transport is the product code."""
+def _build_rccl_mock(tmp_path):
     import os
     import subprocess
-    import sys
     from conftest import ROOT
     so = str(tmp_path / "librccl_mock.so")
     subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", os.path.join(ROOT, "tests", "native", "rccl_mock.c"), "-o", so, "-I/opt/rocm/include",
                            "-D__HIP_PLATFORM_AMD__", "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread"])
-    case = "bunny_small_fast_n32" if mode == "fast" else "bunny_small_n32"
-    uid = ("/shmmock_%d_%s_%d" % (os.getpid(), mode.replace("-", "").replace("+", ""), world)).encode().ljust(128, b"\x00")
+    return so
+
+
+def _run_ranks(tmp_path, so, world, case, mode, tag, extra_env=None):
+    """One process per rank on GPU 0 through the shared-memory double of librccl; returns phi (rank-major concatenation) and the per-rank metadata."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    uid = ("/shmmock_%d_%s_%d" % (os.getpid(), tag, world)).encode().ljust(128, b"\x00")
     env = dict(os.environ, SHM_RCCL_LIB=so)
-    if mode.endswith("+overlap"):
-        # z chunks of 2 planes: every slab (16 / 8 planes) has interior chunks, so the ghost planes of z travel on the second stream while the
-        # interior chunks of the DIR sweep run, and the first / last chunk follow (the default chunking leaves < 3 chunks at 32^3: no split)
-        env["SHM_FUSED_ZC"] = "2"
-        mode = mode[:-len("+overlap")]
+    env.update(extra_env or {})
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multiproc_worker.py"), str(r), str(world), uid.hex(), case, mode, str(tmp_path)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
-    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
-    d = load_golden(case)
-    parts, covered = [], 0
+    parts, metas, covered = [], [], 0
     for r in range(world):
         k0, k1, iters, shift = np.load(tmp_path / ("meta_%d.npy" % r))
         assert int(k0) == covered
         covered = int(k1)
         parts.append(np.load(tmp_path / ("phi_%d.npy" % r)))
+        metas.append((int(k0), int(k1), int(iters), float(shift)))
+    return np.concatenate(parts), metas, covered
+
+
+# ---- several PROCESSES (ranks) on one GPU through a shared-memory double of librccl --------------------------------------
+@pytest.mark.parametrize("world,mode,case", [(2, "dual", "bunny_small_n32"), (4, "dual", "bunny_small_n32"), (8, "dual", "bunny_small_n32"),
+                                             (2, "dual-slabs", "bunny_small_n32"), (4, "dual-slabs", "bunny_small_n32"),
+                                             (2, "primal-plain", "bunny_small_n32"), (8, "primal-plain", "bunny_small_n32"),
+                                             (2, "primal-dct", "bunny_small_n32"), (8, "primal-dct", "bunny_small_n32"),
+                                             (4, "fast", "bunny_small_fast_n32"), (8, "fast", "bunny_small_fast_n32"),
+                                             (2, "primal-plain+overlap", "bunny_small_n32"), (4, "primal-dct+overlap", "bunny_small_n32"),
+                                             # the point overload (configs[3]: no divYt scrub, signed_heat_grid_solver.cpp:116-222) through the rank path
+                                             (2, "dual", "bunny_pc_n32"), (8, "dual", "bunny_pc_n32"), (2, "primal-dct", "bunny_pc_n32"), (8, "primal-dct", "bunny_pc_n32")])
+def test_multiprocess_ranks_on_one_gpu(shm, tmp_path, world, mode, case):
+    """The real multi-rank code path (rank-major z-slabs, halo send/recv, all-reduces, the gather of D^T Y in front of the whole-grid
+    dual solve ("dual"), the all-to-all transposes of the distributed DCT ("dual-slabs", "primal-dct"), the slab-chained fast
+    integration) with one process per rank.  RCCL refuses two ranks on one device, so its nine entry
+    points are replaced by tests/native/rccl_mock.c (SHM_RCCL_LIB) -- everything above the transport is the product code."""
+    so = _build_rccl_mock(tmp_path)
+    extra = {}
+    if mode.endswith("+overlap"):
+        # z chunks of 2 planes: every slab (16 / 8 planes) has interior chunks, so the ghost planes of z travel on the second stream while the
+        # interior chunks of the DIR sweep run, and the first / last chunk follow (the default chunking leaves < 3 chunks at 32^3: no split)
+        extra["SHM_FUSED_ZC"] = "2"
+        extra["SHM_HALO_OVERLAP"] = "1"
+        mode = mode[:-len("+overlap")]
+    phi, metas, covered = _run_ranks(tmp_path, so, world, case, mode, mode.replace("-", "") + case[-6:].replace("_", ""), extra)
+    d = load_golden(case)
+    for (_, _, _, shift) in metas:
         assert abs(shift - float(d["shift"])) < 1e-7
     assert covered == 32
-    phi = np.concatenate(parts)
     assert np.abs(phi - d["phi"]).max() < (1e-9 if mode == "fast" else 1e-7)
     if mode.startswith("primal"):
         # against the SAME solver on one rank: the per-slab partial sums are added in rank order (deterministic, but a different order than
         # the one-slab sum), so the results agree to rounding amplified by the CG, not bit for bit
         s1 = make_solver(shm, d)
-        s1.solve(tol=1e-10, **MODES[mode])
+        s1.solve(tol=1e-10, scrub="_pc_" not in case, **MODES[mode])
         ref, _ = s1.get_phi()
         assert np.abs(phi - ref).max() < 1e-9
+
+
+@pytest.mark.parametrize("mode", ["dual", "primal-dct"])
+def test_multiprocess_ranks_culled_fp32(shm, oracle_c, tmp_path, mode):
+    """A culled fp32 workload through the rank path (configs[4] in small: SprayBottle.pc, 64^3, four ranks): Step 1 skips most source clusters per
+    tile and the slabs differ in how many they keep; every rank must still produce its planes of the single-rank answer.  Against the fp64 C oracle
+    at fp32 tolerance, and against the same fp32 solver on one rank much tighter."""
+    import os
+    so = _build_rccl_mock(tmp_path)
+    world, case = 4, "file:SprayBottle.pc:2"
+    phi, metas, covered = _run_ranks(tmp_path, so, world, case, mode, "spray" + mode.replace("-", ""), {"SHM_WORKER_PRECISION": "32"})
+    pre = _preprocess("SprayBottle.pc", 2.0)
+    n, S = pre["n"], pre["S"]
+    assert n == 64 and covered == n and np.isfinite(phi).all()
+    _, st1, phi1 = _gpu_phi(shm, pre, shm.SHM_F32, False, **MODES[mode])
+    span = np.abs(phi1).max()
+    assert np.abs(phi - phi1).max() < 3e-5 * span, (np.abs(phi - phi1).max(), span)
+    ref = np.zeros(n ** 3)
+    st = np.zeros(5)
+    oracle_c.shmo_set_threads(min(64, os.cpu_count() or 1))
+    rc = oracle_c.shmo_compute_distance(n, c_(pre["bbox_min"]), pre["cell"], S, c_(pre["pos"]).reshape(-1), c_(pre["wnormal"]).reshape(-1),
+                                        c_(pre["area"]), pre["lam"], 0, 0, 1e-12, 100000, ref, st)
+    oracle_c.shmo_set_threads(min(8, os.cpu_count() or 1))
+    assert rc == 0 and np.isfinite(ref).all()
+    assert np.abs(phi - ref).max() < 2e-4 * span, (np.abs(phi - ref).max(), span)
 
 
 def test_multiprocess_noconv_still_returns_phi(shm, tmp_path, monkeypatch):
@@ -981,7 +1095,7 @@ def _device_count():
         return 0
 
 
-@pytest.mark.parametrize("mode", ["dual", "dual-slabs", "primal-plain", "primal-dct", "fast"])
+@pytest.mark.parametrize("mode", ["dual", "dual-slabs", "primal-plain", "primal-dct", "fast", "primal-plain+overlap", "primal-dct+overlap"])
 def test_multiprocess_ranks_real_rccl(shm, tmp_path, mode):
     """Two ranks on two GPUs through the REAL librccl (no test double): the grouped send/recv of the halo planes and of the gather of
     D^T Y, the all-to-alls of the distributed DCT, the all-reduces and the slab-chained fast integration.  Skipped on boxes with one GPU
@@ -997,6 +1111,9 @@ def test_multiprocess_ranks_real_rccl(shm, tmp_path, mode):
     case = "bunny_small_fast_n32" if mode == "fast" else "bunny_small_n32"
     env = dict(os.environ, SHM_WORKER_DEVICE_PER_RANK="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("SHM_RCCL_LIB", None)
+    if mode.endswith("+overlap"):   # the opt-in halo / compute overlap (second stream): 2-plane z chunks so that a 16-plane slab has interior chunks
+        env.update(SHM_FUSED_ZC="2", SHM_HALO_OVERLAP="1")
+        mode = mode[:-len("+overlap")]
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multiproc_worker.py"), str(r), str(world), "file", case, mode, str(tmp_path)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
