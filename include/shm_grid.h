@@ -54,7 +54,12 @@ typedef struct {
     int32_t world;       /* number of processes = GPUs; z-slabs are split rank-major */
     int32_t verbose;     /* mirrors SignedHeatGridSolver::VERBOSE (signed_heat_grid_solver.h:22) */
     const void* rccl_unique_id; /* 128-byte ncclUniqueId from shm_comm_unique_id() of rank 0; NULL iff world==1 */
+    int32_t slab_plan;   /* SHM_SLAB_PLAN_EQUAL (0): n / slabs planes each (shm_plan_slab).  SHM_SLAB_PLAN_STEP1: planes weighted by the Step-1 work the
+                          * culling / precision tiers leave in them (shm_step1_plane_weights + shm_plan_slab_weighted; every rank derives the same plan from
+                          * the sources).  The weighted plan serves the default multi-rank solve (Steps 1-2 on slabs, D^T Y gathered, whole-grid dual solve)
+                          * and the plain stencil CG; the slab-distributed transforms (DUAL_SLABS, PRIMAL + DCT) need equal slabs and are refused with it. */
 } shm_config;
+enum { SHM_SLAB_PLAN_EQUAL = 0, SHM_SLAB_PLAN_STEP1 = 1 };
 
 /* Source geometry, already reduced to what the hot loops read
  * (signed_heat_grid_solver.cpp:53-57 mesh / :162-166 points). */
@@ -201,6 +206,12 @@ shm_status shm_grid_get_isosurface(shm_solver* s, double* vertices /* [3*nv] */,
 shm_status shm_comm_unique_id(void* out128);
 /* z-plane range [k0,k1) owned by slab `slab` of `nslabs` for a grid of n planes (pure host logic). */
 void shm_plan_slab(int32_t n, int32_t nslabs, int32_t slab, int32_t* k0, int32_t* k1);
+/* Relative Step-1 cost of every z-plane (weights[n], pure host logic): the kernels' culling / tier rules evaluated per source on a 12 x 12 sample of
+ * node blocks per block layer.  fp64: near pairs 1, packed-fp32 pairs 0.43, dropped 0; fp32: kept pairs 1, skipped 0. */
+shm_status shm_step1_plane_weights(const shm_sources* src, const shm_grid* grid, int32_t precision, double* weights);
+/* The source-aware variant of shm_plan_slab: contiguous ranges of about equal weight, boundaries at multiples of `granule` planes (4 for the fp64
+ * Step 1, 8 for fp32: the kernels' node blocks), at least one granule per slab. */
+void shm_plan_slab_weighted(int32_t n, int32_t nslabs, int32_t slab, const double* weights, int32_t granule, int32_t* k0, int32_t* k1);
 
 #ifdef __cplusplus
 }

@@ -11,4 +11,4 @@ Layout:
   host_abi.py   ctypes binding of the C++ host layer's flat wrapper
 """
 from .grid_abi import (GridSolver, ShmError, ShmStats, lib_path, load_library, SHM_F32, SHM_F64,  # noqa: F401
-                       plan_slab, comm_unique_id)
+                       plan_slab, comm_unique_id, step1_plane_weights, plan_slab_weighted)

@@ -177,6 +177,140 @@ struct Row {
     double t[3];   // that the explicit Schur complement (shm_schur.hip.h) is assembled from
 };
 
+
+// ---- Step-1 work per z-plane, estimated on the host with the kernels' own culling / tier rules (per source, on a sample of node blocks) ----------------
+// Equal-plane z-slabs are not equal work for Step 1 once sources are culled (fp32 configs: the end slabs keep more per block) or tiered (fp64: blocks near
+// the object evaluate more pairs in fp64).  weights[k] is proportional to the cost of plane k; shm_plan_slab_weighted() cuts the planes by it.
+//   fp64 (tiered kernel): block = 8 x 8 x 4 nodes, classified per source; near pairs cost 1, far (packed fp32) pairs 0.43 (measured ratio of the two tiers,
+//   DESIGN.md section 4), dropped 0
+//   fp32 (conv_normalize_kernel<float>): block = 8 x 8 x 16 nodes (its culled unit), classified per CLUSTER of 32 Morton-sorted sources with the cluster's
+//   bounding sphere and largest weight, like the kernel: kept clusters cost 32 pairs per node, skipped ones 0.  (A per-source rule predicts a 20 % imbalance
+//   of equal slabs on rocker 512^3 where 3 % is measured: the spheres' radii, not the sources' distances, decide what that kernel skips.)
+static void step1_plane_weights_host(int64_t S, const double* pos, const double* wn, double lambda, int n, const double* bbox_min, double cell, int precision,
+                                     double tier_log, double* weights) {
+    const bool f64 = precision == SHM_F64;
+    const int bz = f64 ? 4 : 16;
+    const double half_z = 0.5 * (bz - 1);
+    const double rt = std::sqrt(3.5 * 3.5 * 2 + half_z * half_z) * cell * 1.000001;
+    const double skip_base = std::log(64.0 * (double)S / (f64 ? 1e-11 : 6.0e-8));
+    const double far_cost = 0.43;
+    std::vector<double> wmag((size_t)S);
+    for (int64_t s = 0; s < S; s++) wmag[(size_t)s] = std::sqrt(wn[3 * s] * wn[3 * s] + wn[3 * s + 1] * wn[3 * s + 1] + wn[3 * s + 2] * wn[3 * s + 2]);
+    // fp32: the kernel's clusters (Morton order of the sources, 32 per cluster, bounding sphere about the mean, largest weight)
+    constexpr int kCl = 32;
+    std::vector<double> ccen, crad, clnw;
+    if (!f64) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (int64_t s = 0; s < S; s++)
+            for (int a = 0; a < 3; a++) {
+                lo[a] = std::min(lo[a], pos[3 * s + a]);
+                hi[a] = std::max(hi[a], pos[3 * s + a]);
+            }
+        const double ext = std::max({hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2], 1e-300});
+        auto spread = [](uint64_t v) {
+            v &= 0x1fffff;
+            v = (v | v << 32) & 0x1f00000000ffffULL;
+            v = (v | v << 16) & 0x1f0000ff0000ffULL;
+            v = (v | v << 8) & 0x100f00f00f00f00fULL;
+            v = (v | v << 4) & 0x10c30c30c30c30c3ULL;
+            v = (v | v << 2) & 0x1249249249249249ULL;
+            return v;
+        };
+        std::vector<std::pair<uint64_t, int64_t>> order((size_t)S);
+        for (int64_t s = 0; s < S; s++) {
+            uint64_t code = 0;
+            for (int a = 0; a < 3; a++) code |= spread((uint64_t)std::min(1048575.0, std::max(0.0, (pos[3 * s + a] - lo[a]) / ext * 1048575.0))) << a;
+            order[(size_t)s] = {code, s};
+        }
+        std::sort(order.begin(), order.end());
+        const int64_t ncl = (S + kCl - 1) / kCl;
+        ccen.assign((size_t)ncl * 3, 0.);
+        crad.assign((size_t)ncl, 0.);
+        clnw.assign((size_t)ncl, -1e300);
+        for (int64_t c = 0; c < ncl; c++) {
+            const int64_t a0 = c * kCl, a1 = std::min<int64_t>(S, a0 + kCl);
+            for (int64_t t = a0; t < a1; t++)
+                for (int a = 0; a < 3; a++) ccen[(size_t)c * 3 + a] += pos[3 * order[(size_t)t].second + a] / (double)(a1 - a0);
+            for (int64_t t = a0; t < a1; t++) {
+                const int64_t sidx = order[(size_t)t].second;
+                double d2 = 0.;
+                for (int a = 0; a < 3; a++) d2 += (pos[3 * sidx + a] - ccen[(size_t)c * 3 + a]) * (pos[3 * sidx + a] - ccen[(size_t)c * 3 + a]);
+                crad[(size_t)c] = std::max(crad[(size_t)c], std::sqrt(d2));
+                if (wmag[(size_t)sidx] > 0.) clnw[(size_t)c] = std::max(clnw[(size_t)c], std::log(wmag[(size_t)sidx]));
+            }
+        }
+    }
+    const int tiles = (n + 7) / 8, layers = (n + bz - 1) / bz;
+    const int K = std::min(tiles, 12);   // sampled blocks per axis and layer
+    std::vector<double> dist((size_t)S);
+    for (int L = 0; L < layers; L++) {
+        double acc = 0.;
+        const double cz = (L * bz + half_z) * cell + bbox_min[2];
+        for (int a = 0; a < K; a++)
+            for (int b = 0; b < K; b++) {
+                const int tx = (int)(((2 * a + 1) * (long long)tiles) / (2 * K)), ty = (int)(((2 * b + 1) * (long long)tiles) / (2 * K));
+                const double cx = (tx * 8 + 3.5) * cell + bbox_min[0], cy = (ty * 8 + 3.5) * cell + bbox_min[1];
+                double dmin = 1e300, wnear = 0.;
+                for (int64_t s = 0; s < S; s++) {
+                    const double dx = cx - pos[3 * s], dy = cy - pos[3 * s + 1], dz = cz - pos[3 * s + 2];
+                    const double d = std::sqrt(dx * dx + dy * dy + dz * dz);
+                    dist[(size_t)s] = d;
+                    if (wmag[(size_t)s] > 0. && (d < dmin || (d == dmin && wmag[(size_t)s] > wnear))) {
+                        dmin = d;
+                        wnear = wmag[(size_t)s];
+                    }
+                }
+                if (!(wnear > 0.)) continue;
+                const double r_hi = dmin + rt, ln_near = std::log(wnear);
+                double cost = 0.;
+                if (f64) {
+                    for (int64_t s = 0; s < S; s++) {
+                        if (!(wmag[(size_t)s] > 0.)) continue;
+                        const double lhs = lambda * (dist[(size_t)s] - rt - r_hi), rel = std::log(wmag[(size_t)s]) - ln_near;
+                        if (lhs > skip_base + rel) continue;
+                        cost += lhs > tier_log + rel ? far_cost : 1.0;
+                    }
+                } else {
+                    for (size_t c = 0; c < crad.size(); c++) {
+                        const double dx = cx - ccen[3 * c], dy = cy - ccen[3 * c + 1], dz = cz - ccen[3 * c + 2];
+                        const double gap = std::sqrt(dx * dx + dy * dy + dz * dz) - rt - crad[c] - r_hi;
+                        if (!(gap * lambda > skip_base + clnw[c] - ln_near)) cost += kCl;
+                    }
+                }
+                acc += cost;
+            }
+        const double per_plane = acc / ((double)K * K * (double)S) + 1e-3;   // + a floor: the per-block source scan and the stores cost something everywhere
+        for (int k = L * bz; k < std::min(n, (L + 1) * bz); k++) weights[k] = per_plane;
+    }
+}
+
+// Contiguous split of n planes into nslabs ranges whose boundaries are multiples of `granule` planes and whose weights are as equal as those boundaries allow
+// (each boundary goes to the multiple of the granule nearest to its share of the cumulative weight; every slab keeps at least one granule).
+static void plan_slabs_weighted(int n, int nslabs, const double* w, int granule, std::vector<int32_t>& bounds) {
+    bounds.assign((size_t)nslabs + 1, 0);
+    bounds[(size_t)nslabs] = n;
+    if (granule < 1) granule = 1;
+    if ((long long)granule * nslabs > n) granule = std::max(1, n / nslabs);
+    std::vector<double> cum((size_t)n + 1, 0.);
+    for (int k = 0; k < n; k++) cum[(size_t)k + 1] = cum[(size_t)k] + (w && w[k] > 0. ? w[k] : 0.);
+    if (!(cum[(size_t)n] > 0.))
+        for (int k = 0; k <= n; k++) cum[(size_t)k] = k;
+    for (int i = 1; i < nslabs; i++) {
+        const double target = cum[(size_t)n] * i / nslabs;
+        const int lo = bounds[(size_t)i - 1] + granule, hi = n - (nslabs - i) * granule;   // leave a granule for every slab on either side
+        int best = lo;
+        double best_err = 1e300;
+        for (int k = ((lo + granule - 1) / granule) * granule; k <= hi; k += granule) {
+            const double e = std::fabs(cum[(size_t)k] - target);
+            if (e < best_err) {
+                best_err = e;
+                best = k;
+            }
+        }
+        bounds[(size_t)i] = std::min(std::max(best, lo), std::max(lo, hi));
+    }
+}
+
 struct SolverBase {
     virtual ~SolverBase() = default;
     virtual void set_problem(const shm_sources&, const shm_grid&) = 0;
@@ -251,6 +385,12 @@ struct Solver final : SolverBase {
     DevArray<double> d_exptab;  // 2^(j/2048), j < 2048 (Step 1 fp64 exponential)
     std::vector<Slab<T>> slabs;
     int total_slabs = 1, first_slab = 0;
+    std::vector<int32_t> slab_bounds;   // [total_slabs + 1] plane boundaries of all slabs (every rank holds the whole plan)
+    bool slabs_equal = true;            // the plan is the equal-plane one (what the slab-distributed transforms need)
+    void slab_range(int slab, int32_t* k0, int32_t* k1) const {
+        *k0 = slab_bounds[(size_t)slab];
+        *k1 = slab_bounds[(size_t)slab + 1];
+    }
     bool have_problem = false, have_conv = false, have_div = false, have_phi = false, have_constraints = false;
     // constraints (replicated)
     std::vector<Row> rows;
@@ -531,6 +671,30 @@ struct Solver final : SolverBase {
             HIPCHK(hipStreamSynchronize(stream));
         }
 
+        // z-slab plan (every rank computes the whole of it from the same inputs): equal planes, or -- shm_config.slab_plan = SHM_SLAB_PLAN_STEP1 -- planes
+        // weighted by the Step-1 work the kernels' culling / tier rules leave in them (Step 1 is 80-97 % of a solve and does not shard evenly otherwise)
+        {
+            const bool weighted = cfg.slab_plan == SHM_SLAB_PLAN_STEP1 && total_slabs > 1 && !solve_only;
+            slab_bounds.assign((size_t)total_slabs + 1, 0);
+            if (weighted) {
+                std::vector<double> w((size_t)n);
+                step1_plane_weights_host(S, h_pos.data(), h_wn.data(), lambda, n, bbox_min, cell, sizeof(T) == 8 ? SHM_F64 : SHM_F32, conv_tier_log, w.data());
+                plan_slabs_weighted(n, total_slabs, w.data(), sizeof(T) == 8 ? 4 : 8, slab_bounds);
+            } else {
+                for (int sidx = 0; sidx < total_slabs; sidx++) {
+                    int32_t k0, k1;
+                    shm_plan_slab(n, total_slabs, sidx, &k0, &k1);
+                    slab_bounds[(size_t)sidx] = k0;
+                    slab_bounds[(size_t)sidx + 1] = k1;
+                }
+            }
+            slabs_equal = true;
+            for (int sidx = 0; sidx < total_slabs; sidx++) {
+                int32_t k0, k1;
+                shm_plan_slab(n, total_slabs, sidx, &k0, &k1);
+                slabs_equal = slabs_equal && slab_bounds[(size_t)sidx] == k0 && slab_bounds[(size_t)sidx + 1] == k1;
+            }
+        }
         vec = (n % vec_width<T>() == 0) ? vec_width<T>() : 1;
         // keep the device arrays across calls with the same grid size (the reference's `rebuild=false` reuse, :8): a repeated
         // computeDistance() then costs no hipMalloc/hipFree
@@ -542,7 +706,7 @@ struct Solver final : SolverBase {
         for (int ls = 0; ls < cfg.local_slabs; ls++) {
             Slab<T>& sl = slabs[ls];
             int32_t k0, k1;
-            shm_plan_slab(n, total_slabs, first_slab + ls, &k0, &k1);
+            slab_range(first_slab + ls, &k0, &k1);
             sl.k0 = k0;
             sl.k1 = k1;
             sl.nzl = k1 - k0;
@@ -593,7 +757,14 @@ struct Solver final : SolverBase {
     // ------------------------------------------------------------------------------------------
     // Steps 1+2
     void launch_conv() {
+        const bool slab_log = getenv("SHM_CONV_SLAB_LOG") != nullptr;
+        Event slab_ev[2];
+        unsigned long long slab_pairs_seen[2] = {0, 0};
         for (Slab<T>& sl : slabs) {
+            if (slab_log) {
+                HIPCHK(hipStreamSynchronize(stream));
+                slab_ev[0].record(stream);
+            }
             ConvParams P;
             P.n = n;
             P.kk_begin = 1;  // owned planes only: the ghost planes of Y are exchanged (exchange_Y_halos), not recomputed -- a ghost plane
@@ -663,45 +834,77 @@ struct Solver final : SolverBase {
             if (!d_unit_counters.p) d_unit_counters.alloc(8 * kMaxConvLaunches);
             if (&sl == &slabs[0]) {
                 HIPCHK(hipMemsetAsync(d_pair_counters.p, 0, 2 * sizeof(unsigned long long), stream));
-                if (conv_tiered) HIPCHK(hipMemsetAsync(d_unit_counters.p, 0, 8 * kMaxConvLaunches * sizeof(unsigned), stream));
+                HIPCHK(hipMemsetAsync(d_unit_counters.p, 0, 8 * kMaxConvLaunches * sizeof(unsigned), stream));
                 conv_launch_index = 0;
                 conv_launches_last = 0;
             }
             unsigned long long* const cnt = d_pair_counters.p;
-            for (int b0 = 0; b0 < planes; b0 += chunk_planes) {
+            // one launch over the local planes [1 + b0, 1 + b1) with the kernel shape `sel` (nodes per lane: 8 / 4 / 2; the tiered kernel ignores it)
+            auto launch_range = [&](int b0, int b1, int sel) {
+                if (b1 <= b0) return;
                 conv_launches_last++;
+                const int tz_sel = 4 * sel;
                 ConvParams Pc = P;
                 Pc.kk_begin = 1 + b0;
-                Pc.kk_end = std::min(sl.nzl + 1, 1 + b0 + chunk_planes);
-                Pc.n_tiles = P.tiles_x * P.tiles_y * ((Pc.kk_end - Pc.kk_begin + tile_z - 1) / tile_z);
+                Pc.kk_end = std::min(sl.nzl + 1, 1 + b1);
+                Pc.n_tiles = P.tiles_x * P.tiles_y * ((Pc.kk_end - Pc.kk_begin + tz_sel - 1) / tz_sel);
                 const dim3 g((unsigned)std::min<long long>(Pc.n_tiles, grid));
-                bool launched = false;
-                if constexpr (sizeof(T) == 4) {
-                    if (npt8) {
-                        hipLaunchKernelGGL((conv_normalize_kernel<float, 8>), g, dim3(kBlock), 0, stream, Pc, d_src.p, d_src32.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p,
-                                           sl.Y2.p, cnt);
-                        launched = true;
+                if constexpr (sizeof(T) == 8) {
+                    if (conv_tiered) {
+                        // the unit of work is a wave's sub-tile (8 x 8 x NPT nodes), pulled from a per-launch queue head by the waves of a grid no larger than what is resident
+                        if (conv_launch_index >= kMaxConvLaunches) throw Error(SHM_ERR_INVALID, "too many Step-1 launches");
+                        unsigned* const head = d_unit_counters.p + 8 * conv_launch_index++;   // eight queue heads (one per XCD) per launch
+                        const int npt = npt4 ? 4 : 2;
+                        Pc.tiles_x = (n + kTierTX - 1) / kTierTX;
+                        Pc.tiles_y = (n + kTierTY - 1) / kTierTY;
+                        Pc.n_tiles = Pc.tiles_x * Pc.tiles_y * ((Pc.kk_end - Pc.kk_begin + npt - 1) / npt);
+                        const dim3 gt((unsigned)std::min<long long>((Pc.n_tiles + 3) / 4, grid));
+                        if (npt4)
+                            hipLaunchKernelGGL((conv_tiered_kernel<4>), gt, dim3(kBlock), 0, stream, Pc, d_src.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p, sl.Y2.p, cnt, head);
+                        else
+                            hipLaunchKernelGGL((conv_tiered_kernel<2>), gt, dim3(kBlock), 0, stream, Pc, d_src.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p, sl.Y2.p, cnt, head);
+                        return;
                     }
-                } else if (conv_tiered) {
-                    // the unit of work is a wave's sub-tile (8 x 8 x NPT nodes), pulled from a per-launch queue head by the waves of a grid no larger than what is resident
-                    if (conv_launch_index >= kMaxConvLaunches) throw Error(SHM_ERR_INVALID, "too many Step-1 launches");
-                    unsigned* const head = d_unit_counters.p + 8 * conv_launch_index++;   // eight queue heads (one per XCD) per launch
-                    const int npt = npt4 ? 4 : 2;
-                    Pc.tiles_x = (n + kTierTX - 1) / kTierTX;
-                    Pc.tiles_y = (n + kTierTY - 1) / kTierTY;
-                    Pc.n_tiles = Pc.tiles_x * Pc.tiles_y * ((Pc.kk_end - Pc.kk_begin + npt - 1) / npt);
-                    const dim3 gt((unsigned)std::min<long long>((Pc.n_tiles + 3) / 4, grid));
-                    if (npt4)
-                        hipLaunchKernelGGL((conv_tiered_kernel<4>), gt, dim3(kBlock), 0, stream, Pc, d_src.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p, sl.Y2.p, cnt, head);
-                    else
-                        hipLaunchKernelGGL((conv_tiered_kernel<2>), gt, dim3(kBlock), 0, stream, Pc, d_src.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p, sl.Y2.p, cnt, head);
-                    launched = true;
                 }
-                if (launched) {
-                } else if (npt4)
-                    hipLaunchKernelGGL((conv_normalize_kernel<T, 4>), g, dim3(kBlock), 0, stream, Pc, d_src.p, d_src32.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p, sl.Y2.p, cnt);
+                // the tiles of a launch are handed out by a queue head (culled workloads: their costs differ severalfold); SHM_CONV_STATIC: static stride (A/B knob)
+                static const bool static_tiles = getenv("SHM_CONV_STATIC") != nullptr;
+                unsigned* head = nullptr;
+                if (!static_tiles && conv_launch_index < kMaxConvLaunches) head = d_unit_counters.p + 8 * conv_launch_index++;
+                if constexpr (sizeof(T) == 4) {
+                    if (sel == 8) {
+                        hipLaunchKernelGGL((conv_normalize_kernel<float, 8>), g, dim3(kBlock), 0, stream, Pc, d_src.p, d_src32.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p,
+                                           sl.Y2.p, cnt, head);
+                        return;
+                    }
+                }
+                if (sel >= 4)
+                    hipLaunchKernelGGL((conv_normalize_kernel<T, 4>), g, dim3(kBlock), 0, stream, Pc, d_src.p, d_src32.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p, sl.Y2.p, cnt, head);
                 else
-                    hipLaunchKernelGGL((conv_normalize_kernel<T, 2>), g, dim3(kBlock), 0, stream, Pc, d_src.p, d_src32.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p, sl.Y2.p, cnt);
+                    hipLaunchKernelGGL((conv_normalize_kernel<T, 2>), g, dim3(kBlock), 0, stream, Pc, d_src.p, d_src32.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p, sl.Y2.p, cnt, head);
+            };
+            const int sel0 = npt8 ? 8 : npt4 ? 4 : 2;
+            if (sizeof(T) == 4 && nchunks == 1 && sel0 > 2 && planes % tile_z != 0) {
+                // planes that do not fill the last layer of 32- (16-) plane tiles (a weighted slab plan cuts at multiples of 8 planes): that layer would run with most
+                // of its lanes dead, so the remainder goes to the kernel shapes with fewer nodes per lane (same arithmetic; the 8-plane shape culls in smaller units)
+                int b = (planes / tile_z) * tile_z;
+                launch_range(0, b, sel0);
+                for (int sel = sel0 / 2; sel >= 2; sel /= 2) {
+                    const int tz_sel = 4 * sel, take = sel > 2 ? ((planes - b) / tz_sel) * tz_sel : planes - b;
+                    launch_range(b, b + take, sel);
+                    b += take;
+                }
+            } else {
+                for (int b0 = 0; b0 < planes; b0 += chunk_planes) launch_range(b0, std::min(planes, b0 + chunk_planes), sel0);
+            }
+            if (slab_log) {   // measurement knob (tools/slab_plan_check.py): this slab's Step 1 alone -- time and evaluated pairs -- to stderr
+                slab_ev[1].record(stream);
+                HIPCHK(hipStreamSynchronize(stream));
+                unsigned long long h[2] = {0, 0};
+                HIPCHK(hipMemcpy(h, d_pair_counters.p, sizeof h, hipMemcpyDeviceToHost));
+                fprintf(stderr, "[shm] step1 slab planes [%d,%d) ms %.3f pairs_fp64 %.6e pairs_fp32 %.6e\n", sl.k0, sl.k1, elapsed(slab_ev[0], slab_ev[1]),
+                        (double)(h[0] - slab_pairs_seen[0]), (double)(h[1] - slab_pairs_seen[1]));
+                slab_pairs_seen[0] = h[0];
+                slab_pairs_seen[1] = h[1];
             }
         }
         HIPCHK(hipGetLastError());
@@ -1420,7 +1623,7 @@ struct Solver final : SolverBase {
             hipLaunchKernelGGL(green_symbol_kernel, dim3(grid_for((size_t)n * n * n, 4096)), dim3(kBlock), 0, st, n, gs_lam.p, W0.p);
             // beside the tiered fp64 Step 1 (two 176-register waves per SIMD) only the narrow shape fits on a SIMD; otherwise the 128 x 128 tiles
             static const bool gemm_wide_env = getenv("SHM_GREEN_WIDE") != nullptr;   // A/B knob
-            const bool narrow = conv_tiered && !gemm_wide_env;
+            const bool narrow = (conv_tiered || getenv("SHM_GREEN_NARROW") != nullptr) && !gemm_wide_env;
             auto tiles = [](size_t v) { return (unsigned)((v + kGemmT - 1) / kGemmT); };
             auto gemm = [&](unsigned batches, int M, int N, int K, const double* A, int lda, long long sA, const double* B, int ldb, long long sB, double* C, int ldc, long long sC) {
                 if (narrow)
@@ -1676,7 +1879,7 @@ struct Solver final : SolverBase {
     bool precond_available() const {
         if (n < 16 || n > 1024 || (n & (n - 1)) != 0) return false;
         if (total_slabs == 1) return true;
-        return (total_slabs & (total_slabs - 1)) == 0 && n % total_slabs == 0;
+        return slabs_equal && (total_slabs & (total_slabs - 1)) == 0 && n % total_slabs == 0;
     }
     void setup_precond() {
         if (precond_ready) return;
@@ -2254,7 +2457,7 @@ struct Solver final : SolverBase {
                 for (Slab<T>& sl : slabs) R.chk(R.Send(sl.r.p + plane, sl.nown, dt, peer, comm, stream), "ncclSend(gather b)");
                 for (int b = 0; b < cfg.local_slabs; b++) {  // the peer sends its slabs in this order
                     int32_t k0, k1;
-                    shm_plan_slab(n, total_slabs, peer * cfg.local_slabs + b, &k0, &k1);
+                    slab_range(peer * cfg.local_slabs + b, &k0, &k1);
                     R.chk(R.Recv(fs.r.p + (size_t)(k0 + 1) * plane, (size_t)(k1 - k0) * plane, dt, peer, comm, stream), "ncclRecv(gather b)");
                 }
             }
@@ -2883,6 +3086,22 @@ void shm_plan_slab(int32_t n, int32_t nslabs, int32_t slab, int32_t* k0, int32_t
     const int32_t b = slab * q + (slab < r ? slab : r);
     if (k0) *k0 = b;
     if (k1) *k1 = b + q + (slab < r ? 1 : 0);
+}
+
+shm_status shm_step1_plane_weights(const shm_sources* src, const shm_grid* grid, int32_t precision, double* weights) {
+    if (!src || !grid || !weights || src->S <= 0 || !src->pos || !src->wnormal || grid->n < 1 || !(grid->cell > 0.) || !(src->lambda > 0.) ||
+        (precision != SHM_F64 && precision != SHM_F32))
+        return SHM_ERR_INVALID;
+    const char* tl = getenv("SHM_CONV_TIER_LOG");
+    shm::step1_plane_weights_host(src->S, src->pos, src->wnormal, src->lambda, grid->n, grid->bbox_min, grid->cell, precision, tl ? atof(tl) : 8.0, weights);
+    return SHM_OK;
+}
+
+void shm_plan_slab_weighted(int32_t n, int32_t nslabs, int32_t slab, const double* weights, int32_t granule, int32_t* k0, int32_t* k1) {
+    std::vector<int32_t> b;
+    shm::plan_slabs_weighted(n, nslabs, weights, granule, b);
+    if (k0) *k0 = b[(size_t)slab];
+    if (k1) *k1 = b[(size_t)slab + 1];
 }
 
 shm_status shm_grid_create(const shm_config* cfg, shm_solver** out) {

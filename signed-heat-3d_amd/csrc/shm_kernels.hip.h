@@ -167,13 +167,20 @@ constexpr int kConvClusterRec = 5;  // floats per cluster record: bounding spher
 //     distance that exceeds the nearest one by at most the tile diameter, so exp(-lambda (r - d0)) of the nearest source never
 //     underflows (SURVEY trap #4); the common factor exp(lambda d0) cancels in X/|X|.  Coarse grids (lambda * tile
 //     diameter > 30) take one extra sweep for exact per-node offsets.
-template <int NPT> struct ConvSrcUnroll { static constexpr int value = NPT == 8 ? 4 : 2; };   // sources in flight per lane in the packed fp32 loop
+// Two sources in flight per lane, also at 8 nodes per lane: 162 registers = three waves per SIMD.  (Round 2 ran four in flight -- 228 registers, two waves --
+// which was 4 % faster while the tiles were strided statically; with the tile queue the third wave is worth more than the deeper unroll: rocker 512^3
+// 383.5 against 386.6 ms, SprayBottle 1024^3 4163 against 4238 ms; three in flight, 175 registers: 419 / -- .)
+#ifndef SHM_CONV32_UNROLL
+#define SHM_CONV32_UNROLL 2
+#endif
+template <int NPT> struct ConvSrcUnroll { static constexpr int value = NPT == 8 ? SHM_CONV32_UNROLL : 2; };   // sources in flight per lane in the packed fp32 loop
 template <typename T, int NPT>
 __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, const T* __restrict__ src /* [S][6]: pos xyz, wn xyz */,
                                                                 const float* __restrict__ src32, const float* __restrict__ clusters,
                                                                 const double* __restrict__ exp_tab_g /* [2048]: 2^(j/2048) */,
                                                                 T* __restrict__ Y0, T* __restrict__ Y1, T* __restrict__ Y2,
-                                                                unsigned long long* __restrict__ counters /* [0] fp64, [1] fp32 (node, source) pairs evaluated; may be null */) {
+                                                                unsigned long long* __restrict__ counters /* [0] fp64, [1] fp32 (node, source) pairs evaluated; may be null */,
+                                                                unsigned* __restrict__ next_tile /* work-queue head, zeroed before the launch; null: tiles strided statically */) {
     // tile = 8 x 8 x (4 NPT) nodes; a lane owns the z-column (i, j, k0 + w + 4 e), e < NPT (w = its wave): the NPT nodes share
     // dx^2 + dy^2 of every source
     constexpr int kTileZ = (kBlock / 64) * NPT;
@@ -200,7 +207,17 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
     const int n = P.n;
     const size_t plane = (size_t)n * n;
     unsigned cnt_half64 = 0, cnt_half32 = 0;   // (cluster, half tile) pairs evaluated in fp64 / fp32 by this workgroup (uniform: scalar registers)
-    for (int bt = blockIdx.x; bt < P.n_tiles; bt += gridDim.x) {
+    // Tiles are handed out by a queue head (one atomic per tile): with culling their costs differ severalfold, and on a thin z-slab (a multi-GPU rank)
+    // a static stride leaves the workgroups 10-20 % apart at the end of the launch.
+    __shared__ int queue_bt;
+    auto next_bt = [&](int cur) {
+        if (!next_tile) return cur + (int)gridDim.x;
+        __syncthreads();   // (also: everybody has read the previous value)
+        if (threadIdx.x == 0) queue_bt = (int)atomicAdd(next_tile, 1u);
+        __syncthreads();
+        return queue_bt;
+    };
+    for (int bt = next_tile ? next_bt(0) : (int)blockIdx.x; bt < P.n_tiles; bt = next_bt(bt)) {
     __syncthreads();  // LDS reuse between consecutive tiles of this workgroup
     const int tz = bt / (P.tiles_x * P.tiles_y), trem = bt - tz * (P.tiles_x * P.tiles_y);
     const int ty = trem / P.tiles_x, tx = trem - ty * P.tiles_x;
@@ -391,7 +408,7 @@ __global__ __launch_bounds__(kBlock) void conv_normalize_kernel(ConvParams P, co
                 static_assert(NPT % 2 == 0, "packed fp32 path handles the lane's nodes in pairs");
                 auto sweep = [&](auto e_begin, auto e_end) {   // nodes [e_begin, e_end) of every lane against cluster c
                     constexpr int E0 = decltype(e_begin)::value, E1 = decltype(e_end)::value;
-#pragma unroll ConvSrcUnroll<NPT>::value   // four sources in flight at 8 nodes per lane: 228 registers, two waves per SIMD, rocker 512^3 474 -> 455 ms (8: 480, 6: 460)
+#pragma unroll ConvSrcUnroll<NPT>::value   // sources in flight per lane (see ConvSrcUnroll)
                     for (int s = c * kConvCluster; s < (c + 1) * kConvCluster; s++) {
                         const float sz = tile[6 * s + 2];
                         const float wx = tile[6 * s + 3], wy = tile[6 * s + 4], wz = tile[6 * s + 5];

@@ -20,7 +20,7 @@ STATUS_NAMES = {0: "SHM_OK", 1: "SHM_ERR_INVALID", 2: "SHM_ERR_HIP", 3: "SHM_ERR
 ABI_SYMBOLS = ["shm_grid_create", "shm_grid_destroy", "shm_grid_last_error", "shm_grid_abi_version", "shm_grid_set_problem",
                "shm_grid_solve", "shm_grid_get_phi", "shm_grid_compute_distance", "shm_grid_run_conv", "shm_grid_run_divergence",
                "shm_grid_get_field", "shm_grid_apply_laplacian", "shm_grid_get_constraints", "shm_grid_get_schur", "shm_grid_apply_projector", "shm_grid_apply_preconditioner", "shm_grid_isosurface", "shm_grid_get_isosurface",
-               "shm_comm_unique_id", "shm_plan_slab"]
+               "shm_comm_unique_id", "shm_plan_slab", "shm_step1_plane_weights", "shm_plan_slab_weighted"]
 
 
 class ShmError(RuntimeError):
@@ -31,7 +31,7 @@ class ShmError(RuntimeError):
 
 class _Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("precision", C.c_int32), ("local_slabs", C.c_int32), ("rank", C.c_int32),
-                ("world", C.c_int32), ("verbose", C.c_int32), ("rccl_unique_id", C.c_void_p)]
+                ("world", C.c_int32), ("verbose", C.c_int32), ("rccl_unique_id", C.c_void_p), ("slab_plan", C.c_int32)]
 
 
 class _Sources(C.Structure):
@@ -99,6 +99,9 @@ def load_library():
     lib.shm_comm_unique_id.argtypes = [C.c_void_p]
     lib.shm_plan_slab.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.shm_plan_slab.restype = None
+    lib.shm_step1_plane_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.shm_plan_slab_weighted.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.shm_plan_slab_weighted.restype = None
     _LIB = lib
     return lib
 
@@ -107,6 +110,28 @@ def plan_slab(n, nslabs, slab):
     lib = load_library()
     k0, k1 = C.c_int32(), C.c_int32()
     lib.shm_plan_slab(n, nslabs, slab, C.byref(k0), C.byref(k1))
+    return k0.value, k1.value
+
+
+def step1_plane_weights(pos, wnormal, lam, n, bbox_min, cell, precision=SHM_F64):
+    """Relative Step-1 cost of every z-plane (shm_step1_plane_weights: pure host logic, no GPU)."""
+    lib = load_library()
+    pos, wn = _f64(pos).reshape(-1), _f64(wnormal).reshape(-1)
+    area = np.zeros(pos.size // 3)
+    src = _Sources(pos.size // 3, pos.ctypes.data, wn.ctypes.data, area.ctypes.data, float(lam))
+    g = _Grid(int(n), (C.c_double * 3)(*[float(x) for x in bbox_min]), float(cell))
+    w = np.zeros(int(n))
+    rc = lib.shm_step1_plane_weights(C.byref(src), C.byref(g), int(precision), w.ctypes.data)
+    if rc != 0:
+        raise ShmError(rc, "shm_step1_plane_weights: invalid argument")
+    return w
+
+
+def plan_slab_weighted(n, nslabs, slab, weights, granule):
+    lib = load_library()
+    w = _f64(weights)
+    k0, k1 = C.c_int32(), C.c_int32()
+    lib.shm_plan_slab_weighted(int(n), int(nslabs), int(slab), w.ctypes.data, int(granule), C.byref(k0), C.byref(k1))
     return k0.value, k1.value
 
 
@@ -128,12 +153,12 @@ class GridSolver:
 
     FIELD_Y0, FIELD_Y1, FIELD_Y2, FIELD_DIV, FIELD_PHI = 0, 1, 2, 3, 4
 
-    def __init__(self, device=0, precision=SHM_F64, local_slabs=1, rank=0, world=1, verbose=False, rccl_unique_id=None):
+    def __init__(self, device=0, precision=SHM_F64, local_slabs=1, rank=0, world=1, verbose=False, rccl_unique_id=None, slab_plan=0):
         self._lib = load_library()
         self._h = C.c_void_p()
         self._uid = C.create_string_buffer(rccl_unique_id, 128) if rccl_unique_id is not None else None
         cfg = _Config(device, precision, local_slabs, rank, world, int(verbose),
-                      C.cast(self._uid, C.c_void_p) if self._uid is not None else None)
+                      C.cast(self._uid, C.c_void_p) if self._uid is not None else None, int(slab_plan))
         rc = self._lib.shm_grid_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:
             raise ShmError(rc, self._lib.shm_grid_last_error(None).decode())

@@ -4,7 +4,8 @@
 cd $(dirname $0)/../signed-heat-3d_amd/csrc
 mkdir -p ../lib/variants
 build() { name=$1; shift; /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-parameter "$@" -shared shm_grid.hip -o ../lib/variants/libshm_grid_$name.so -ldl 2>&1 | grep -E "error" ; echo built $name; }
-build nont -DSHM_TIER_NT=0 &
-build tx16nont -DSHM_TIER_TX=16 -DSHM_TIER_NT=0 &
+build u4 &
+build u3 -DSHM_CONV32_UNROLL=3 &
+build u2 -DSHM_CONV32_UNROLL=2 &
 wait
 ls -la ../lib/variants

@@ -10,7 +10,7 @@ def main(db, max_rows=400):
     # the Step-1 launches of the last solve: walk back while the gaps between conv launches are short
     first = convs[-1]
     for i in reversed(convs[:-1]):
-        if rows[first][1] - rows[i][2] > 3e6: break   # > 3 ms apart: previous solve
+        if rows[first][1] - rows[i][2] > 1e5: break   # > 0.1 ms apart: previous solve (the chunk launches of one Step 1 follow each other within microseconds)
         first = i
     t0, t1 = rows[first][1], last_end
     print("Step 1 of the last solve: %.3f ms (%d launches)" % ((t1 - t0) * 1e-6, sum(1 for i in convs if i >= first)))
