@@ -165,6 +165,9 @@ shm_status shm_grid_solve(shm_solver* s, const shm_opts* opts, shm_stats* stats)
 /* Copy phi of the z-planes owned by this process to the host: k in [*k_begin,*k_end), x fastest,
  * (k_end-k_begin)*n*n doubles.  With world==1 that is the whole grid (N = n^3 values). */
 shm_status shm_grid_get_phi(shm_solver* s, double* phi_out, int32_t* k_begin, int32_t* k_end);
+/* The z-planes [*k_begin, *k_end) this process owns under the slab plan in force (after shm_grid_set_problem): what sizes the buffers of
+ * shm_grid_get_phi / shm_grid_get_field.  With SHM_SLAB_PLAN_EQUAL it equals shm_plan_slab(n, world * local_slabs, ...); with the weighted plan ask here. */
+shm_status shm_grid_owned_planes(shm_solver* s, int32_t* k_begin, int32_t* k_end);
 /* One-shot convenience = set_problem + solve + get_phi (world==1 only): the call a C++ adapter's
  * computeDistance() makes. */
 shm_status shm_grid_compute_distance(shm_solver* s, const shm_sources* src, const shm_grid* grid,

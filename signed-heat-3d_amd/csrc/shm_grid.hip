@@ -316,6 +316,7 @@ struct SolverBase {
     virtual void set_problem(const shm_sources&, const shm_grid&) = 0;
     virtual void solve(const shm_opts&, shm_stats*) = 0;
     virtual void get_phi(double*, int32_t*, int32_t*) = 0;
+    virtual void owned_planes(int32_t*, int32_t*) = 0;
     virtual void run_conv() = 0;
     virtual void run_divergence(int scrub) = 0;
     virtual void get_field(shm_field, double*) = 0;
@@ -2889,6 +2890,11 @@ struct Solver final : SolverBase {
         HIPCHK(hipStreamSynchronize(stream));
     }
 
+    void owned_planes(int32_t* kb, int32_t* ke) override {
+        need_problem();
+        if (kb) *kb = slabs.front().k0;
+        if (ke) *ke = slabs.back().k1;
+    }
     void get_phi(double* out, int32_t* kb, int32_t* ke) override {
         need_problem();
         if (!have_phi) throw Error(SHM_ERR_STATE, "no phi: shm_grid_solve has not completed");
@@ -3158,6 +3164,10 @@ shm_status shm_grid_get_phi(shm_solver* s, double* phi_out, int32_t* k_begin, in
         if (!phi_out) throw shm::Error(SHM_ERR_INVALID, "null phi_out");
         s->impl->get_phi(phi_out, k_begin, k_end);
     });
+}
+
+shm_status shm_grid_owned_planes(shm_solver* s, int32_t* k_begin, int32_t* k_end) {
+    return guard(s, [&] { s->impl->owned_planes(k_begin, k_end); });
 }
 
 shm_status shm_grid_compute_distance(shm_solver* s, const shm_sources* src, const shm_grid* grid, const shm_opts* opts, double* phi_out,

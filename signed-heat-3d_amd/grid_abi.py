@@ -17,7 +17,7 @@ STATUS_NAMES = {0: "SHM_OK", 1: "SHM_ERR_INVALID", 2: "SHM_ERR_HIP", 3: "SHM_ERR
                 5: "SHM_ERR_NOCONV", 6: "SHM_ERR_RCCL", 7: "SHM_ERR_STATE", 8: "SHM_ERR_SINGULAR"}
 
 # every symbol include/shm_grid.h declares (tests check the library exports all of them)
-ABI_SYMBOLS = ["shm_grid_create", "shm_grid_destroy", "shm_grid_last_error", "shm_grid_abi_version", "shm_grid_set_problem",
+ABI_SYMBOLS = ["shm_grid_owned_planes", "shm_grid_create", "shm_grid_destroy", "shm_grid_last_error", "shm_grid_abi_version", "shm_grid_set_problem",
                "shm_grid_solve", "shm_grid_get_phi", "shm_grid_compute_distance", "shm_grid_run_conv", "shm_grid_run_divergence",
                "shm_grid_get_field", "shm_grid_apply_laplacian", "shm_grid_get_constraints", "shm_grid_get_schur", "shm_grid_apply_projector", "shm_grid_apply_preconditioner", "shm_grid_isosurface", "shm_grid_get_isosurface",
                "shm_comm_unique_id", "shm_plan_slab", "shm_step1_plane_weights", "shm_plan_slab_weighted"]
@@ -96,6 +96,7 @@ def load_library():
     lib.shm_grid_apply_preconditioner.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.shm_grid_isosurface.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.shm_grid_get_isosurface.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.shm_grid_owned_planes.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.shm_comm_unique_id.argtypes = [C.c_void_p]
     lib.shm_plan_slab.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.shm_plan_slab.restype = None
@@ -193,9 +194,10 @@ class GridSolver:
         self.n, self.S = int(n), S
 
     def owned_planes(self):
-        first = self.rank * self.local_slabs
-        total = self.world * self.local_slabs
-        return plan_slab(self.n, total, first)[0], plan_slab(self.n, total, first + self.local_slabs - 1)[1]
+        """z-planes [k0, k1) this handle owns under the slab plan in force (shm_grid_owned_planes: the weighted plan is not the equal-plane one)."""
+        k0, k1 = C.c_int32(), C.c_int32()
+        self._chk(self._lib.shm_grid_owned_planes(self._h, C.byref(k0), C.byref(k1)))
+        return k0.value, k1.value
 
     PRECOND = {"auto": 0, "none": 1, "dct": 2}
 

@@ -42,7 +42,8 @@ def main():
                 time.sleep(0.05)
             uid = open(path, "rb").read()
         uid_hex = uid.hex()
-    s = shm.GridSolver(device=device, precision=precision, rank=rank, world=world, rccl_unique_id=bytes.fromhex(uid_hex))
+    s = shm.GridSolver(device=device, precision=precision, rank=rank, world=world, rccl_unique_id=bytes.fromhex(uid_hex),
+                       slab_plan=int(os.environ.get("SHM_WORKER_SLAB_PLAN", "0")))
     s.set_problem(d["pos"], d["wnormal"], d["area"], float(d["lam"]), int(d["n"]), d["bbox_min"], float(d["cell"]))
     kw = {"primal-plain": dict(solver="primal", precond="none"), "primal-dct": dict(solver="primal", precond="dct"),
           "dual": dict(solver="dual"), "dual-slabs": dict(solver="dual_slabs"), "fast": dict(fast=True)}[mode]

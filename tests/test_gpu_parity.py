@@ -287,6 +287,35 @@ def test_local_slabs_match_single_slab(shm, slabs):
     assert np.abs(phi - d["phi"]).max() < 1e-7
 
 
+@pytest.mark.parametrize("fast", [False, True])
+def test_weighted_slab_plan_matches_single_slab(shm, fast):
+    """Unequal z-slabs (shm_config.slab_plan = SHM_SLAB_PLAN_STEP1: planes weighted by the Step-1 work of the tiered fp64 kernel, cut at multiples of 4 planes)
+    through the slab code path on one GPU: plain stencil CG / the slab-chained fast integration must reproduce the single-slab result, and the
+    slab-distributed transforms, which need equal slabs, must be refused rather than run on the wrong layout."""
+    pre = _preprocess("SprayBottle.pc", 2.0)          # 64^3; most sources are dropped per block and the kept share varies along z
+    n = pre["n"]
+    w = shm.step1_plane_weights(pre["pos"], pre["wnormal"], pre["lam"], n, pre["bbox_min"], pre["cell"], 64)
+    plan = [shm.plan_slab_weighted(n, 3, r, w, 4) for r in range(3)]
+    assert plan != [shm.plan_slab(n, 3, r) for r in range(3)], plan   # (equal planes: 22 + 21 + 21; weighted: multiples of 4)
+    out = {}
+    for slabs in (1, 3):
+        s = shm.GridSolver(local_slabs=slabs, slab_plan=1)
+        s.set_problem(pre["pos"], pre["wnormal"], pre["area"], pre["lam"], n, pre["bbox_min"], pre["cell"])
+        st = s.solve(tol=1e-10, fast=fast, scrub=False, precond="none", solver="primal")
+        phi, (k0, k1) = s.get_phi()
+        assert (k0, k1) == (0, n)
+        out[slabs] = phi
+        if slabs == 3 and not fast:
+            assert st.solver == 1 and st.preconditioner == 1
+            with pytest.raises(shm.ShmError):                      # the slab-distributed transforms need equal slabs
+                s.solve(tol=1e-10, scrub=False, solver="dual_slabs")
+            with pytest.raises(shm.ShmError):
+                s.solve(tol=1e-10, scrub=False, solver="primal", precond="dct")
+        s.close()
+    assert np.isfinite(out[1]).all()
+    assert np.abs(out[3] - out[1]).max() < 1e-8 * max(1.0, np.abs(out[1]).max())
+
+
 @pytest.mark.parametrize("n,slabs", [(48, 1), (33, 1), (33, 3), (70, 1)])
 def test_matches_c_oracle_128(shm, oracle_c, n, slabs):
     """Same inputs through the HIP path (plain stencil CG: sizes that are not powers of two, odd sizes without vector loads,
@@ -1033,18 +1062,25 @@ def test_multiprocess_ranks_on_one_gpu(shm, tmp_path, world, mode, case):
         assert np.abs(phi - ref).max() < 1e-9
 
 
-@pytest.mark.parametrize("mode", ["dual", "primal-dct"])
-def test_multiprocess_ranks_culled_fp32(shm, oracle_c, tmp_path, mode):
+@pytest.mark.parametrize("mode,plan", [("dual", 0), ("primal-dct", 0), ("dual", 1), ("primal-plain", 1)])
+def test_multiprocess_ranks_culled_fp32(shm, oracle_c, tmp_path, mode, plan):
     """A culled fp32 workload through the rank path (configs[4] in small: SprayBottle.pc, 64^3, four ranks): Step 1 skips most source clusters per
     tile and the slabs differ in how many they keep; every rank must still produce its planes of the single-rank answer.  Against the fp64 C oracle
     at fp32 tolerance, and against the same fp32 solver on one rank much tighter."""
     import os
     so = _build_rccl_mock(tmp_path)
-    world, case = 4, "file:SprayBottle.pc:2"
-    phi, metas, covered = _run_ranks(tmp_path, so, world, case, mode, "spray" + mode.replace("-", ""), {"SHM_WORKER_PRECISION": "32"})
+    world, case = (3 if plan else 4), "file:SprayBottle.pc:2"   # (three ranks with the weighted plan: 64 planes in multiples of 8 cannot be three equal slabs)
+    phi, metas, covered = _run_ranks(tmp_path, so, world, case, mode, "spray%d" % plan + mode.replace("-", ""), {"SHM_WORKER_PRECISION": "32", "SHM_WORKER_SLAB_PLAN": str(plan)})
     pre = _preprocess("SprayBottle.pc", 2.0)
     n, S = pre["n"], pre["S"]
     assert n == 64 and covered == n and np.isfinite(phi).all()
+    heights = [k1 - k0 for (k0, k1, _, _) in metas]
+    if plan:   # the source-aware plan (shm_config.slab_plan = SHM_SLAB_PLAN_STEP1): unequal slabs, cut at multiples of 8 planes, the same on every rank
+        assert len(set(heights)) > 1 and all(h % 8 == 0 and h >= 8 for h in heights), heights
+        w = shm.step1_plane_weights(pre["pos"], pre["wnormal"], pre["lam"], n, pre["bbox_min"], pre["cell"], 32)
+        assert [shm.plan_slab_weighted(n, world, r, w, 8) for r in range(world)] == [(k0, k1) for (k0, k1, _, _) in metas]
+    else:
+        assert heights == [16] * 4
     _, st1, phi1 = _gpu_phi(shm, pre, shm.SHM_F32, False, **MODES[mode])
     span = np.abs(phi1).max()
     assert np.abs(phi - phi1).max() < 3e-5 * span, (np.abs(phi - phi1).max(), span)
