@@ -9,9 +9,10 @@
 // wave owns a compact 8 x 8 x NPT block of nodes and each of its 64 lanes tests one source of a 64-source cluster against that block's
 // bounds, a ballot turns the 64 answers into two scalar masks, and the wave then walks the near mask through the fp64 body and the far
 // mask through the packed fp32 body (scalar bit scans: no divergence, no per-cluster bounding sphere in the bound).
-//   far(s)  <=>  lambda (|c_w - b_s| - rt_w - r_hi_w) > G + ln(|w_s| / |w_near|)
-// with c_w / rt_w the sub-tile's centre / circumscribed radius, r_hi_w = dmin(c_w) + rt_w an upper bound of every node's distance to its
-// nearest source and w_near that source's weight: every term of s is then below e^-G of the dominant term of every node of the block.
+//   far(s)  <=>  lambda (dist(b_s, box_w) - r_hi_w) > G + ln(|w_s| / |w_near|)
+// with box_w the block's bounding box, r_hi_w the distance from the block's farthest corner to the source s* nearest to its centre -- an upper
+// bound of every node's distance to its nearest source -- and w_near the weight of s*: every term of s is then below e^-G of the dominant term
+// of every node of the block.
 // The same lane-parallel test with the skip threshold drops sources whose terms vanish against the budget altogether.
 // What the far tier contributes to Y is bounded by eps32 * sum_far |term| / |X|; `tools/tier_budget.py` evaluates that on the host
 // and the GPU tests hold Y to the stated budget against the all-fp64 kernel (SHM_CONV_EXACT=1).
@@ -100,6 +101,9 @@ constexpr int kTierFill = kTierCluster * kTierChunk;
 #ifndef SHM_TIER_NEAR_BFS
 #define SHM_TIER_NEAR_BFS 1
 #endif
+#ifndef SHM_TIER_NEAR_BATCH
+#define SHM_TIER_NEAR_BATCH 2   // pairs whose e^{-lambda r}/r chains are interleaved stage by stage
+#endif
 #ifndef SHM_TIER_WAVES_PER_EU
 #define SHM_TIER_WAVES_PER_EU 2
 #endif
@@ -133,6 +137,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
     constexpr double kHalfZ = 0.5 * (NPT - 1);
     constexpr double kHalfX = 0.5 * (kTierTX - 1), kHalfY = 0.5 * (kTierTY - 1);
     const float rt_w = (float)(sqrt(kHalfX * kHalfX + kHalfY * kHalfY + kHalfZ * kHalfZ) * P.cell) * 1.000001f;
+    const float hx = uniform_f32((float)(kHalfX * P.cell) * 1.000001f), hy = uniform_f32((float)(kHalfY * P.cell) * 1.000001f),
+                hz = uniform_f32((float)(kHalfZ * P.cell) * 1.000001f);   // half extents of a block
     unsigned long long cnt_near = 0, cnt_far = 0;
     // Eight queue heads, one per XCD (workgroup b runs on XCD b % 8): the units -- x fastest, then y, then z -- are cut into eight contiguous ranges, so
     // that the two 64-byte halves of a 128-byte line of Y (x-adjacent blocks) are written through the same L2 and leave it as one line; an XCD
@@ -163,7 +169,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
         double pz[NPT], ax[NPT], ay[NPT], az[NPT];
         float qz[NPT], fx[NPT], fy[NPT], fz[NPT];
         bool live[NPT];
-        size_t vidx[NPT];
         const int li = i0 + (lane % kTierTX), lj = j0 + (lane / kTierTX);
         const int ci = min(li, n - 1), cj = min(lj, n - 1);
         // indicesToNodePosition: (i,j,k)*cellSize + bboxMin, evaluated in double like the reference (:510-514)
@@ -174,7 +179,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
             int kk = kk0 + e;   // the wave's nodes form a compact kTierTX x kTierTY x NPT block
             live[e] = li < n && lj < n && kk < P.kk_end;
             kk = min(kk, P.kk_end - 1);
-            vidx[e] = (size_t)kk * plane + (size_t)cj * n + ci;
             const double z = (P.k0 + kk - 1) * P.cell + P.bbox_min[2];
             pz[e] = z;
             qz[e] = (float)z;
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
         // nearest source of the block's centre (and its weight): one source per lane and step, butterfly minimum
         const float cx = (float)((i0 + kHalfX) * P.cell + P.bbox_min[0]), cy = (float)((j0 + kHalfY) * P.cell + P.bbox_min[1]);
         const float cz = (float)((P.k0 + kk0 - 1 + kHalfZ) * P.cell + P.bbox_min[2]);
-        float dmin = 3.0e38f, wnear = 0.f;
+        float dmin = 3.0e38f, wnear = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;   // nearest source: squared distance, squared weight, offset from the centre
         for (int s = lane; s < P.S; s += kWave) {
             const double* q = src + (size_t)s * 6;
             const float dx = cx - (float)q[0], dy = cy - (float)q[1], dz = cz - (float)q[2];
@@ -193,18 +197,28 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
             if (d2 < dmin || (d2 == dmin && w2 > wnear)) {   // ties (the zero-weight padding repeats a source) go to the larger weight
                 dmin = d2;
                 wnear = w2;
+                nx = dx;
+                ny = dy;
+                nz = dz;
             }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const float od = __shfl_xor(dmin, off, kWave), ow = __shfl_xor(wnear, off, kWave);
+            const float ox = __shfl_xor(nx, off, kWave), oy = __shfl_xor(ny, off, kWave), oz = __shfl_xor(nz, off, kWave);
             if (od < dmin || (od == dmin && ow > wnear)) {
                 dmin = od;
                 wnear = ow;
+                nx = ox;
+                ny = oy;
+                nz = oz;
             }
         }
         dmin = sqrtf(dmin);
-        const float r_hi_w = uniform_f32(dmin * 1.000001f + rt_w);                                // every node of the block has a source at most this far
+        // every node of the block has a source at most r_hi_w away: the block's farthest corner from the source nearest to its centre (the block is the box
+        // centre +- (hx, hy, hz); tighter than dmin + rt_w unless that source lies along a diagonal)
+        const float fxn = fabsf(nx) + hx, fyn = fabsf(ny) + hy, fzn = fabsf(nz) + hz;
+        const float r_hi_w = uniform_f32(sqrtf(fxn * fxn + fyn * fyn + fzn * fzn) * 1.000001f);
         const float lnear_w = uniform_f32(0.5f * __log2f(fmaxf(wnear, 1e-37f)) - 1e-5f);         // log2 of that source's weight, rounded down
         const float d0_w = uniform_f32(fmaxf(0.f, dmin * 0.999999f - rt_w));                      // no source is closer than this to any node of the block
         const float coff = lam_l2 * d0_w;   // far tier: e^{-lambda (r - d0)} = 2^(r cexp32 + coff), folded back in by e^{-lambda d0} at the end
@@ -238,11 +252,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                 float q32[6];
 #pragma unroll
                 for (int a = 0; a < 6; a++) q32[a] = (float)q[a];
-                const float dx = cx - q32[0], dy = cy - q32[1], dz = cz - q32[2];
+                // no node of the block is closer to the source than the source is to the block's box
+                const float dx = fmaxf(fabsf(cx - q32[0]) - hx, 0.f), dy = fmaxf(fabsf(cy - q32[1]) - hy, 0.f), dz = fmaxf(fabsf(cz - q32[2]) - hz, 0.f);
                 const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
                 const float w2 = q32[3] * q32[3] + q32[4] * q32[4] + q32[5] * q32[5];
                 const float rel = 0.5f * __log2f(w2) + 1e-5f - lnear_w;                    // log2(|w_s| / |w_near|), rounded up (w = 0: -inf)
-                const float lhs = (dist * 0.999999f - rt_w - r_hi_w) * lam_l2;             // lower bound of lambda (r(x, s) - r_near(x)) / ln 2
+                const float lhs = (dist * 0.999999f - r_hi_w) * lam_l2;                    // lower bound of lambda (r(x, s) - r_near(x)) / ln 2
                 const bool valid = w2 > 0.f;                                              // the zero-weight padding is never evaluated
                 const bool far = lhs > g_l2 + rel;
                 const bool drop = lhs > skip_l2 + rel;
@@ -288,7 +303,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                 }
                 double g[kNearUnroll][NPT];
 #if SHM_TIER_NEAR_BFS
-                yukawa_near_batch<kNearUnroll * NPT>(&x[0][0], P.cexp, exp_tab, &g[0][0]);
+                constexpr int kB = SHM_TIER_NEAR_BATCH < kNearUnroll * NPT ? SHM_TIER_NEAR_BATCH : kNearUnroll * NPT;
+#pragma unroll
+                for (int b0 = 0; b0 < kNearUnroll * NPT; b0 += kB) yukawa_near_batch<kB>(&x[0][0] + b0, P.cexp, exp_tab, &g[0][0] + b0);
 #else
 #pragma unroll
                 for (int u = 0; u < kNearUnroll; u++)
@@ -340,17 +357,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
             if (!live[e]) continue;
             const double x0 = ax[e] + (double)fx[e] * e0, x1 = ay[e] + (double)fy[e] * e0, x2 = az[e] + (double)fz[e] * e0;
             const double nrm = sqrt(x0 * x0 + x1 * x1 + x2 * x2);
+            const size_t vi = (size_t)(kk0 + e) * plane + (size_t)cj * n + ci;   // (live: kk0 + e is a plane of the launch)
             // 0/0 -> NaN exactly like X /= X.norm() (:61).  A wave writes 64-byte row segments (8 nodes: half lines); the x-adjacent block is a neighbouring
             // unit of the same XCD's queue, so the two halves meet in that XCD's L2: PMC, kernel alone (tools/conv_pmc.sh): 412 MB written for 384 MB of
             // output (non-temporal stores: 497 MB; 16 x 4 x NPT blocks: 387 MB but 7 % slower -- the wider block classifies fewer sources as far)
 #if SHM_TIER_NT
-            __builtin_nontemporal_store(x0 / nrm, &Y0[vidx[e]]);
-            __builtin_nontemporal_store(x1 / nrm, &Y1[vidx[e]]);
-            __builtin_nontemporal_store(x2 / nrm, &Y2[vidx[e]]);
+            __builtin_nontemporal_store(x0 / nrm, &Y0[vi]);
+            __builtin_nontemporal_store(x1 / nrm, &Y1[vi]);
+            __builtin_nontemporal_store(x2 / nrm, &Y2[vi]);
 #else
-            Y0[vidx[e]] = x0 / nrm;
-            Y1[vidx[e]] = x1 / nrm;
-            Y2[vidx[e]] = x2 / nrm;
+            Y0[vi] = x0 / nrm;
+            Y1[vi] = x1 / nrm;
+            Y2[vi] = x2 / nrm;
 #endif
         }
     }  // unit loop

@@ -1787,9 +1787,11 @@ struct Solver final : SolverBase {
         // the kernel under 128 VGPRs = two workgroups per CU running out of phase (512^3 fp64: DIR 0.70 -> 0.60 ms, RES 0.64 -> 0.58 ms against
         // 4 rows per lane / one workgroup per CU; 8 rows per lane spill)
         c.yblocks = (n + wy * c.ry - 1) / (wy * c.ry);
-        // z chunks for two rounds of resident workgroups: ~4 workgroups per CU with 8 waves (two resident), ~2 with 16 (one resident; 512^3 fp64: 64
-        // instead of 32 planes per workgroup, DIR 5.65 -> 5.79 TB/s)
-        const int want = std::max(1, ((c.nw == 16 ? 2 : 4) * num_cus + c.yblocks - 1) / c.yblocks);
+        // z chunks for ONE round of resident workgroups (two 8-wave or one 16-wave workgroup per CU: 2 num_cus row blocks x z chunks), i.e. the deepest
+        // chunks that still fill the chip: a chunk's first two planes are loaded before anything is computed, and every chunk re-reads its two bordering planes.
+        // Round 2 ran two rounds with 8 waves; one measured better in round 3 (tools/r03_cg_probe.sh): 512^3 fp32 64 instead of 32 planes per chunk DIR
+        // 0.699 -> 0.723, RES 0.725 -> 0.746 of the HBM peak; 256^3 fp64 16 instead of 8 planes: loop 0.569 -> 0.589; deeper than one round: worse.
+        const int want = std::max(1, (2 * num_cus + c.yblocks - 1) / c.yblocks);
         c.zc = std::min(64, std::max(8, sl.nzl / want));
         if (zc_env > 0) c.zc = zc_env;
         c.zc = std::max(1, std::min(c.zc, sl.nzl));

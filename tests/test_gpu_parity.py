@@ -72,10 +72,14 @@ def test_tiered_conv_stays_within_its_budget(shm, path, hcoef, monkeypatch):
     assert stt.pairs_fp64 > 0
 
 
+@pytest.mark.parametrize("exact", [False, True])
 @pytest.mark.parametrize("lam_scale,n", [(4.0, 32), (8.0, 24)])
-def test_conv_far_clusters_in_fp32_keep_fp64_accuracy(shm, oracle_c, lam_scale, n):
-    """With a short diffusion length most source clusters are "far" for most node tiles and take the fp32 branch of the
-    fp64 kernel; the normalised field must still agree with the all-fp64 C oracle to rounding."""
+def test_conv_far_clusters_in_fp32_keep_fp64_accuracy(shm, oracle_c, lam_scale, n, exact, monkeypatch):
+    """With a short diffusion length most sources are "far" for most node blocks.  The all-fp64 kernel (SHM_CONV_EXACT=1) sends a cluster to fp32 only when
+    its terms are below e^-25 of the tile's dominant term: Y agrees with the all-fp64 C oracle to rounding.  The shipped tiered kernel (terms below e^-8
+    of a block's dominant terms in packed fp32, vanishing ones dropped) stays within its budget."""
+    if exact:
+        monkeypatch.setenv("SHM_CONV_EXACT", "1")
     d = load_golden("bunny_small_n16")
     lam = float(d["lam"]) * lam_scale
     cell = float(d["cell"]) * 15 / (n - 1)
@@ -88,7 +92,7 @@ def test_conv_far_clusters_in_fp32_keep_fp64_accuracy(shm, oracle_c, lam_scale, 
     ref = ref.reshape(-1, 3)
     ok = np.isfinite(ref).all(axis=1)
     assert ok.mean() > 0.5            # beyond lambda*r ~ 745 the fp64 reference itself underflows to 0/0
-    assert np.abs(Y[ok] - ref[ok]).max() < 1e-10
+    assert np.abs(Y[ok] - ref[ok]).max() < (1e-10 if exact else Y_BUDGET)
 
 
 @pytest.mark.parametrize("case,scrub", [("bunny_small_n16", True), ("bunny_small_n32", True), ("bunny_pc_n32", False)])

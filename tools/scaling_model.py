@@ -3,24 +3,31 @@
 NO HARDWARE CURVE EXISTS YET (the development pool has one-GPU boxes; the driver's 8-GPU leg has not run): this is the cost model
 DESIGN.md section 5 quotes, so that the solver choice per (n, m, P) is an argument and not a guess.
 
-    python tools/scaling_model.py profiles/r02_bench_default.json [profiles/r02_bench_256_primal_plain.json]
+    python tools/scaling_model.py profiles/r03_bench_default.json [profiles/r03_bench_256_primal_plain.json]
 
-Model, per solve on P ranks (z-slabs; constants at the top of the file):
-  gathered dual (AUTO):  t = (conv + div)/P + max(0, setup - conv/P) + gather + pcg + shift
-        Steps 1-2 and the divergence shard perfectly; the constraint set-up (host + Gauss-Jordan, replicated) hides behind Step 1 until Step 1
-        gets shorter than it; the right-hand side is all-gathered (every rank receives (P-1)/P of one N-vector over its xGMI links); the
-        m-dimensional dual iteration is replicated (latency-bound: slicing it buys nothing).
+Model, per solve on P ranks (z-slabs; constants at the top of the file, each marked MEASURED (with its profiles/ file) or ASSUMED):
+  gathered dual (AUTO):  t = imb(P) (conv + div)/P + exposed_setup + gather + pcg + shift
+        Steps 1-2 and the divergence shard up to the measured slab imbalance imb(P) (tools/slab_plan_check.py); the constraint set-up (replicated) runs
+        beside Step 1 -- co-resident with the tiered fp64 kernel, where it takes `beside` ms, time-sliced to Step 1's end against the fp32 one -- and what is
+        left of it when Step 1 ends runs at its idle-GPU rate: exposed = max(0, 1 - (conv/P)/beside) * alone; the right-hand side is all-gathered (every rank
+        receives (P-1)/P of one N-vector over its xGMI links); the m-dimensional dual solve is replicated (latency-bound: slicing it buys nothing).
   primal stencil CG:     t = (conv + div)/P + max(0, setup - conv/P) + iters * (sweeps/P + halo + 2 allreduce + project) + shift
         the N-sized sweeps shard, the m-sized projection is replicated, one ghost plane of z per neighbour and two all-reduces per iteration.
 """
 import json
 import sys
 
-XGMI_LINK_GBS = 50.0     # sustained per link and direction for large send/recv (153 GB/s bidirectional peak per link, 7 links per GPU)
-LINKS = 7
-P2P_LAT_US = 15.0        # one grouped ncclSend/ncclRecv pair on an idle stream
-ALLREDUCE_LAT_US = 20.0  # small (<= 400 KB) all-reduce over 8 ranks
-SETUP_GJ_US_PER_STEP = 45.0  # three launch-bound kernels per 64-row pivot block (dense inverse, m <= 6144)
+XGMI_LINK_GBS = 50.0     # ASSUMED: sustained per link and direction for large send/recv (153 GB/s bidirectional peak per link, 7 links per GPU)
+LINKS = 7                # hardware: xGMI links per GPU
+P2P_LAT_US = 15.0        # ASSUMED: one grouped ncclSend/ncclRecv pair on an idle stream
+ALLREDUCE_LAT_US = 20.0  # ASSUMED: small (<= 400 KB) all-reduce over 8 ranks
+SETUP_GJ_US_PER_STEP = 98.0  # MEASURED (profiles/r03_timeline_256.txt): pivot 39 + panels 23 + update 36 us per 64-row pivot block on an idle GPU
+# MEASURED (profiles/r03_setup_alone.txt, tools/setup_alone.py): constraint set-up wall time in ms, (alone on an idle GPU, beside Step 1), by constraint rows m
+SETUP_MS = {1129: (2.06, 2.22), 2496: (5.19, 6.84), 2842: (8.15, 10.51), 2856: (20.09, 25.68), 1430: (13.36, 18.65), 12612: (25.21, None), 48893: (145.0, None)}
+# MEASURED (profiles/r03_slab_plan_check*.txt, tools/slab_plan_check.py): max / mean of the slabs' own Step-1 times, by workload and slab count;
+# fp32 culled workloads with the weighted plan (shm_config.slab_plan = SHM_SLAB_PLAN_STEP1), the others with equal planes
+IMBALANCE = {"bunny_small_256_f64": {4: 1.03, 8: 1.07}, "bunny_small_512_f64": {4: 1.03, 8: 1.05}, "bunny_pc_512_f64": {4: 1.03, 8: 1.05},
+             "rocker_512_f32": {4: 1.05, 8: 1.07}, "spraybottle_pc_1024_f32": {4: 1.013, 8: 1.034}}
 
 
 def setup_alone_ms(m, host_ms):
@@ -40,18 +47,22 @@ def main():
     N = n ** 3
     m = cfg["constraint_rows"]
     host_ms = 0.6e-3 * m + 0.3
-    # set-up on an otherwise idle GPU, measured with SHM_SETUP_ALONE=1 (MI355X).  Direct dual solve (m <= 4096: S assembled and inverted): m = 1129: 2.3 ms,
-    # 1430: 4.4, 2496: 5.6, 2842: 8.4;  through the grid + two-level G^-1: 26 ms at m = 12 612,
-    # 145 ms at m = 48 893; in between by the launch-bound Gauss-Jordan step count
-    measured = {1129: 2.3, 1430: 4.4, 2496: 5.6, 2842: 8.4, 2856: 8.4, 12612: 26.0, 48893: 145.0}
-    setup = measured.get(m, setup_alone_ms(m, host_ms) if m <= 6144 else 3.0e-3 * m)
-    print("workload %s  n=%d  m=%d  single-GPU: conv %.1f  pcg %.2f ms (%d iterations)  set-up alone ~%.1f ms" % (cfg["workload"], n, m, ph["ms_conv"], ph["ms_pcg"], cfg["cg_iters"], setup))
+    alone, beside = SETUP_MS.get(m, (setup_alone_ms(m, host_ms) if m <= 6144 else 3.0e-3 * m, None))
+    setup = alone
+    imb = IMBALANCE.get(cfg["workload"], {})
+    print("workload %s  n=%d  m=%d  single-GPU: conv %.1f  pcg %.2f ms (%d iterations)  set-up alone %.1f ms, beside Step 1 %s" % (
+        cfg["workload"], n, m, ph["ms_conv"], ph["ms_pcg"], cfg["cg_iters"], alone, ("%.1f ms" % beside) if beside else "time-sliced to Step 1's end"))
     print("%-28s %10s %10s %10s %10s" % ("gathered dual (AUTO)", "P=1", "P=2", "P=4", "P=8"))
     rows = {"ms_per_solve": [], "speedup": [], "nodes_per_s": []}
     t1 = None
     for P in (1, 2, 4, 8):
         gather = 0.0 if P == 1 else (N * T * (P - 1) / P) / (min(P - 1, LINKS) * XGMI_LINK_GBS * 1e9) * 1e3 + P2P_LAT_US * 1e-3
-        t = (ph["ms_conv"] + ph["ms_div"]) / P + max(0.0, setup - ph["ms_conv"] / P) + gather + ph["ms_pcg"] + ph["ms_shift"]
+        conv_p = ph["ms_conv"] / P * (imb.get(P, 1.0) if P > 1 else 1.0)
+        if beside:   # co-resident: progresses at alone/beside of its idle rate while Step 1 runs, at full rate afterwards
+            exposed = max(0.0, 1.0 - conv_p / beside) * alone
+        else:        # time-sliced: practically no progress until Step 1 ends (measured: rocker waits 45 of its 25 ms on one GPU)
+            exposed = ph["ms_wait_setup"] if P == 1 else alone
+        t = conv_p + ph["ms_div"] / P + exposed + gather + ph["ms_pcg"] + ph["ms_shift"]
         t1 = t1 or t
         rows["ms_per_solve"].append(t)
         rows["speedup"].append(t1 / t)
