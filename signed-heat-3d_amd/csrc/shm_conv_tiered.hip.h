@@ -115,19 +115,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
     static_assert(NPT % 2 == 0, "the far tier handles a lane's nodes in packed pairs");
     constexpr int kWaves = kBlock / kWave;
     constexpr int kNearUnroll = SHM_TIER_NEAR_UNROLL, kFarUnroll = SHM_TIER_FAR_UNROLL;
-    constexpr int kDummy = kTierCluster;   // one more staged entry: zero weight, far away -- pads the masks to whole groups of sources in flight
-    __shared__ double stage64[kWaves][(kTierCluster + 1) * 6];
-    __shared__ float stage32[kWaves][(kTierCluster + 1) * 6];
+    constexpr int kPad = kNearUnroll > kFarUnroll ? kNearUnroll : kFarUnroll;   // staged entries behind the last real one: zero weight, far away -- they pad the
+    __shared__ double stage64[kWaves][(kTierCluster + kPad) * 6];              // compacted lists to whole groups of sources in flight
+    __shared__ float stage32[kWaves][(kTierCluster + kPad) * 6];
     __shared__ double exp_tab[2048];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
     double* const tile = stage64[wave];
     float* const tile32 = stage32[wave];
     for (int a = threadIdx.x; a < 2048; a += kBlock) exp_tab[a] = exp_tab_g[a];
-    if (lane < 6) {
-        const double far_away = lane < 3 ? P.bbox_min[lane] - (double)P.n * P.cell : 0.0;   // >= one grid side from every node
-        tile[kDummy * 6 + lane] = far_away;
-        tile32[kDummy * 6 + lane] = (float)far_away;
-    }
     __syncthreads();   // the only workgroup barrier: the table
     const int n = P.n;
     const size_t plane = (size_t)n * n;
@@ -235,16 +230,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
             double q[6];
 #pragma unroll
             for (int a = 0; a < 6; a++) q[a] = nq[a];
-            if (c + 1 < P.n_clusters) {
-                const double* qn = src + ((size_t)(c + 1) * kTierCluster + lane) * 6;
+            auto prefetch_next = [&]() {   // the lane's source of the next cluster: issued once this cluster is staged, in flight while its two loops run
+                if (c + 1 < P.n_clusters) {
+                    const double* qn = src + ((size_t)(c + 1) * kTierCluster + lane) * 6;
 #pragma unroll
-                for (int a = 0; a < 6; a++) nq[a] = qn[a];
-            }
+                    for (int a = 0; a < 6; a++) nq[a] = qn[a];
+                }
+            };
             {   // the whole cluster against the block (bounding sphere, scalar loads): dropped before anything is staged
                 const float* rec = clusters + (size_t)c * kConvClusterRec;
                 const float gdx = cx - rec[0], gdy = cy - rec[1], gdz = cz - rec[2];
                 const float gap = sqrtf(gdx * gdx + gdy * gdy + gdz * gdz) * 0.999999f - rt_w - rec[3] - r_hi_w;
-                if (gap * lam_l2 > skip_l2 + rec[4] * 1.4426950408889634f - lnear_w) continue;
+                if (gap * lam_l2 > skip_l2 + rec[4] * 1.4426950408889634f - lnear_w) {
+                    prefetch_next();
+                    continue;
+                }
             }
             // one source per lane: near / far / dropped for this wave's block of nodes
             unsigned long long nearmask, farmask;
@@ -263,32 +263,40 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                 const bool drop = lhs > skip_l2 + rel;
                 nearmask = __ballot(valid && !far);
                 farmask = __ballot(valid && far && !drop);
-                // stage the cluster for the broadcast reads below (wave-private region: no barrier)
+                // stage the cluster for the broadcast reads below (wave-private region: no barrier), COMPACTED: the near sources in fp64 and the far ones in fp32
+                // each as a dense list in mask order, so that the two loops below walk consecutive entries with a plain counter (a bit scan per source cost
+                // ~10 scalar instructions on the wave's in-order instruction stream)
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (valid && !far) {
+                    const int rnk = __builtin_popcountll(nearmask & below);
 #pragma unroll
-                for (int a = 0; a < 6; a++) {
-                    tile[lane * 6 + a] = q[a];
-                    tile32[lane * 6 + a] = q32[a];
+                    for (int a = 0; a < 6; a++) tile[rnk * 6 + a] = q[a];
+                } else if (valid && !drop) {
+                    const int rnk = __builtin_popcountll(farmask & below);
+#pragma unroll
+                    for (int a = 0; a < 6; a++) tile32[rnk * 6 + a] = q32[a];
                 }
             }
-            cnt_near += (unsigned)__builtin_popcountll(nearmask);
-            cnt_far += (unsigned)__builtin_popcountll(farmask);
-            // next set bit of a scalar mask as a staged source index; an exhausted mask yields the zero-weight dummy entry
-            auto pop = [&](unsigned long long& m) {
-                const int s = m ? __builtin_ctzll(m) : kDummy;
-                m &= m - 1;
-                return s;
-            };
-            // ---- near tier: fp64, kNearUnroll sources in flight ----
-            while (nearmask) {
-                int sidx[kNearUnroll];
+            prefetch_next();
+            const int nnear = __builtin_popcountll(nearmask), nfar = __builtin_popcountll(farmask);
+            if (lane < kPad) {
 #pragma unroll
-                for (int u = 0; u < kNearUnroll; u++) sidx[u] = pop(nearmask);
-                // breadth-first over the kNearUnroll x NPT pairs in flight: every stage of e^{-lambda r}/r for all of them before the next stage, so that
+                for (int a = 0; a < 6; a++) {
+                    const double pv = a < 3 ? P.bbox_min[a] - (double)P.n * P.cell : 0.0;   // the padding entry: >= one grid side from every node, zero weight
+                    tile[(nnear + lane) * 6 + a] = pv;
+                    tile32[(nfar + lane) * 6 + a] = (float)pv;
+                }
+            }
+            cnt_near += (unsigned)nnear;
+            cnt_far += (unsigned)nfar;
+            // ---- near tier: fp64, kNearUnroll sources in flight ----
+            for (int i0 = 0; i0 < nnear; i0 += kNearUnroll) {
+                // breadth-first over the pairs in flight: every stage of e^{-lambda r}/r for all of them before the next stage, so that
                 // the dependent chain of one pair (rsq -> Newton -> exponent -> table -> ldexp) is covered by the others' independent work
                 double wx[kNearUnroll], wy[kNearUnroll], wz[kNearUnroll], x[kNearUnroll][NPT];
 #pragma unroll
                 for (int u = 0; u < kNearUnroll; u++) {
-                    const int s = sidx[u];
+                    const int s = i0 + u;
                     const double sz = tile[6 * s + 2];
                     wx[u] = tile[6 * s + 3];
                     wy[u] = tile[6 * s + 4];
@@ -322,13 +330,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                     }
             }
             // ---- far tier: packed fp32 (two nodes per instruction), kFarUnroll sources in flight (the transcendentals' results arrive late) ----
-            while (farmask) {
-                int sidx[kFarUnroll];
-#pragma unroll
-                for (int u = 0; u < kFarUnroll; u++) sidx[u] = pop(farmask);
+            for (int i0 = 0; i0 < nfar; i0 += kFarUnroll) {
 #pragma unroll
                 for (int u = 0; u < kFarUnroll; u++) {
-                    const int s = sidx[u];
+                    const int s = i0 + u;
                     const float sz = tile32[6 * s + 2];
                     const float wx = tile32[6 * s + 3], wy = tile32[6 * s + 4], wz = tile32[6 * s + 5];
                     const float dx = qx - tile32[6 * s], dy = qy - tile32[6 * s + 1];

@@ -1491,9 +1491,14 @@ struct Solver final : SolverBase {
         gjFlag.alloc(1);
         HIPCHK(hipMemsetAsync(gjFlag.p, 0, sizeof(int), stream));
         const int c_ld = outer * kGJ;
+        static const int pivot_e = getenv("SHM_GJ_PIVOT_E") ? atoi(getenv("SHM_GJ_PIVOT_E")) : 4;   // A/B knob: 4 = 256 threads; 2 = 1024 threads (2 % faster on an idle GPU, but four 40-register waves per SIMD do not fit beside Step 1)
+        auto launch_pivot = [&](int kb) {
+            if (pivot_e == 4) hipLaunchKernelGGL(gj_pivot_kernel<4>, dim3(1), dim3(256), 0, stream, M, mp, kb, gjP.p, gjFlag.p);
+            else hipLaunchKernelGGL(gj_pivot_kernel<2>, dim3(1), dim3(1024), 0, stream, M, mp, kb, gjP.p, gjFlag.p);
+        };
         if (outer == 1) {
             for (int kb = 0; kb < nb; kb++) {
-                hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(kBlock), 0, stream, M, mp, kb, gjP.p, gjFlag.p);
+                launch_pivot(kb);
                 hipLaunchKernelGGL(gj_panels_kernel, dim3(nb), dim3(kBlock), 0, stream, M, mp, kb, gjP.p, gjR.p, 0, gjC.p, c_ld, 0);
                 hipLaunchKernelGGL((gj_update_kernel<GJ_ALL>), dim3((unsigned)((size_t)nb * (nb + 1) / 2)), dim3(kBlock), 0, stream, M, mp, nb, kb, 0, 1,
                                    gjR.p, 0, gjC.p, c_ld, 0, kGJ);
@@ -1503,7 +1508,7 @@ struct Solver final : SolverBase {
                 const int nO = std::min(outer, nb - k0);
                 for (int t = 0; t < nO; t++) {
                     const int kb = k0 + t;
-                    hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(kBlock), 0, stream, M, mp, kb, gjP.p, gjFlag.p);
+                    launch_pivot(kb);
                     hipLaunchKernelGGL(gj_panels_kernel, dim3(nb), dim3(kBlock), 0, stream, M, mp, kb, gjP.p, gjR.p, t * kGJ, gjC.p, c_ld, t * kGJ);
                     hipLaunchKernelGGL((gj_update_kernel<GJ_CROSS>), dim3((unsigned)(nO * nb + nO * k0)), dim3(kBlock), 0, stream, M, mp, nb, kb, k0, nO,
                                        gjR.p, t * kGJ, gjC.p, c_ld, t * kGJ, kGJ);
@@ -1622,13 +1627,13 @@ struct Solver final : SolverBase {
             HIPCHK(hipMemsetAsync(gs_Ct.p, 0, (size_t)n * P * sizeof(double), st));
             hipLaunchKernelGGL(cosine_tables_kernel, dim3(grid_for(n1 * n, 1024)), dim3(kBlock), 0, st, n, P, gs_ctab.p, gs_Cm.p, gs_Ct.p);
             hipLaunchKernelGGL(green_symbol_kernel, dim3(grid_for((size_t)n * n * n, 4096)), dim3(kBlock), 0, st, n, gs_lam.p, W0.p);
-            // beside the tiered fp64 Step 1 (two 176-register waves per SIMD) only the narrow shape fits on a SIMD; otherwise the 128 x 128 tiles
+            // beside the tiered fp64 Step 1 (two 184-register waves per SIMD) only the narrow shape fits on a SIMD; otherwise the 128 x 128 tiles
             static const bool gemm_wide_env = getenv("SHM_GREEN_WIDE") != nullptr;   // A/B knob
             const bool narrow = (conv_tiered || getenv("SHM_GREEN_NARROW") != nullptr) && !gemm_wide_env;
             auto tiles = [](size_t v) { return (unsigned)((v + kGemmT - 1) / kGemmT); };
             auto gemm = [&](unsigned batches, int M, int N, int K, const double* A, int lda, long long sA, const double* B, int ldb, long long sB, double* C, int ldc, long long sC) {
                 if (narrow)
-                    hipLaunchKernelGGL(dgemm_rm_kernel<2>, dim3((unsigned)((N + 63) / 64), tiles((size_t)M), batches), dim3(kBlock), 0, st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC);
+                    hipLaunchKernelGGL(dgemm_rm_kernel<1>, dim3((unsigned)((N + 31) / 32), tiles((size_t)M), batches), dim3(kBlock), 0, st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC);
                 else
                     hipLaunchKernelGGL(dgemm_rm_kernel<4>, dim3(tiles((size_t)N), tiles((size_t)M), batches), dim3(kBlock), 0, st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC);
             };

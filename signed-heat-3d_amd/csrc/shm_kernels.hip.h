@@ -1142,32 +1142,37 @@ constexpr int kGJ = 64;
 // step 1: invert the 64x64 pivot block (Gauss-Jordan, SPD -> no pivoting).  256 threads, each owning a 4x4 sub-block
 // in registers; per elimination step only the pivot row and column travel through LDS (double-buffered: one barrier
 // per step).
-__global__ __launch_bounds__(kBlock) void gj_pivot_kernel(double* __restrict__ G, int ld, int kb, double* __restrict__ Pout, int* __restrict__ flag) {
+// E = elements per thread and dimension: E = 4 -> 256 threads (one wave per SIMD), E = 2 -> 1024 threads (four waves per SIMD).  The 64 elimination steps are a
+// dependent chain; with one wave per SIMD every one of a step's ~95 fp64 instructions waits out its predecessor's latency, with four a quarter of the
+// instructions per thread and three other waves to issue from meanwhile (round 3: 39 -> see DESIGN.md section 4 per 64 x 64 block).
+template <int E>
+__global__ __launch_bounds__((kGJ / E) * (kGJ / E)) void gj_pivot_kernel(double* __restrict__ G, int ld, int kb, double* __restrict__ Pout, int* __restrict__ flag) {
+    constexpr int kT = kGJ / E;   // threads per dimension
     __shared__ double rowk[2][kGJ], colk[2][kGJ];
     __builtin_amdgcn_s_setprio(3);   // (see gj_panels_kernel)
-    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    const int ty = threadIdx.x / kT, tx = threadIdx.x % kT;
     const size_t o = (size_t)kb * kGJ;
-    double r[4][4];
+    double r[E][E];
 #pragma unroll
-    for (int a = 0; a < 4; a++)
+    for (int a = 0; a < E; a++)
 #pragma unroll
-        for (int b = 0; b < 4; b++) r[a][b] = G[(o + ty * 4 + a) * ld + o + tx * 4 + b];
+        for (int b = 0; b < E; b++) r[a][b] = G[(o + ty * E + a) * ld + o + tx * E + b];
     for (int k = 0; k < kGJ; k++) {
-        const int pb = k & 1, kq = k >> 2, kr = k & 3;
+        const int pb = k & 1, kq = k / E, kr = k % E;
         if (kq == ty) {
 #pragma unroll
-            for (int a = 0; a < 4; a++)
+            for (int a = 0; a < E; a++)
                 if (a == kr) {
 #pragma unroll
-                    for (int b = 0; b < 4; b++) rowk[pb][tx * 4 + b] = r[a][b];
+                    for (int b = 0; b < E; b++) rowk[pb][tx * E + b] = r[a][b];
                 }
         }
         if (kq == tx) {
 #pragma unroll
-            for (int b = 0; b < 4; b++)
+            for (int b = 0; b < E; b++)
                 if (b == kr) {
 #pragma unroll
-                    for (int a = 0; a < 4; a++) colk[pb][ty * 4 + a] = r[a][b];
+                    for (int a = 0; a < E; a++) colk[pb][ty * E + a] = r[a][b];
                 }
         }
         __syncthreads();
@@ -1178,17 +1183,17 @@ __global__ __launch_bounds__(kBlock) void gj_pivot_kernel(double* __restrict__ G
         double ip = __builtin_amdgcn_rcp(piv);
         ip = fma(fma(-piv, ip, 1.0), ip, ip);
         ip = fma(fma(-piv, ip, 1.0), ip, ip);
-        double rv[4], cv[4];
+        double rv[E], cv[E];
 #pragma unroll
-        for (int b = 0; b < 4; b++) rv[b] = rowk[pb][tx * 4 + b];
+        for (int b = 0; b < E; b++) rv[b] = rowk[pb][tx * E + b];
 #pragma unroll
-        for (int a = 0; a < 4; a++) cv[a] = colk[pb][ty * 4 + a];
+        for (int a = 0; a < E; a++) cv[a] = colk[pb][ty * E + a];
 #pragma unroll
-        for (int a = 0; a < 4; a++)
+        for (int a = 0; a < E; a++)
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
+            for (int b = 0; b < E; b++) {
                 // branch-free selects (v_cndmask): a divergent if/else chain here cost ~1 us per elimination step
-                const bool ik = (ty * 4 + a) == k, jk = (tx * 4 + b) == k;
+                const bool ik = (ty * E + a) == k, jk = (tx * E + b) == k;
                 const double rowv = rv[b] * ip, colv = -cv[a] * ip;
                 const double base = fma(-cv[a], rowv, r[a][b]);
                 const double vk = jk ? ip : rowv;
@@ -1197,9 +1202,9 @@ __global__ __launch_bounds__(kBlock) void gj_pivot_kernel(double* __restrict__ G
             }
     }
 #pragma unroll
-    for (int a = 0; a < 4; a++)
+    for (int a = 0; a < E; a++)
 #pragma unroll
-        for (int b = 0; b < 4; b++) Pout[(ty * 4 + a) * kGJ + tx * 4 + b] = r[a][b];
+        for (int b = 0; b < E; b++) Pout[(ty * E + a) * kGJ + tx * E + b] = r[a][b];
 }
 
 // step 2: R[:, b] = P * G[kb, b] and C[b, :] = G[b, kb] for every block index b, from the block-lower triangle:

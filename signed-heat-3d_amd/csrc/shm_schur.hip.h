@@ -49,12 +49,12 @@ __global__ __launch_bounds__(kBlock) void cosine_tables_kernel(int n, int P, con
 // zero-filled / masked).  128 x 128 tile per workgroup, one 64 x 64 quadrant per wave as 4 x 4 v_mfma_f64_16x16x4_f64 accumulators, K in LDS chunks
 // of 16 (operand layout of gj_update_kernel), the next chunk's operands prefetched into registers under the matrix instructions: 41 TFLOP/s at n = 512
 // (a 64 x 64-tile version without the prefetch: 13).
-// WN = 4: the shape above.  WN = 2: 128 x 64 tiles, a 64 x 32 quadrant per wave -- half the accumulators (64 AGPRs; the whole kernel stays under 160 registers),
-// so that its workgroups fit on a SIMD beside two waves of the tiered fp64 Step-1 kernel (176 registers each) and the table is built WHILE Step 1 runs
-// rather than in the gaps between its launches.
+// WN = 4: the shape above.  WN = 1: 128 x 32 tiles, a 64 x 16 quadrant per wave -- a quarter of the accumulators; the whole kernel stays under 128 registers,
+// so that its workgroups fit on a SIMD beside two waves of the tiered fp64 Step-1 kernel (184 registers each: 144 are left) and the table is built WHILE
+// Step 1 runs rather than in the gaps between its launches.  (WN = 2, 160 registers, served the first, 176-register version of that kernel.)
 constexpr int kGemmT = 128, kGemmK = 16;
 template <int WN>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WN == 2 ? 3 : 2, WN == 2 ? 3 : 2))) void dgemm_rm_kernel(int M, int N, int K, const double* __restrict__ A, int lda, long long sA, const double* __restrict__ B, int ldb,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WN == 4 ? 2 : WN == 2 ? 3 : 4, WN == 4 ? 2 : WN == 2 ? 3 : 4))) void dgemm_rm_kernel(int M, int N, int K, const double* __restrict__ A, int lda, long long sA, const double* __restrict__ B, int ldb,
                                                           long long sB, double* __restrict__ C, int ldc, long long sC) {
     constexpr int kTN = 32 * WN;                // columns of the workgroup tile
     __builtin_amdgcn_s_setprio(3);              // (see gj_panels_kernel)

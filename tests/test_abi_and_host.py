@@ -197,11 +197,12 @@ def test_kernel_register_schedules():
     # the tiered fp64 Step 1 must leave room on every SIMD for a wave of the set-up kernels (two of its waves + one of theirs <= 512 registers, LDS likewise):
     # that is what lets the constraint set-up run WHILE Step 1 runs instead of in the gaps between its launches
     tier = by_name["void shm::conv_tiered_kernel<4>"]
-    assert tier["VGPRs"] <= 176 and tier["LDS Size"] <= 36 * 1024, tier
+    assert tier["VGPRs"] <= 184 and tier["LDS Size"] <= 36 * 1024, tier
     room = 512 - 2 * ((tier["VGPRs"] + 7) // 8 * 8)
-    for k in ("void shm::dgemm_rm_kernel<2>", "shm::gj_pivot_kernel", "shm::gj_panels_kernel", "void shm::gj_update_kernel<0>", "shm::schur_assemble_kernel", "shm::green_symbol_kernel"):
+    for k in ("void shm::dgemm_rm_kernel<1>", "void shm::gj_pivot_kernel<4>", "shm::gj_panels_kernel", "void shm::gj_update_kernel<0>", "shm::schur_assemble_kernel", "shm::green_symbol_kernel"):
         v = by_name[k]
-        assert v["VGPRs"] + v.get("AGPRs", 0) <= room and v["LDS Size"] <= 40 * 1024, (k, v, room)
+        waves_per_simd = 4 if "gj_pivot_kernel<2>" in k else 1      # (1024-thread workgroup: four waves on every SIMD)
+        assert waves_per_simd * ((v["VGPRs"] + v.get("AGPRs", 0) + 7) // 8 * 8) <= room and v["LDS Size"] <= 40 * 1024, (k, v, room)
     conv32 = by_name["void shm::conv_normalize_kernel<float, 8>"]   # two sources in flight, three waves per SIMD (measured best with the tile queue)
     assert conv32["VGPRs"] <= 168 and conv32["Occupancy"] >= 3, conv32
     for k, v in by_name.items():   # the shipped shape of the fused stencil-CG sweeps: two rows per lane, four waves per SIMD
