@@ -241,6 +241,9 @@ def main():
     ap.add_argument("--max-iters", type=int, default=0, help="cap the CG iterations (0 = library default 20 n); a capped run reports kernel rates, not a converged solve")
     ap.add_argument("--precond", default="auto", choices=["auto", "none", "dct"])
     ap.add_argument("--solver", default="auto", choices=["auto", "primal", "dual", "dual_slabs"])
+    ap.add_argument("--slab-plan", default="auto", choices=["auto", "equal", "step1"],
+                    help="z-slab plan of a multi-GPU run: equal planes, or planes weighted by the Step-1 work that source culling leaves in them "
+                         "(shm_config.slab_plan; auto = step1 for the culled fp32 workloads, equal otherwise -- DESIGN.md section 5)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the bootstrap/timing collectives (gloo + SHM_RCCL_LIB + SHM_BENCH_ONE_DEVICE=1 lets "
                          "several ranks share one GPU in tests)")
@@ -282,7 +285,8 @@ def main():
     pre = host.preprocess(hCoef=hCoef)                    # centroid/radius/h/areas/barycenters on the host (cheap)
     n, N = pre["n"], pre["n"] ** 3
 
-    solver = shm.GridSolver(device=local_rank, precision=precision, rank=rank, world=world, rccl_unique_id=uid)
+    slab_plan = {"equal": 0, "step1": 1, "auto": 1 if (precision == 32 and world > 1) else 0}[args.slab_plan]
+    solver = shm.GridSolver(device=local_rank, precision=precision, rank=rank, world=world, rccl_unique_id=uid, slab_plan=slab_plan)
     solver.set_problem(pre["pos"], pre["wnormal"], pre["area"], pre["lam"], n, pre["bbox_min"], pre["cell"])  # inputs resident in HBM
     scrub = not path.endswith(".pc")
 
@@ -336,7 +340,7 @@ def main():
             "data": "reference data file %s (no RNG; sources + grid resident in HBM before the timed region)" % path,
             "config": {"workload": args.workload, "grid": "%d^3" % n, "sources": int(pre["S"]), "constraint_rows": int(avg["m"]),
                        "tol": args.tol if args.tol > 0 else (1e-8 if precision == 64 else 1e-5), "cg_iters": int(avg["iters"]),
-                       "rel_residual": avg["rel_residual"], "partition": "z-slabs x%d" % world,
+                       "rel_residual": avg["rel_residual"], "partition": "z-slabs x%d%s" % (world, " (planes weighted by Step-1 work)" if slab_plan and world > 1 else ""),
                        "solver": (("dual, direct: the Schur complement S = A K^+ A^T is assembled explicitly (image-sum Green's table) and inverted beside Step 1; "
                                    "after Step 1: g = A K^+ b, mu = S^-1-solve of the bordered system, x = K^+ (A^T mu - b); cg_iters = passes (the first is "
                                    "the solve, further ones iterative refinement); K^+ = DCT fast Poisson solve"

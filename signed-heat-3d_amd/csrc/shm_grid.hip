@@ -1480,7 +1480,10 @@ struct Solver final : SolverBase {
     }
 
     // in-place inverse of the SPD matrix M (mp x mp, mp a multiple of 64, identity tail) on the set-up stream: blocked Gauss-Jordan (shm_kernels.hip.h)
-    void enqueue_gj_invert(double* M, int mp) {
+    // `refined_later`: the caller checks the inverse by a residual and refines (the direct dual solve with S^-1): the pivot blocks may then be inverted by the
+    // 16-step block kernel, whose result differs from the scalar 64-step one at the 1e-11 level on ill-conditioned matrices (A A^T: near-dependent rows of
+    // neighbouring cells; the projector test holds A P v to 1e-11 without refinement, so G keeps the scalar kernel)
+    void enqueue_gj_invert(double* M, int mp, bool refined_later = false) {
         hipStream_t stream = stream2;
         const int nb = mp / kGJ;
         static const int outer_env = getenv("SHM_GJ_OUTER") ? atoi(getenv("SHM_GJ_OUTER")) : 0;   // experiment knob: pivot blocks per outer block
@@ -1491,9 +1494,11 @@ struct Solver final : SolverBase {
         gjFlag.alloc(1);
         HIPCHK(hipMemsetAsync(gjFlag.p, 0, sizeof(int), stream));
         const int c_ld = outer * kGJ;
-        static const int pivot_e = getenv("SHM_GJ_PIVOT_E") ? atoi(getenv("SHM_GJ_PIVOT_E")) : 4;   // A/B knob: 4 = 256 threads; 2 = 1024 threads (2 % faster on an idle GPU, but four 40-register waves per SIMD do not fit beside Step 1)
+        static const int pivot_env = getenv("SHM_GJ_PIVOT_E") ? atoi(getenv("SHM_GJ_PIVOT_E")) : 0;
+        const int pivot_e = pivot_env ? pivot_env : (refined_later ? 16 : 4);   // 16 = block Gauss-Jordan with 4 x 4 pivot blocks (round 3);   // A/B knob: 4 = 256 threads; 2 = 1024 threads (2 % faster on an idle GPU, but four 40-register waves per SIMD do not fit beside Step 1)
         auto launch_pivot = [&](int kb) {
-            if (pivot_e == 4) hipLaunchKernelGGL(gj_pivot_kernel<4>, dim3(1), dim3(256), 0, stream, M, mp, kb, gjP.p, gjFlag.p);
+            if (pivot_e == 16) hipLaunchKernelGGL(gj_pivot_block4_kernel, dim3(1), dim3(256), 0, stream, M, mp, kb, gjP.p, gjFlag.p);
+            else if (pivot_e == 4) hipLaunchKernelGGL(gj_pivot_kernel<4>, dim3(1), dim3(256), 0, stream, M, mp, kb, gjP.p, gjFlag.p);
             else hipLaunchKernelGGL(gj_pivot_kernel<2>, dim3(1), dim3(1024), 0, stream, M, mp, kb, gjP.p, gjFlag.p);
         };
         if (outer == 1) {
@@ -1655,7 +1660,7 @@ struct Solver final : SolverBase {
             Sinv.alloc((size_t)mp * mp);
             HIPCHK(hipMemcpyAsync(Sinv.p, Sdense.p, (size_t)mp * mp * sizeof(double), hipMemcpyDeviceToDevice, st));
             if (mp > m) hipLaunchKernelGGL(set_diagonal_kernel, dim3((unsigned)((mp - m + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, Sinv.p, mp, m, mp, 1.0);   // identity tail
-            enqueue_gj_invert(Sinv.p, mp);
+            enqueue_gj_invert(Sinv.p, mp, true);
         } else {
             e_sch_done->record(st);
             HIPCHK(hipStreamWaitEvent(stream2, e_sch_done->e, 0));   // "set-up done" on stream2 (what the solve waits for) now includes S

@@ -1207,18 +1207,161 @@ __global__ __launch_bounds__((kGJ / E) * (kGJ / E)) void gj_pivot_kernel(double*
         for (int b = 0; b < E; b++) Pout[(ty * E + a) * kGJ + tx * E + b] = r[a][b];
 }
 
+// The same inverse by BLOCK Gauss-Jordan with 4 x 4 pivot blocks (round 3): 16 elimination steps instead of 64.  Thread (ty, tx) of a 16 x 16 grid owns the 4 x 4
+// block (ty, tx); in step q the owner of block (q, q) inverts it in registers (four unrolled scalar steps) while the threads of block row / column q publish
+// their blocks through LDS; after ONE barrier every thread forms T = Binv * Rb and r <- base - Cb * T (two 4 x 4 x 4 products: 128 FMAs), with the
+// operands selected branch-free so that the four cases (pivot block, pivot row, pivot column, elsewhere) run the same instructions:
+//   elsewhere:  Rb = M[q, tx], Cb = M[ty, q], base = r      -> r - M[ty,q] Binv M[q,tx]
+//   row q:      Rb = r,                                     -> Binv M[q,tx]                (result = T)
+//   column q:   Rb = I,        Cb = r,       base = 0       -> - M[ty,q] Binv
+//   (q, q):     Rb = I                                      -> Binv
+// The scalar version's 64 steps each pay a barrier, an LDS round trip and a reciprocal chain (0.6 us per step: 39 us per pivot block, the longest
+// link of the three-launch chain per pivot block that the constraint set-up waits for at <= 128^3).
+__global__ __launch_bounds__(256) void gj_pivot_block4_kernel(double* __restrict__ G, int ld, int kb, double* __restrict__ Pout, int* __restrict__ flag) {
+    __shared__ double rowb[2][16][16], colb[2][16][16], binv[2][16];
+    __builtin_amdgcn_s_setprio(3);   // (see gj_panels_kernel)
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    const size_t o = (size_t)kb * kGJ;
+    double r[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) r[a][b] = G[(o + ty * 4 + a) * ld + o + tx * 4 + b];
+    for (int q = 0; q < 16; q++) {
+        const int pb = q & 1;
+        const bool in_row = ty == q, in_col = tx == q;
+        if (in_row && in_col) {
+            // 4 x 4 Gauss-Jordan in registers (SPD: no pivoting); a non-positive pivot raises the flag like the scalar kernel
+            double B0[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) B0[a][b] = r[a][b];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const double piv = r[k][k];
+                if (!(piv > 0.)) *flag = 1;
+                double ip = __builtin_amdgcn_rcp(piv);
+                ip = fma(fma(-piv, ip, 1.0), ip, ip);
+                ip = fma(fma(-piv, ip, 1.0), ip, ip);
+                double rowv[4], colv[4];
+#pragma unroll
+                for (int b = 0; b < 4; b++) rowv[b] = r[k][b] * ip;
+#pragma unroll
+                for (int a = 0; a < 4; a++) colv[a] = r[a][k];
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        if (a == k) r[a][b] = (b == k) ? ip : rowv[b];
+                        else r[a][b] = (b == k) ? -colv[a] * ip : fma(-colv[a], rowv[b], r[a][b]);
+                    }
+            }
+            {   // one Newton step X <- X + X (I - B X): neighbouring source cells make near-dependent rows, and what the 4 x 4 inverse loses to them every
+                // later block step would carry along (the projector test holds A P v to 1e-11)
+                double E[4][4];
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        double e = a == b ? 1.0 : 0.0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) e = fma(-B0[a][k], r[k][b], e);
+                        E[a][b] = e;
+                    }
+                double X[4][4];
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        double x = r[a][b];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) x = fma(r[a][k], E[k][b], x);
+                        X[a][b] = x;
+                    }
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b = 0; b < 4; b++) r[a][b] = X[a][b];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) binv[pb][a * 4 + b] = r[a][b];
+        } else if (in_row) {
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) rowb[pb][tx][a * 4 + b] = r[a][b];
+        } else if (in_col) {
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) colb[pb][ty][a * 4 + b] = r[a][b];
+        }
+        __syncthreads();
+        // T = Binv Rb, column by column (r is still intact: the pivot row's Rb is its own block), then r row by row.  The pivot column's Cb is its own
+        // block -- which is exactly what it wrote to colb -- so Cb always comes from LDS and never needs a register copy; the live set is r, T and a few
+        // operand rows: the kernel has to fit in the registers Step 1's waves leave free.
+        double T[4][4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            double Rc[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const double rrow = rowb[pb][tx][k * 4 + b];   // (stale where unused: selected away)
+                Rc[k] = in_col ? (k == b ? 1.0 : 0.0) : (in_row ? r[k][b] : rrow);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                double t = binv[pb][a * 4] * Rc[0];
+#pragma unroll
+                for (int k = 1; k < 4; k++) t = fma(binv[pb][a * 4 + k], Rc[k], t);
+                T[a][b] = t;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            double Cr[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) Cr[k] = colb[pb][ty][a * 4 + k];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                double v = in_col ? 0.0 : r[a][b];
+#pragma unroll
+                for (int k = 0; k < 4; k++) v = fma(-Cr[k], T[k][b], v);
+                r[a][b] = in_row ? T[a][b] : v;
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) Pout[(ty * 4 + a) * kGJ + tx * 4 + b] = r[a][b];
+}
+
 // step 2: R[:, b] = P * G[kb, b] and C[b, :] = G[b, kb] for every block index b, from the block-lower triangle:
 //   X = stored block (b >= kb ? G[b,kb] : G[kb,b]);   b > kb: G[kb,b] = X^T, G[b,kb] = X;   b < kb: G[kb,b] = X, G[b,kb] = -X^T.
+typedef double gj_f64x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(kBlock) void gj_panels_kernel(const double* __restrict__ G, int ld, int kb, const double* __restrict__ P,
                                                            double* __restrict__ R /* [..][ld]: rows r_row0 .. r_row0+63 */, int r_row0,
                                                            double* __restrict__ C /* [ld][c_ld]: columns c_col0 .. c_col0+63 */, int c_ld, int c_col0) {
-    // x alone in LDS (33 KB): the row of P a wave multiplies with is the same for all its lanes (i = t / 64) and comes through the scalar / L1 path.
-    // (With P staged as well the kernel needed 65 KB of LDS and could not be placed on a CU beside two workgroups of the tiered Step-1 kernel.)
+    // X alone in LDS (33 KB; with P staged as well the kernel needed 65 KB and could not be placed on a CU beside two workgroups of the tiered Step-1
+    // kernel).  The 64 x 64 x 64 product P X (or P X^T) runs on the matrix cores (round 3; the scalar LDS version took 23-32 us per launch, three quarters of
+    // it waiting on LDS): one 32 x 32 quadrant per wave as 2 x 2 v_mfma_f64_16x16x4_f64 tiles; the A operand (P: the same 32 KB for every workgroup of
+    // the launch, L2-resident) goes from global memory straight into the lanes that feed it.
+    // Operand layout (one f64 per lane): A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15], D: col = lane & 15, row = (lane >> 4) + 4 reg.
     __shared__ double x[kGJ][kGJ + 1];
     __builtin_amdgcn_s_setprio(3);   // set-up kernels share their SIMDs with Step-1 waves: they are short and on the critical path
     const int b = blockIdx.x;
     const size_t o = (size_t)kb * kGJ, ob = (size_t)b * kGJ;
     const bool below = b >= kb;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w >> 1, wc = w & 1, l15 = lane & 15, l4 = lane >> 4;
+    double pa[2][kGJ / 4];   // this lane's A operands: rows wr*32 + a*16 + l15, k = 4 s + l4
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int s4 = 0; s4 < kGJ / 4; s4++) pa[a][s4] = P[(wr * 32 + a * 16 + l15) * kGJ + 4 * s4 + l4];
     for (int t = threadIdx.x; t < kGJ * kGJ; t += kBlock) {
         const int i = t / kGJ, j = t % kGJ;
         x[i][j] = below ? G[(ob + i) * ld + o + j] : G[(o + i) * ld + ob + j];
@@ -1227,17 +1370,38 @@ __global__ __launch_bounds__(kBlock) void gj_panels_kernel(const double* __restr
     for (int t = threadIdx.x; t < kGJ * kGJ; t += kBlock) {
         const int i = t / kGJ, j = t % kGJ;
         C[(ob + i) * c_ld + c_col0 + j] = below ? x[i][j] : -x[j][i];
-        const double* __restrict__ prow = P + i * kGJ;
-        double s = 0.;
-        if (b > kb) {
-#pragma unroll 8
-            for (int k = 0; k < kGJ; k++) s += prow[k] * x[j][k];
-        } else {
-#pragma unroll 8
-            for (int k = 0; k < kGJ; k++) s += prow[k] * x[k][j];
-        }
-        R[(size_t)(r_row0 + i) * ld + ob + j] = (b == kb) ? prow[j] : s;  // the pivot block column of R carries P: G[:,kb] = -C P, G[kb,kb] = P
     }
+    gj_f64x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) acc[a][c] = gj_f64x4{0., 0., 0., 0.};
+    if (b != kb) {
+#pragma unroll
+        for (int s4 = 0; s4 < kGJ / 4; s4++) {
+            const int k = 4 * s4 + l4;
+            double bf[2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const int j = wc * 32 + c * 16 + l15;
+                bf[c] = (b > kb) ? x[j][k] : x[k][j];   // R[:, b] = P X^T below the pivot block, P X above it
+            }
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int c = 0; c < 2; c++) acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[a][s4], bf[c], acc[a][c], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = wr * 32 + a * 16 + l4 + 4 * r, j = wc * 32 + c * 16 + l15;
+                // the pivot block column of R carries P: G[:,kb] = -C P, G[kb,kb] = P
+                R[(size_t)(r_row0 + i) * ld + ob + j] = (b == kb) ? P[i * kGJ + j] : acc[a][c][r];
+            }
 }
 
 // step 3+4: rank-64 update  G[i,j] -= C[i,:] R[:,j]  with the pivot row / column rewritten on the fly:
@@ -1246,7 +1410,6 @@ __global__ __launch_bounds__(kBlock) void gj_panels_kernel(const double* __restr
 // Dense fp64 GEMM -> matrix cores: v_mfma_f64_16x16x4_f64.  64x64 output tile per workgroup, one 32x32 quadrant per wave
 // (2x2 accumulators of 16x16), K = 64 in two LDS chunks of 32.  Operand layout (one f64 per lane):
 //   A[i = lane&15][k = lane>>4],  B[k = lane>>4][j = lane&15],  D: col = lane&15, row = (lane>>4) + 4*reg.
-typedef double gj_f64x4 __attribute__((ext_vector_type(4)));
 constexpr int kGJK = 32;
 // Which tiles of the block-lower triangle a launch updates, and with what:
 //   GJ_ALL   every tile, rank 64 (pivot block kb): the single-level algorithm (small m: latency-bound, fewest launches)

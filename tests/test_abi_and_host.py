@@ -199,7 +199,7 @@ def test_kernel_register_schedules():
     tier = by_name["void shm::conv_tiered_kernel<4>"]
     assert tier["VGPRs"] <= 184 and tier["LDS Size"] <= 36 * 1024, tier
     room = 512 - 2 * ((tier["VGPRs"] + 7) // 8 * 8)
-    for k in ("void shm::dgemm_rm_kernel<1>", "void shm::gj_pivot_kernel<4>", "shm::gj_panels_kernel", "void shm::gj_update_kernel<0>", "shm::schur_assemble_kernel", "shm::green_symbol_kernel"):
+    for k in ("void shm::dgemm_rm_kernel<1>", "shm::gj_pivot_block4_kernel", "shm::gj_panels_kernel", "void shm::gj_update_kernel<0>", "shm::schur_assemble_kernel", "shm::green_symbol_kernel"):
         v = by_name[k]
         waves_per_simd = 4 if "gj_pivot_kernel<2>" in k else 1      # (1024-thread workgroup: four waves on every SIMD)
         assert waves_per_simd * ((v["VGPRs"] + v.get("AGPRs", 0) + 7) // 8 * 8) <= room and v["LDS Size"] <= 40 * 1024, (k, v, room)
