@@ -186,7 +186,7 @@ def also_legs(shm, HostSolver, device, tol):
         if precision == 64:
             s.solve(tol=tol)
             t0 = time.perf_counter()
-            reps = 2
+            reps = 3
             sts = [s.solve(tol=tol).as_dict() for _ in range(reps)]
             dt = (time.perf_counter() - t0) / reps
             a = {k: float(np.mean([x[k] for x in sts])) for k in sts[0]}
@@ -216,9 +216,11 @@ def also_legs(shm, HostSolver, device, tol):
         s = shm.GridSolver(device=device, precision=precision)
         s.set_problem(pre["pos"], pre["wnormal"], pre["area"], pre["lam"], n, pre["bbox_min"], pre["cell"])
         s.solve()
+        reps = 3 if precision == 32 else 1
         t0 = time.perf_counter()
-        st = s.solve().as_dict()
-        dt = time.perf_counter() - t0
+        for _ in range(reps):
+            st = s.solve().as_dict()
+        dt = (time.perf_counter() - t0) / reps
         phis[precision] = s.get_phi()[0]
         if precision == 32:
             out["rocker_512_f32"] = {"value": n ** 3 / dt, "unit": "grid-nodes/s", "ms_per_step": 1e3 * dt, "cg_iters": int(st["iters"]),
@@ -232,8 +234,8 @@ def also_legs(shm, HostSolver, device, tol):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="bunny_small_256_f64", choices=sorted(WORKLOADS))
     ap.add_argument("--tol", type=float, default=0.0, help="projected-CG relative residual tolerance (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

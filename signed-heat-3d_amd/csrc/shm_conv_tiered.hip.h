@@ -127,7 +127,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
     const int n = P.n;
     const size_t plane = (size_t)n * n;
     const float lam_l2 = (float)(P.lambda * 1.4426950408889634);     // lambda in powers of two per unit length
-    const float cexp32 = -lam_l2;
     const float g_l2 = P.tier_log * 1.4426950408889634f, skip_l2 = P.skip_base * 1.4426950408889634f;
     constexpr double kHalfZ = 0.5 * (NPT - 1);
     constexpr double kHalfX = 0.5 * (kTierTX - 1), kHalfY = 0.5 * (kTierTY - 1);
@@ -168,7 +167,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
         const int ci = min(li, n - 1), cj = min(lj, n - 1);
         // indicesToNodePosition: (i,j,k)*cellSize + bboxMin, evaluated in double like the reference (:510-514)
         const double px = ci * P.cell + P.bbox_min[0], py = cj * P.cell + P.bbox_min[1];
-        const float qx = (float)px, qy = (float)py;
+        const float qx = (float)(px * (P.lambda * 1.4426950408889634)), qy = (float)(py * (P.lambda * 1.4426950408889634));   // far tier: scaled coordinates (see the far loop)
 #pragma unroll
         for (int e = 0; e < NPT; e++) {
             int kk = kk0 + e;   // the wave's nodes form a compact kTierTX x kTierTY x NPT block
@@ -176,7 +175,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
             kk = min(kk, P.kk_end - 1);
             const double z = (P.k0 + kk - 1) * P.cell + P.bbox_min[2];
             pz[e] = z;
-            qz[e] = (float)z;
+            qz[e] = (float)(z * (P.lambda * 1.4426950408889634));
             ax[e] = ay[e] = az[e] = 0.;
             fx[e] = fy[e] = fz[e] = 0.f;
         }
@@ -216,7 +215,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
         const float r_hi_w = uniform_f32(sqrtf(fxn * fxn + fyn * fyn + fzn * fzn) * 1.000001f);
         const float lnear_w = uniform_f32(0.5f * __log2f(fmaxf(wnear, 1e-37f)) - 1e-5f);         // log2 of that source's weight, rounded down
         const float d0_w = uniform_f32(fmaxf(0.f, dmin * 0.999999f - rt_w));                      // no source is closer than this to any node of the block
-        const float coff = lam_l2 * d0_w;   // far tier: e^{-lambda (r - d0)} = 2^(r cexp32 + coff), folded back in by e^{-lambda d0} at the end
+        const float coff = lam_l2 * d0_w;   // far tier: e^{-lambda (r - d0)} = 2^(coff - lambda log2 e r), folded back in by e^{-lambda d0} at the end
 
         // the lane's source of the next cluster, loaded one cluster ahead
         double nq[6];
@@ -273,8 +272,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                     for (int a = 0; a < 6; a++) tile[rnk * 6 + a] = q[a];
                 } else if (valid && !drop) {
                     const int rnk = __builtin_popcountll(farmask & below);
+                    // positions in units of 1 / (lambda log2 e): the far loop then gets lambda r log2 e = d2' rsq(d2') without a multiplication of its own
 #pragma unroll
-                    for (int a = 0; a < 6; a++) tile32[rnk * 6 + a] = q32[a];
+                    for (int a = 0; a < 6; a++) tile32[rnk * 6 + a] = a < 3 ? q32[a] * lam_l2 : q32[a];
                 }
             }
             prefetch_next();
@@ -336,16 +336,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                     const int s = i0 + u;
                     const float sz = tile32[6 * s + 2];
                     const float wx = tile32[6 * s + 3], wy = tile32[6 * s + 4], wz = tile32[6 * s + 5];
-                    const float dx = qx - tile32[6 * s], dy = qy - tile32[6 * s + 1];
+                    const float dx = qx - tile32[6 * s], dy = qy - tile32[6 * s + 1];   // (scaled coordinates: qx, qy, qz and the staged positions are x lambda log2 e)
                     const float dxy2 = dx * dx + dy * dy;
 #pragma unroll
                     for (int e = 0; e < NPT; e += 2) {
                         const float2v z2 = {qz[e], qz[e + 1]};
                         const float2v dz = z2 - sz;
                         const float2v d2 = __builtin_elementwise_fma(dz, dz, float2v{dxy2, dxy2});
-                        const float2v rinv = {__builtin_amdgcn_rsqf(d2.x), __builtin_amdgcn_rsqf(d2.y)};
-                        const float2v r = d2 * rinv;
-                        const float2v arg = __builtin_elementwise_fma(r, float2v{cexp32, cexp32}, float2v{coff, coff});
+                        const float2v rinv = {__builtin_amdgcn_rsqf(d2.x), __builtin_amdgcn_rsqf(d2.y)};   // 1 / (lambda log2 e r)
+                        const float2v arg = __builtin_elementwise_fma(-d2, rinv, float2v{coff, coff});     // -lambda log2 e (r - d0)
                         const float2v ex = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
                         const float2v g = ex * rinv;
                         float2v a;
@@ -356,7 +355,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                 }
             }
         }
-        const double e0 = YukawaMath<double>::exp_neg(-P.lambda * (double)d0_w);
+        const double e0 = YukawaMath<double>::exp_neg(-P.lambda * (double)d0_w) * (P.lambda * 1.4426950408889634);   // (the far sums hold 1 / (lambda log2 e r))
 #pragma unroll
         for (int e = 0; e < NPT; e++) {
             if (!live[e]) continue;

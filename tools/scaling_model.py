@@ -21,13 +21,13 @@ XGMI_LINK_GBS = 50.0     # ASSUMED: sustained per link and direction for large s
 LINKS = 7                # hardware: xGMI links per GPU
 P2P_LAT_US = 15.0        # ASSUMED: one grouped ncclSend/ncclRecv pair on an idle stream
 ALLREDUCE_LAT_US = 20.0  # ASSUMED: small (<= 400 KB) all-reduce over 8 ranks
-SETUP_GJ_US_PER_STEP = 98.0  # MEASURED (profiles/r03_timeline_256.txt): pivot 39 + panels 23 + update 36 us per 64-row pivot block on an idle GPU
+SETUP_GJ_US_PER_STEP = 80.0  # MEASURED (profiles/r03_bench256_kernel_stats.txt, idle-GPU launches): pivot 30 + panels 14 + update 36 us per 64-row pivot block
 # MEASURED (profiles/r03_setup_alone.txt, tools/setup_alone.py): constraint set-up wall time in ms, (alone on an idle GPU, beside Step 1), by constraint rows m
-SETUP_MS = {1129: (2.06, 2.22), 2496: (5.19, 6.84), 2842: (8.15, 10.51), 2856: (20.09, 25.68), 1430: (13.36, 18.65), 12612: (25.21, None), 48893: (145.0, None)}
+SETUP_MS = {1129: (1.68, 1.78), 2496: (4.37, 5.81), 2842: (7.07, 10.02), 2856: (19.52, 29.40), 1430: (13.27, 23.09), 12612: (25.33, None), 48893: (145.0, None)}
 # MEASURED (profiles/r03_slab_plan_check*.txt, tools/slab_plan_check.py): max / mean of the slabs' own Step-1 times, by workload and slab count;
 # fp32 culled workloads with the weighted plan (shm_config.slab_plan = SHM_SLAB_PLAN_STEP1), the others with equal planes
-IMBALANCE = {"bunny_small_256_f64": {4: 1.03, 8: 1.07}, "bunny_small_512_f64": {4: 1.03, 8: 1.05}, "bunny_pc_512_f64": {4: 1.03, 8: 1.05},
-             "rocker_512_f32": {4: 1.05, 8: 1.07}, "spraybottle_pc_1024_f32": {4: 1.013, 8: 1.034}}
+IMBALANCE = {"bunny_small_256_f64": {4: 1.02, 8: 1.07}, "bunny_small_512_f64": {4: 1.04, 8: 1.10}, "bunny_pc_512_f64": {4: 1.04, 8: 1.10},
+             "rocker_512_f32": {4: 1.057, 8: 1.066}, "spraybottle_pc_1024_f32": {4: 1.011, 8: 1.040}}
 
 
 def setup_alone_ms(m, host_ms):
