@@ -40,6 +40,8 @@ WORKLOADS = {
     "spraybottle_pc_1024_f32": ("data/SprayBottle.pc", 6.0, 32),  # configs[4] (.obj missing upstream -> .pc)
     "bunny_small_512_f64": ("data/bunny_small.obj", 5.0, 64),
     "bunny_small_512_f32": ("data/bunny_small.obj", 5.0, 32),
+    "rocker_512_f64": ("data/rocker.obj", 5.0, 64),             # configs[2] / [4] in the reference's own arithmetic (BASELINE names fp32 for them)
+    "spraybottle_pc_1024_f64": ("data/SprayBottle.pc", 6.0, 64),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured streaming ceiling
 

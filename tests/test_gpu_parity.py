@@ -713,7 +713,7 @@ def test_config2_rocker_512_fp32_full_size(shm):
 @pytest.mark.skipif(bool(__import__("os").environ.get("SHM_SKIP_1024")), reason="SHM_SKIP_1024 set")
 def test_config4_spraybottle_1024_fp32_full_size(shm):
     """BASELINE.json configs[4] on one GPU: SprayBottle.pc, 1024^3, fp32 (S = 52 290 points, m = 48 893; ~60 GB of HBM, ~10 s solve).
-    No fp64 run beside it (another 110 GB and ~25 s of Step 1); the fp32-vs-fp64 error of this input is asserted at 128^3 / 256^3."""
+    No fp64 run beside it (another 110 GB of HBM and 6 s: profiles/r03_bench_spraybottle_pc_1024_f64.json); the fp32-vs-fp64 error of this input is asserted at 128^3 / 256^3."""
     import psutil
     if psutil.virtual_memory().available < 80 * 2 ** 30:
         pytest.skip("needs ~50 GB of host memory for the float64 copies of phi, b and L phi")
