@@ -26,8 +26,8 @@ SETUP_GJ_US_PER_STEP = 80.0  # MEASURED (profiles/r03_bench256_kernel_stats.txt,
 SETUP_MS = {1129: (1.68, 1.78), 2496: (4.37, 5.81), 2842: (7.07, 10.02), 2856: (19.52, 29.40), 1430: (13.27, 23.09), 12612: (25.33, None), 48893: (145.0, None)}
 # MEASURED (profiles/r03_slab_plan_check*.txt, tools/slab_plan_check.py): max / mean of the slabs' own Step-1 times, by workload and slab count;
 # fp32 culled workloads with the weighted plan (shm_config.slab_plan = SHM_SLAB_PLAN_STEP1), the others with equal planes
-IMBALANCE = {"bunny_small_256_f64": {4: 1.02, 8: 1.07}, "bunny_small_512_f64": {4: 1.04, 8: 1.10}, "bunny_pc_512_f64": {4: 1.04, 8: 1.10},
-             "rocker_512_f32": {4: 1.057, 8: 1.066}, "spraybottle_pc_1024_f32": {4: 1.011, 8: 1.040}}
+IMBALANCE = {"bunny_small_256_f64": {4: 1.04, 8: 1.09}, "bunny_small_512_f64": {4: 1.03, 8: 1.10}, "bunny_pc_512_f64": {4: 1.05, 8: 1.12},
+             "rocker_512_f32": {4: 1.027, 8: 1.069}, "spraybottle_pc_1024_f32": {4: 1.016, 8: 1.014}}
 
 
 def setup_alone_ms(m, host_ms):
