@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -127,6 +128,59 @@ struct Rccl {
     }
 };
 
+// Host -> device uploads go through pinned staging chunks: hipMemcpyAsync from pageable memory first waits for everything queued on its stream, and the
+// set-up stream's work cannot progress while a Step-1 kernel that fills the SIMDs runs (fp32 and all-fp64 Step 1) -- the host part of the constraint
+// set-up then stalled at its first upload until Step 1 had finished (rocker 512^3 fp32: 40 ms of exposed wait, 13 of them host work that had not started;
+// round 3).  A chunk is reused once the event recorded behind its copy has completed; the pool never shrinks (hundreds of MB for the 1024^3 set-up) and
+// falls back to the plain copy beyond kMaxBytes or when pinned memory cannot be had.
+struct PinnedPool {
+    struct Chunk {
+        void* p;
+        size_t cap;
+        hipEvent_t ev;
+        bool busy;
+    };
+    static constexpr size_t kMaxBytes = (size_t)4 << 30;
+    std::vector<Chunk> chunks;
+    size_t total = 0;
+    std::mutex mu;
+    static PinnedPool& get() {
+        static PinnedPool* P = new PinnedPool();   // (never destroyed: no HIP calls at process exit)
+        return *P;
+    }
+    void upload(void* dst, const void* src, size_t bytes, hipStream_t st) {
+        std::lock_guard<std::mutex> lk(mu);
+        Chunk* c = nullptr;
+        for (Chunk& k : chunks) {
+            if (k.cap < bytes) continue;
+            if (k.busy) {
+                if (hipEventQuery(k.ev) == hipSuccess) k.busy = false;
+                else (void)hipGetLastError();   // hipErrorNotReady is not an error here
+            }
+            if (!k.busy && (!c || k.cap < c->cap)) c = &k;
+        }
+        if (!c && total + bytes <= kMaxBytes) {
+            Chunk k{nullptr, std::max(bytes + bytes / 4, (size_t)1 << 20), nullptr, false};
+            if (hipHostMalloc(&k.p, k.cap, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&k.ev, hipEventDisableTiming) == hipSuccess) {
+                chunks.push_back(k);
+                total += k.cap;
+                c = &chunks.back();
+            } else {
+                (void)hipGetLastError();
+                if (k.p) (void)hipHostFree(k.p);
+            }
+        }
+        if (!c) {
+            HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+            return;
+        }
+        memcpy(c->p, src, bytes);
+        HIPCHK(hipMemcpyAsync(dst, c->p, bytes, hipMemcpyHostToDevice, st));
+        HIPCHK(hipEventRecord(c->ev, st));
+        c->busy = true;
+    }
+};
+
 template <typename T> struct DevArray {
     T* p = nullptr;
     size_t count = 0;
@@ -152,7 +206,7 @@ template <typename T> struct DevArray {
     }
     void upload(const std::vector<T>& v, hipStream_t st) {
         alloc(v.size());
-        if (!v.empty()) HIPCHK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+        if (!v.empty()) PinnedPool::get().upload(p, v.data(), v.size() * sizeof(T), st);   // the vector may die right after the call
     }
 };
 
@@ -1439,9 +1493,9 @@ struct Solver final : SolverBase {
         d_tidx.upload(tidx, stream);
         d_tval.upload(tval, stream);
         hipLaunchKernelGGL(scatter_triplets_kernel, dim3(grid_for(tidx.size(), 4096)), dim3(kBlock), 0, stream, (size_t)tidx.size(), d_tidx.p, d_tval.p, Ginv.p);
-        gjFlag.alloc(1);
-        HIPCHK(hipMemsetAsync(gjFlag.p, 0, sizeof(int), stream));
-        hipLaunchKernelGGL(tl_block_inverse_kernel, dim3((unsigned)P), dim3(kBlock), 0, stream, tl.view(), (const int*)nullptr, tl.D.p, gjFlag.p);
+        gjFlag.alloc(2);   // [0]: blocked Gauss-Jordan (enqueue_gj_invert), [1]: the boxes' inverses; both read by finish_invert_G()
+        HIPCHK(hipMemsetAsync(gjFlag.p + 1, 0, sizeof(int), stream));
+        hipLaunchKernelGGL(tl_block_inverse_kernel, dim3((unsigned)P), dim3(kBlock), 0, stream, tl.view(), (const int*)nullptr, tl.D.p, gjFlag.p + 1);
         for (int col = 0; col < 8; col++) {
             const int cntc = tl.colour_ptr[col + 1] - tl.colour_ptr[col];
             if (cntc > 0)
@@ -1456,10 +1510,8 @@ struct Solver final : SolverBase {
         hipLaunchKernelGGL((convert_kernel<double, float>), dim3(grid_for(szE, 4096)), dim3(kBlock), 0, stream, szE, tl.E.p, tl.E32.p);
         hipLaunchKernelGGL((convert_kernel<double, float>), dim3(grid_for(szE, 4096)), dim3(kBlock), 0, stream, szE, tl.Tm.p, tl.T32.p);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(stream));  // host vectors above are locals
-        int flag = 0;
-        HIPCHK(hipMemcpy(&flag, gjFlag.p, sizeof(int), hipMemcpyDeviceToHost));
-        if (flag) throw Error(SHM_ERR_SINGULAR, "A A^T (or A K^+ A^T) is not positive definite (duplicate or degenerate constraint rows)");
+        // (no synchronisation here: the uploads above were staged, and a non-positive pivot of a box is reported by finish_invert_G() with the others --
+        // waiting for the set-up stream at this point stalls the rest of the host set-up behind a Step-1 kernel that leaves it no SIMD)
         log("[shm] two-level inverse of A A^T: box %d, %d boxes (%d interior rows), separator %d rows", tl.box, P, tl.nI, nS);
         return true;
     }
@@ -1497,7 +1549,7 @@ struct Solver final : SolverBase {
         gjP.alloc(kGJ * kGJ);
         gjR.alloc((size_t)outer * kGJ * mp);   // [outer * 64][mp]
         gjC.alloc((size_t)mp * outer * kGJ);   // [mp][outer * 64]
-        gjFlag.alloc(1);
+        gjFlag.alloc(2);
         HIPCHK(hipMemsetAsync(gjFlag.p, 0, sizeof(int), stream));
         const int c_ld = outer * kGJ;
         static const int pivot_env = getenv("SHM_GJ_PIVOT_E") ? atoi(getenv("SHM_GJ_PIVOT_E")) : 0;
@@ -1675,10 +1727,11 @@ struct Solver final : SolverBase {
     }
     void finish_invert_G() {
         hipStream_t stream = stream2;
-        int flag = 0;
-        HIPCHK(hipMemcpyAsync(&flag, gjFlag.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+        int flag[2] = {0, 0};
+        if (!tl.on) HIPCHK(hipMemsetAsync(gjFlag.p + 1, 0, sizeof(int), stream));   // (slot 1 belongs to the two-level build)
+        HIPCHK(hipMemcpyAsync(flag, gjFlag.p, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
-        if (flag) throw Error(SHM_ERR_SINGULAR, "A A^T is not positive definite (duplicate or degenerate constraint rows)");
+        if (flag[0] || flag[1]) throw Error(SHM_ERR_SINGULAR, "A A^T is not positive definite (duplicate or degenerate constraint rows)");
     }
 
     // ------------------------------------------------------------------------------------------

@@ -60,8 +60,9 @@ def main():
         conv_p = ph["ms_conv"] / P * (imb.get(P, 1.0) if P > 1 else 1.0)
         if beside:   # co-resident: progresses at alone/beside of its idle rate while Step 1 runs, at full rate afterwards
             exposed = max(0.0, 1.0 - conv_p / beside) * alone
-        else:        # time-sliced: practically no progress until Step 1 ends (measured: rocker waits 45 of its 25 ms on one GPU)
-            exposed = ph["ms_wait_setup"] if P == 1 else alone
+        else:        # time-sliced: the host part of the set-up runs under Step 1 (staged uploads, round 3), its kernels queue up behind Step 1 and run when it
+            # ends -- what one GPU shows as ms_wait_setup; a slab's Step 1 shorter than the whole set-up leaves the rest exposed as well
+            exposed = max(ph["ms_wait_setup"], alone - conv_p)
         t = conv_p + ph["ms_div"] / P + exposed + gather + ph["ms_pcg"] + ph["ms_shift"]
         t1 = t1 or t
         rows["ms_per_solve"].append(t)
