@@ -486,6 +486,10 @@ struct Solver final : SolverBase {
     bool have_S = false;
     bool dual_direct_requested = false, dual_direct = false;   // direct dual solve: S^-1 (Sinv) instead of G^-1; requested by solve(), decided in build_constraints()
     DevArray<double> Sinv;
+    // s_setprio(3) in the set-up kernels that share the SIMDs with the tiered Step 1: they are short and on the critical path when Step 1 is (64^3 ... 256^3, thin
+    // slabs of a multi-GPU run); where Step 1 outlasts the set-up several times over the raised priority only costs Step 1 issue slots at the wrong moments
+    // (512^3: 198.8 -> 196-197 ms, bunny.pc 512^3: 106.0 -> 104-105 ms without it; 128^3: 6.2 -> 7.7 ms, hence the switch).  Decided per solve in build_constraints().
+    int setup_prio = 1;
     double conv_est_total_ms = 1e30;   // estimate of this rank's last Step-1 launch (1e30: none was launched -- stand-alone set-up, test entry points)
     int gs_n = 0;   // grid the Green's table in gs_T was built for (0: none)
     double gs_cell = 0.;
@@ -1096,6 +1100,8 @@ struct Solver final : SolverBase {
     void build_constraints() {
         hipStream_t stream = stream2;  // everything below runs beside the Step-1 kernel of the main stream
         const auto th0 = std::chrono::steady_clock::now();
+        static const int prio_env = getenv("SHM_SETUP_PRIO") ? atoi(getenv("SHM_SETUP_PRIO")) : -1;   // A/B knob: 0 / 1
+        setup_prio = prio_env >= 0 ? prio_env : (conv_tiered && conv_est_total_ms >= 150. && conv_est_total_ms < 1e29 ? 0 : 1);   // (estimate: 256^3 bunny 40, 512^3 320 / 160 ms)
         auto lap = [&](const char* what) { log("[shm]   setup %-28s %.2f ms", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count()); };
         build_rows();
         lap("rows");
@@ -1555,16 +1561,16 @@ struct Solver final : SolverBase {
         static const int pivot_env = getenv("SHM_GJ_PIVOT_E") ? atoi(getenv("SHM_GJ_PIVOT_E")) : 0;
         const int pivot_e = pivot_env ? pivot_env : (refined_later ? 16 : 4);   // 16 = block Gauss-Jordan with 4 x 4 pivot blocks (round 3);   // A/B knob: 4 = 256 threads; 2 = 1024 threads (2 % faster on an idle GPU, but four 40-register waves per SIMD do not fit beside Step 1)
         auto launch_pivot = [&](int kb) {
-            if (pivot_e == 16) hipLaunchKernelGGL(gj_pivot_block4_kernel, dim3(1), dim3(256), 0, stream, M, mp, kb, gjP.p, gjFlag.p);
-            else if (pivot_e == 4) hipLaunchKernelGGL(gj_pivot_kernel<4>, dim3(1), dim3(256), 0, stream, M, mp, kb, gjP.p, gjFlag.p);
-            else hipLaunchKernelGGL(gj_pivot_kernel<2>, dim3(1), dim3(1024), 0, stream, M, mp, kb, gjP.p, gjFlag.p);
+            if (pivot_e == 16) hipLaunchKernelGGL(gj_pivot_block4_kernel, dim3(1), dim3(256), 0, stream, M, mp, kb, gjP.p, gjFlag.p, setup_prio);
+            else if (pivot_e == 4) hipLaunchKernelGGL(gj_pivot_kernel<4>, dim3(1), dim3(256), 0, stream, M, mp, kb, gjP.p, gjFlag.p, setup_prio);
+            else hipLaunchKernelGGL(gj_pivot_kernel<2>, dim3(1), dim3(1024), 0, stream, M, mp, kb, gjP.p, gjFlag.p, setup_prio);
         };
         if (outer == 1) {
             for (int kb = 0; kb < nb; kb++) {
                 launch_pivot(kb);
-                hipLaunchKernelGGL(gj_panels_kernel, dim3(nb), dim3(kBlock), 0, stream, M, mp, kb, gjP.p, gjR.p, 0, gjC.p, c_ld, 0);
+                hipLaunchKernelGGL(gj_panels_kernel, dim3(nb), dim3(kBlock), 0, stream, M, mp, kb, gjP.p, gjR.p, 0, gjC.p, c_ld, 0, setup_prio);
                 hipLaunchKernelGGL((gj_update_kernel<GJ_ALL>), dim3((unsigned)((size_t)nb * (nb + 1) / 2)), dim3(kBlock), 0, stream, M, mp, nb, kb, 0, 1,
-                                   gjR.p, 0, gjC.p, c_ld, 0, kGJ);
+                                   gjR.p, 0, gjC.p, c_ld, 0, kGJ, setup_prio);
             }
         } else {
             for (int k0 = 0; k0 < nb; k0 += outer) {
@@ -1572,14 +1578,14 @@ struct Solver final : SolverBase {
                 for (int t = 0; t < nO; t++) {
                     const int kb = k0 + t;
                     launch_pivot(kb);
-                    hipLaunchKernelGGL(gj_panels_kernel, dim3(nb), dim3(kBlock), 0, stream, M, mp, kb, gjP.p, gjR.p, t * kGJ, gjC.p, c_ld, t * kGJ);
+                    hipLaunchKernelGGL(gj_panels_kernel, dim3(nb), dim3(kBlock), 0, stream, M, mp, kb, gjP.p, gjR.p, t * kGJ, gjC.p, c_ld, t * kGJ, setup_prio);
                     hipLaunchKernelGGL((gj_update_kernel<GJ_CROSS>), dim3((unsigned)(nO * nb + nO * k0)), dim3(kBlock), 0, stream, M, mp, nb, kb, k0, nO,
-                                       gjR.p, t * kGJ, gjC.p, c_ld, t * kGJ, kGJ);
+                                       gjR.p, t * kGJ, gjC.p, c_ld, t * kGJ, kGJ, setup_prio);
                 }
                 const size_t nr = (size_t)(nb - nO);
                 if (nr > 0)
                     hipLaunchKernelGGL((gj_update_kernel<GJ_REST>), dim3((unsigned)(nr * (nr + 1) / 2)), dim3(kBlock), 0, stream, M, mp, nb, -1, k0, nO,
-                                       gjR.p, 0, gjC.p, c_ld, 0, nO * kGJ);
+                                       gjR.p, 0, gjC.p, c_ld, 0, nO * kGJ, setup_prio);
             }
         }
         if (nb > 1) hipLaunchKernelGGL(gj_mirror_kernel, dim3((unsigned)((size_t)nb * (nb - 1) / 2)), dim3(kBlock), 0, stream, M, mp);
@@ -1696,9 +1702,9 @@ struct Solver final : SolverBase {
             auto tiles = [](size_t v) { return (unsigned)((v + kGemmT - 1) / kGemmT); };
             auto gemm = [&](unsigned batches, int M, int N, int K, const double* A, int lda, long long sA, const double* B, int ldb, long long sB, double* C, int ldc, long long sC) {
                 if (narrow)
-                    hipLaunchKernelGGL(dgemm_rm_kernel<1>, dim3((unsigned)((N + 31) / 32), tiles((size_t)M), batches), dim3(kBlock), 0, st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC);
+                    hipLaunchKernelGGL(dgemm_rm_kernel<1>, dim3((unsigned)((N + 31) / 32), tiles((size_t)M), batches), dim3(kBlock), 0, st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, setup_prio);
                 else
-                    hipLaunchKernelGGL(dgemm_rm_kernel<4>, dim3(tiles((size_t)N), tiles((size_t)M), batches), dim3(kBlock), 0, st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC);
+                    hipLaunchKernelGGL(dgemm_rm_kernel<4>, dim3(tiles((size_t)N), tiles((size_t)M), batches), dim3(kBlock), 0, st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, setup_prio);
             };
             // W1[(k1,k2)][d3] = sum_k3 W0[(k1,k2)][k3] Ct[k3][d3]
             gemm(1, n * n, P, n, W0.p, n, 0LL, gs_Ct.p, P, 0LL, W1.p, P, 0LL);
@@ -1712,7 +1718,7 @@ struct Solver final : SolverBase {
         }
         HIPCHK(hipMemsetAsync(Sdense.p, 0, (size_t)mp * mp * sizeof(double), st));
         const unsigned mt = (unsigned)((m + 15) / 16);
-        hipLaunchKernelGGL(schur_assemble_kernel, dim3(mt, mt), dim3(kBlock), 0, st, m, mp, n, P, d_rowX.p, d_rowT.p, gs_T.p, Sdense.p);
+        hipLaunchKernelGGL(schur_assemble_kernel, dim3(mt, mt), dim3(kBlock), 0, st, m, mp, n, P, d_rowX.p, d_rowT.p, gs_T.p, Sdense.p, setup_prio);
         HIPCHK(hipGetLastError());
         if (dual_direct) {
             Sinv.alloc((size_t)mp * mp);

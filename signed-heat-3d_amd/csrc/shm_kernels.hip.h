@@ -1146,10 +1146,10 @@ constexpr int kGJ = 64;
 // dependent chain; with one wave per SIMD every one of a step's ~95 fp64 instructions waits out its predecessor's latency, with four a quarter of the
 // instructions per thread and three other waves to issue from meanwhile (round 3: 39 -> see DESIGN.md section 4 per 64 x 64 block).
 template <int E>
-__global__ __launch_bounds__((kGJ / E) * (kGJ / E)) void gj_pivot_kernel(double* __restrict__ G, int ld, int kb, double* __restrict__ Pout, int* __restrict__ flag) {
+__global__ __launch_bounds__((kGJ / E) * (kGJ / E)) void gj_pivot_kernel(double* __restrict__ G, int ld, int kb, double* __restrict__ Pout, int* __restrict__ flag, int prio) {
     constexpr int kT = kGJ / E;   // threads per dimension
     __shared__ double rowk[2][kGJ], colk[2][kGJ];
-    __builtin_amdgcn_s_setprio(3);   // (see gj_panels_kernel)
+    if (prio) __builtin_amdgcn_s_setprio(3);   // (see gj_panels_kernel)
     const int ty = threadIdx.x / kT, tx = threadIdx.x % kT;
     const size_t o = (size_t)kb * kGJ;
     double r[E][E];
@@ -1217,9 +1217,9 @@ __global__ __launch_bounds__((kGJ / E) * (kGJ / E)) void gj_pivot_kernel(double*
 //   (q, q):     Rb = I                                      -> Binv
 // The scalar version's 64 steps each pay a barrier, an LDS round trip and a reciprocal chain (0.6 us per step: 39 us per pivot block, the longest
 // link of the three-launch chain per pivot block that the constraint set-up waits for at <= 128^3).
-__global__ __launch_bounds__(256) void gj_pivot_block4_kernel(double* __restrict__ G, int ld, int kb, double* __restrict__ Pout, int* __restrict__ flag) {
+__global__ __launch_bounds__(256) void gj_pivot_block4_kernel(double* __restrict__ G, int ld, int kb, double* __restrict__ Pout, int* __restrict__ flag, int prio) {
     __shared__ double rowb[2][16][16], colb[2][16][16], binv[2][16];
-    __builtin_amdgcn_s_setprio(3);   // (see gj_panels_kernel)
+    if (prio) __builtin_amdgcn_s_setprio(3);   // (see gj_panels_kernel)
     const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
     const size_t o = (size_t)kb * kGJ;
     double r[4][4];
@@ -1345,14 +1345,14 @@ __global__ __launch_bounds__(256) void gj_pivot_block4_kernel(double* __restrict
 typedef double gj_f64x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(kBlock) void gj_panels_kernel(const double* __restrict__ G, int ld, int kb, const double* __restrict__ P,
                                                            double* __restrict__ R /* [..][ld]: rows r_row0 .. r_row0+63 */, int r_row0,
-                                                           double* __restrict__ C /* [ld][c_ld]: columns c_col0 .. c_col0+63 */, int c_ld, int c_col0) {
+                                                           double* __restrict__ C /* [ld][c_ld]: columns c_col0 .. c_col0+63 */, int c_ld, int c_col0, int prio) {
     // X alone in LDS (33 KB; with P staged as well the kernel needed 65 KB and could not be placed on a CU beside two workgroups of the tiered Step-1
     // kernel).  The 64 x 64 x 64 product P X (or P X^T) runs on the matrix cores (round 3; the scalar LDS version took 23-32 us per launch, three quarters of
     // it waiting on LDS): one 32 x 32 quadrant per wave as 2 x 2 v_mfma_f64_16x16x4_f64 tiles; the A operand (P: the same 32 KB for every workgroup of
     // the launch, L2-resident) goes from global memory straight into the lanes that feed it.
     // Operand layout (one f64 per lane): A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15], D: col = lane & 15, row = (lane >> 4) + 4 reg.
     __shared__ double x[kGJ][kGJ + 1];
-    __builtin_amdgcn_s_setprio(3);   // set-up kernels share their SIMDs with Step-1 waves: they are short and on the critical path
+    if (prio) __builtin_amdgcn_s_setprio(3);   // (prio: set by the host where Step 1 leaves the set-up little slack -- Solver::setup_prio) set-up kernels share their SIMDs with Step-1 waves: they are short and on the critical path
     const int b = blockIdx.x;
     const size_t o = (size_t)kb * kGJ, ob = (size_t)b * kGJ;
     const bool below = b >= kb;
@@ -1427,10 +1427,10 @@ __device__ __forceinline__ void gj_tri_decode(unsigned t, int& bi, int& bj) {   
 template <int TILES>
 __global__ __launch_bounds__(kBlock) void gj_update_kernel(double* __restrict__ G, int ld, int nb, int kb /* inner pivot block; unused for GJ_REST */,
                                                            int k0, int nO, const double* __restrict__ R /* [..][ld] */, int r_row0,
-                                                           const double* __restrict__ C /* [ld][c_ld] */, int c_ld, int c_col0, int K) {
+                                                           const double* __restrict__ C /* [ld][c_ld] */, int c_ld, int c_col0, int K, int prio) {
     __shared__ double cs[kGJ][kGJK + 1];  // C chunk  [i][k]
     __shared__ double rs[kGJK][kGJ + 1];  // R chunk  [k][j]
-    __builtin_amdgcn_s_setprio(3);   // (see gj_panels_kernel)
+    if (prio) __builtin_amdgcn_s_setprio(3);   // (see gj_panels_kernel)
     int bi, bj;
     if (TILES == GJ_ALL) {
         gj_tri_decode(blockIdx.x, bi, bj);

@@ -55,9 +55,9 @@ __global__ __launch_bounds__(kBlock) void cosine_tables_kernel(int n, int P, con
 constexpr int kGemmT = 128, kGemmK = 16;
 template <int WN>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WN == 4 ? 2 : WN == 2 ? 3 : 4, WN == 4 ? 2 : WN == 2 ? 3 : 4))) void dgemm_rm_kernel(int M, int N, int K, const double* __restrict__ A, int lda, long long sA, const double* __restrict__ B, int ldb,
-                                                          long long sB, double* __restrict__ C, int ldc, long long sC) {
+                                                          long long sB, double* __restrict__ C, int ldc, long long sC, int prio) {
     constexpr int kTN = 32 * WN;                // columns of the workgroup tile
-    __builtin_amdgcn_s_setprio(3);              // (see gj_panels_kernel)
+    if (prio) __builtin_amdgcn_s_setprio(3);              // (see gj_panels_kernel)
     __shared__ double as[kGemmT][kGemmK + 1];   // A chunk [i][k]
     __shared__ double bs[kGemmK][kTN + 1];      // B chunk [k][j]
     A += (long long)blockIdx.z * sA;
@@ -134,9 +134,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WN == 4 
 // tiles below the diagonal are left to their mirror images.
 __device__ __forceinline__ int schur_fold(int e, int n) { return e <= n ? e : 2 * n - e; }
 __global__ __launch_bounds__(kBlock) void schur_assemble_kernel(int m, int ld, int n, int P, const int* __restrict__ rowX /* [m][4]: cell i, j, k and the row index, in Morton order of the cells */,
-                                                                const double* __restrict__ rowT /* [m][3] */, const double* __restrict__ T, double* __restrict__ S) {
+                                                                const double* __restrict__ rowT /* [m][3] */, const double* __restrict__ T, double* __restrict__ S, int prio) {
     if (blockIdx.x < blockIdx.y) return;
-    __builtin_amdgcn_s_setprio(3);   // runs on the SIMDs Step 1 occupies (see gj_panels_kernel)
+    if (prio) __builtin_amdgcn_s_setprio(3);   // runs on the SIMDs Step 1 occupies (see gj_panels_kernel)
     const int i = blockIdx.y * 16 + (threadIdx.x >> 4), j = blockIdx.x * 16 + (threadIdx.x & 15);
     if (i >= m || j >= m || j < i) return;   // (diagonal tiles: the upper entry writes its mirror image too, so S is exactly symmetric)
     int D[3], E[3];
