@@ -115,13 +115,14 @@ def cpu_baseline(pre, iters_cpu, tol, seconds_budget=25.0, threads=1):
     }
 
 
-def step1_roofline(avg, nominal_pairs, precision):
+def step1_roofline(avg, nominal_pairs, precision, tiered=None):
     """Step 1+2 against the vector-ALU roofline, from the pairs the kernel evaluated (per rank)."""
     p64, p32 = float(avg.get("pairs_fp64", 0.0)), float(avg.get("pairs_fp32", 0.0))
     t = avg["ms_conv"] * 1e-3
     ev = p64 + p32
     t_at_peak = 18.0 * p64 / 78.6e12 + 18.0 * p32 / 157.3e12
-    tiered = precision == 64 and not os.environ.get("SHM_CONV_EXACT")
+    if tiered is None:
+        tiered = precision == 64 and not os.environ.get("SHM_CONV_EXACT")
     return {"kernel": "conv_tiered_kernel" if tiered else "conv_normalize_kernel", "bound": "valu",
             "pairs_nominal": nominal_pairs, "pairs_fp64": p64, "pairs_fp32": p32,
             "pairs_evaluated_over_nominal": ev / nominal_pairs if nominal_pairs else None,
@@ -172,46 +173,78 @@ def kernel_table(avg, n_local, T, world, gathered):
     return kernels, kinfo
 
 
-def also_legs(shm, HostSolver, device, tol):
-    """Extra N=1 legs so that the driver's line carries the whole BASELINE.json metric ("256^3 & 512^3") and the north star's
-    "stencil-PCG at 512^3" as driver-observed numbers: (1) the 512^3 end-to-end solve (default dual solver), (2) the primal stencil-PCG at
-    512^3 in fp64 and fp32 for a fixed iteration count with per-kernel achieved GB/s, (3) configs[2] (rocker 512^3 fp32) with the L_inf of
-    its fp32 phi against an fp64 run of the same configuration ("fp32 configs: report only")."""
+def stencil_pcg_leg(shm, pre, precision, device, label, iters=200):
+    """The north star's stencil-PCG at a fixed iteration count: the primal projected stencil CG (fused sweeps, 8NT per iteration) with the constraint projector
+    of THIS source set in the loop -- dense (A A^T)^-1 for m <= 6144 (bunny), two-level (boxes + separator) above (rocker at 512^3: m = 12 612)."""
+    n = pre["n"]
+    N = n ** 3
+    T = precision // 8
+    s = shm.GridSolver(device=device, precision=precision)
+    s.set_problem(pre["pos"], pre["wnormal"], pre["area"], pre["lam"], n, pre["bbox_min"], pre["cell"])
+    s.solve(tol=1e-30, solver="primal", precond="none", max_iters=16, allow_noconv=True)
+    st = s.solve(tol=1e-30, solver="primal", precond="none", max_iters=iters, allow_noconv=True).as_dict()
+    s.close()
+    _, kinfo = kernel_table(st, N, T, 1, False)
+    per_iter = st["ms_pcg"] / max(1.0, st["iters"])
+    return {
+        "workload": "%s 512^3, primal projected stencil CG, %d iterations (fixed count: kernel rates, not a converged solve)" % (label, iters),
+        "dtype": "f%d" % precision, "iters": int(st["iters"]), "constraint_rows": int(st["m"]),
+        "projector": "dense (A A^T)^-1" if int(st["m"]) <= 6144 else "two-level (A A^T)^-1 (boxes + separator)",
+        "ms_per_iter": per_iter, "algorithmic_bytes_per_iter": st["bytes_per_iter"],
+        "loop_achieved_GBps": st["bytes_per_iter"] / (per_iter * 1e-3) / 1e9, "loop_frac_of_hbm_peak": st["bytes_per_iter"] / (per_iter * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "ms_project_avg": st["ms_project_avg"], "kernels": kinfo,
+        "note": "N-sized launches per iteration: DIR (3NT) + RES (3NT) + x_update2 (4NT every other iteration) = 8NT; the loop figure also contains "
+                "the m-sized projection (gather, (A A^T)^-1 mat-vec, scatter: ms_project_avg) and the scalar reductions"}
+
+
+def also_legs(shm, HostSolver, device, tol, pre256, scrub256):
+    """Extra N=1 legs so that the driver's line carries the whole BASELINE.json metric ("256^3 & 512^3") and the north star's "stencil-PCG at 512^3" as
+    driver-observed numbers: (0) the headline workload with Step 1 entirely in fp64 (shm_opts.step1_arith = EXACT_F64: the reference's arithmetic), (1) the
+    512^3 end-to-end solve (default dual solver), (2) the primal stencil-PCG at 512^3 in fp64 and fp32 for a fixed iteration count with per-kernel achieved
+    GB/s -- on bunny_small.obj AND on rocker.obj, BASELINE.json configs[2]'s "HBM-roofline run", whose 12 612 constraint rows put the two-level
+    (A A^T)^-1 into every projection -- (3) configs[2] (rocker 512^3 fp32) end to end with the L_inf of its fp32 phi against an fp64 run of the same
+    configuration ("fp32 configs: report only")."""
     out = {}
+    # (0) all-fp64 Step 1 on the headline workload
+    s = shm.GridSolver(device=device, precision=64)
+    s.set_problem(pre256["pos"], pre256["wnormal"], pre256["area"], pre256["lam"], pre256["n"], pre256["bbox_min"], pre256["cell"])
+    s.solve(tol=tol, scrub=scrub256, step1="exact_f64")
+    reps = 5
+    t0 = time.perf_counter()
+    sts = [s.solve(tol=tol, scrub=scrub256, step1="exact_f64").as_dict() for _ in range(reps)]
+    dt = (time.perf_counter() - t0) / reps
+    s.close()
+    a = {k: float(np.mean([x[k] for x in sts])) for k in sts[0]}
+    N256 = pre256["n"] ** 3
+    out["exact_fp64"] = {
+        "workload": "the headline workload (bunny_small.obj 256^3 fp64) with shm_opts.step1_arith = SHM_STEP1_EXACT_F64: every (node, source) pair of Step 1 in fp64 "
+                    "like the reference (signed_heat_3d.cpp:45-49); %d timed solves" % reps,
+        "value": N256 / dt, "unit": "grid-nodes/s", "ms_per_step": 1e3 * dt, "dtype": "f64",
+        "phases_ms": {k: a[k] for k in ("ms_conv", "ms_div", "ms_wait_setup", "ms_pcg", "ms_shift", "ms_total")},
+        "step1": step1_roofline(a, float(N256) * float(pre256["S"]), 64, tiered=False)}
     pre = HostSolver(os.path.join(ROOT, "data/bunny_small.obj")).preprocess(hCoef=5.0)
     n = pre["n"]
     N = n ** 3
+    s = shm.GridSolver(device=device, precision=64)
+    s.set_problem(pre["pos"], pre["wnormal"], pre["area"], pre["lam"], n, pre["bbox_min"], pre["cell"])
+    s.solve(tol=tol)
+    t0 = time.perf_counter()
+    reps = 3
+    sts = [s.solve(tol=tol).as_dict() for _ in range(reps)]
+    dt = (time.perf_counter() - t0) / reps
+    s.close()
+    a = {k: float(np.mean([x[k] for x in sts])) for k in sts[0]}
+    _, kinfo = kernel_table(a, N, 8, 1, False)
+    out["bunny_small_512_f64_end_to_end"] = {
+        "value": N / dt, "unit": "grid-nodes/s", "ms_per_step": 1e3 * dt, "solver": "dual (library default)", "cg_iters": int(a["iters"]),
+        "phases_ms": {k: a[k] for k in ("ms_conv", "ms_div", "ms_wait_setup", "ms_pcg", "ms_shift", "ms_total")},
+        "ms_per_iter": a["ms_pcg"] / max(1.0, a["iters"]), "kernels": kinfo}
+    pre_r = HostSolver(os.path.join(ROOT, "data/rocker.obj")).preprocess(hCoef=5.0)
     for precision, name in ((64, "f64"), (32, "f32")):
-        T = precision // 8
-        s = shm.GridSolver(device=device, precision=precision)
-        s.set_problem(pre["pos"], pre["wnormal"], pre["area"], pre["lam"], n, pre["bbox_min"], pre["cell"])
-        if precision == 64:
-            s.solve(tol=tol)
-            t0 = time.perf_counter()
-            reps = 3
-            sts = [s.solve(tol=tol).as_dict() for _ in range(reps)]
-            dt = (time.perf_counter() - t0) / reps
-            a = {k: float(np.mean([x[k] for x in sts])) for k in sts[0]}
-            _, kinfo = kernel_table(a, N, T, 1, False)
-            out["bunny_small_512_f64_end_to_end"] = {
-                "value": N / dt, "unit": "grid-nodes/s", "ms_per_step": 1e3 * dt, "solver": "dual (library default)", "cg_iters": int(a["iters"]),
-                "phases_ms": {k: a[k] for k in ("ms_conv", "ms_div", "ms_wait_setup", "ms_pcg", "ms_shift", "ms_total")},
-                "ms_per_iter": a["ms_pcg"] / max(1.0, a["iters"]), "kernels": kinfo}
-        iters = 200
-        s.solve(tol=1e-30, solver="primal", precond="none", max_iters=16, allow_noconv=True)
-        st = s.solve(tol=1e-30, solver="primal", precond="none", max_iters=iters, allow_noconv=True).as_dict()
-        _, kinfo = kernel_table(st, N, T, 1, False)
-        per_iter = st["ms_pcg"] / max(1.0, st["iters"])
-        out["stencil_pcg_512_" + name] = {
-            "workload": "bunny_small.obj 512^3, primal projected stencil CG, %d iterations (fixed count: kernel rates, not a converged solve)" % iters,
-            "dtype": name, "iters": int(st["iters"]), "ms_per_iter": per_iter, "algorithmic_bytes_per_iter": st["bytes_per_iter"],
-            "loop_achieved_GBps": st["bytes_per_iter"] / (per_iter * 1e-3) / 1e9, "loop_frac_of_hbm_peak": st["bytes_per_iter"] / (per_iter * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "ms_project_avg": st["ms_project_avg"], "kernels": kinfo,
-            "note": "N-sized launches per iteration: DIR (3NT) + RES (3NT) + x_update2 (4NT every other iteration) = 8NT; the loop figure also contains "
-                    "the m-sized projection (gather, (A A^T)^-1 mat-vec, scatter) and the scalar reductions"}
-        s.close()
+        out["stencil_pcg_512_" + name] = stencil_pcg_leg(shm, pre, precision, device, "bunny_small.obj")
+        out["stencil_pcg_512_" + name + "_rocker"] = stencil_pcg_leg(shm, pre_r, precision, device, "rocker.obj (BASELINE.json configs[2])")
     # configs[2]: rocker.obj 512^3 fp32, and the same configuration in fp64 for the error of the fp32 path
-    pre = HostSolver(os.path.join(ROOT, "data/rocker.obj")).preprocess(hCoef=5.0)
+    pre = pre_r
     n = pre["n"]
     phis = {}
     for precision in (32, 64):
@@ -233,6 +266,48 @@ def also_legs(shm, HostSolver, device, tol):
     return out
 
 
+def multi_gpu_legs(shm, dist, torch, args, pre, precision, scrub, rank, world, local_rank, barrier):
+    """N > 1 only.  The timed default above is the gathered dual solve (Steps 1-2 on z-slabs, D^T Y gathered, whole-grid solve replicated).  The split the
+    north star names -- z-slab stencil PCG with a one-plane halo exchange per sweep and an all-reduce per dot product -- is SHM_SOLVER_PRIMAL; it is
+    run here as further legs on the SAME ranks so that whichever multi-GPU run the driver gets covers both: the DCT-preconditioned stencil PCG to the
+    tolerance (z-slab transforms: two all-to-alls per application) and the plain stencil CG for a fixed 200 iterations (halo + two all-reduces per
+    iteration, nothing else).  Collective: every rank calls this with the same arguments."""
+    box = [shm.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    s = shm.GridSolver(device=local_rank, precision=precision, rank=rank, world=world, rccl_unique_id=box[0], slab_plan=0)   # equal planes: what the z-slab transforms need
+    n = pre["n"]
+    N = n ** 3
+    s.set_problem(pre["pos"], pre["wnormal"], pre["area"], pre["lam"], n, pre["bbox_min"], pre["cell"])
+    out = {}
+    legs = [("primal_pcg", dict(solver="primal", precond="auto", tol=args.tol), max(1, min(3, args.steps))),
+            ("primal_plain_cg_200", dict(solver="primal", precond="none", tol=1e-30, max_iters=200, allow_noconv=True), 1)]
+    for name, kw, reps in legs:
+        try:
+            s.solve(scrub=scrub, **kw)
+            barrier()
+            t0 = time.perf_counter()
+            sts = [s.solve(scrub=scrub, **kw).as_dict() for _ in range(reps)]
+            barrier()
+            dt = time.perf_counter() - t0
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item()) / reps
+            a = {k: float(np.mean([x[k] for x in sts])) for k in sts[0]}
+            _, kinfo = kernel_table(a, N / world, precision // 8, world, False)
+            per_iter = a["ms_pcg"] / max(1.0, a["iters"])
+            out[name] = {"value": N / dt, "unit": "grid-nodes/s", "ms_per_step": 1e3 * dt, "steps": reps, "cg_iters": int(a["iters"]), "rel_residual": a["rel_residual"],
+                         "preconditioner": "dct (z-slab transforms, two all-to-alls per application)" if int(a["preconditioner"]) == 2 else "none",
+                         "per_iteration": "one-plane halo of the direction to each slab neighbour before the DIR sweep, all-reduce of p.Kp, all-reduce of [||r||^2, A r]",
+                         "phases_ms": {k: a[k] for k in ("ms_conv", "ms_div", "ms_wait_setup", "ms_pcg", "ms_shift", "ms_total")},
+                         "ms_per_iter": per_iter, "algorithmic_bytes_per_iter_per_rank": a["bytes_per_iter"] / world,
+                         "loop_frac_of_hbm_peak_per_rank": a["bytes_per_iter"] / world / (per_iter * 1e-3) / 1e9 / HBM_PEAK_GBS if per_iter > 0 else None,
+                         "kernels": kinfo}
+        except Exception as e:   # never lose the headline over an extra leg (every rank fails alike: the library's checks are rank-independent)
+            out[name] = {"failed": repr(e)}
+    s.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,7 +316,8 @@ def main():
     ap.add_argument("--workload", default="bunny_small_256_f64", choices=sorted(WORKLOADS))
     ap.add_argument("--tol", type=float, default=0.0, help="projected-CG relative residual tolerance (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the extra N=1 legs (512^3 end-to-end, 512^3 stencil-PCG fp64/fp32, rocker 512^3 fp32 vs fp64)")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra legs (N=1: all-fp64 Step 1, 512^3 end-to-end, 512^3 stencil-PCG fp64/fp32 on bunny and rocker, "
+                                                            "rocker 512^3 fp32 vs fp64; N>1: the z-slab stencil-PCG legs)")
     ap.add_argument("--max-iters", type=int, default=0, help="cap the CG iterations (0 = library default 20 n); a capped run reports kernel rates, not a converged solve")
     ap.add_argument("--precond", default="auto", choices=["auto", "none", "dct"])
     ap.add_argument("--solver", default="auto", choices=["auto", "primal", "dual", "dual_slabs"])
@@ -289,7 +365,10 @@ def main():
     pre = host.preprocess(hCoef=hCoef)                    # centroid/radius/h/areas/barycenters on the host (cheap)
     n, N = pre["n"], pre["n"] ** 3
 
-    slab_plan = {"equal": 0, "step1": 1, "auto": 1 if (precision == 32 and world > 1) else 0}[args.slab_plan]
+    # auto: the weighted plan serves the default (gathered dual) solve of the culled fp32 workloads; the slab-distributed transforms (dual_slabs, primal + DCT)
+    # need equal slabs, and the plain stencil CG is an explicit request for the north star's split -- those keep equal planes
+    auto_weighted = precision == 32 and world > 1 and args.solver in ("auto", "dual") and args.precond == "auto"
+    slab_plan = {"equal": 0, "step1": 1, "auto": 1 if auto_weighted else 0}[args.slab_plan]
     solver = shm.GridSolver(device=local_rank, precision=precision, rank=rank, world=world, rccl_unique_id=uid, slab_plan=slab_plan)
     solver.set_problem(pre["pos"], pre["wnormal"], pre["area"], pre["lam"], n, pre["bbox_min"], pre["cell"])  # inputs resident in HBM
     scrub = not path.endswith(".pc")
@@ -316,6 +395,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    multi = None
+    if world > 1 and not args.no_also and args.solver == "auto" and args.precond == "auto" and args.max_iters == 0:
+        solver.close()   # (its communicator and whole-grid arrays go first: the legs build their own solver on a fresh communicator)
+        multi = multi_gpu_legs(shm, dist, torch, args, pre, precision, scrub, rank, world, local_rank, barrier)
+
     if rank == 0:
         T = precision // 8
         avg = {k: float(np.mean([s[k] for s in stats])) for k in stats[0]}
@@ -330,7 +414,7 @@ def main():
         traffic = None
         # HBM bytes per launch from the rocprofv3 PMC passes of THIS command (tools/pmc_traffic.py; FETCH_SIZE doubled per the gfx950
         # correction), committed per round; PMC counters cannot be collected from inside the run
-        tfile = next((f for f in (os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"), os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))
+        tfile = next((f for f in (os.path.join(ROOT, "profiles", "r04_pmc_traffic.json"), os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"))
                       if os.path.exists(f)), "")
         if os.path.exists(tfile):
             try:
@@ -340,7 +424,11 @@ def main():
         out = {
             "metric": "grid-nodes/sec end-to-end SHM (conv+PCG)", "value": N * args.steps / elapsed, "unit": "grid-nodes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64" if precision == 64 else "f32",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            # the arithmetic the path computes in.  fp64 handles: everything in fp64 except Step 1's far tier -- (node, source) pairs whose terms are below e^-8 of
+            # their node block's dominant terms are summed in packed fp32 (step1.pairs_fp32; error budget on Y 1e-8, asserted against the C oracle at full
+            # size in tests/); `also.exact_fp64` is the same workload with every pair in fp64
+            "dtype": ("f64 (Step 1: f64 / packed-f32 tiers)" if not os.environ.get("SHM_CONV_EXACT") else "f64") if precision == 64 else "f32",
             "data": "reference data file %s (no RNG; sources + grid resident in HBM before the timed region)" % path,
             "config": {"workload": args.workload, "grid": "%d^3" % n, "sources": int(pre["S"]), "constraint_rows": int(avg["m"]),
                        "tol": args.tol if args.tol > 0 else (1e-8 if precision == 64 else 1e-5), "cg_iters": int(avg["iters"]),
@@ -377,8 +465,8 @@ def main():
         # issue (no GEMM shape, HBM traffic 3 words per node), so its roofline is the fp64/fp32 vector peak at the
         # nominal 18 flop per EVALUATED pair; when the CG loop takes longer than Step 1 the HBM roofline of its dominant kernel is reported
         s1 = out["step1"]
-        conv_traffic = None   # PMC-measured HBM bytes of Step 1 per step (all its launches), profiles/r03_pmc_traffic.json
-        tfile3 = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+        conv_traffic = None   # PMC-measured HBM bytes of Step 1 per step (all its launches), profiles/r0N_pmc_traffic.json (latest round)
+        tfile3 = tfile
         if os.path.exists(tfile3):
             try:
                 conv_traffic = json.load(open(tfile3)).get(args.workload, {}).get("step1_bytes_per_step")
@@ -414,9 +502,11 @@ def main():
         if world == 1 and not args.no_also and args.workload == "bunny_small_256_f64":
             try:
                 solver.close()
-                out["also"] = also_legs(shm, HostSolver, local_rank, args.tol)
+                out["also"] = also_legs(shm, HostSolver, local_rank, args.tol, pre, scrub)
             except Exception as e:  # never lose the headline over an extra leg
                 out["also"] = {"failed": repr(e)}
+        if multi is not None:
+            out["also_multi"] = multi
         print(json.dumps(out))
     if dist.is_initialized():
         dist.barrier()

@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define SHM_GRID_ABI_VERSION 3 /* 2: shm_stats grew by cg_form (round 2); 3: by pairs_fp64 / pairs_fp32 / conv_launches (round 3); callers allocate shm_stats by this header */
+#define SHM_GRID_ABI_VERSION 4 /* 2: shm_stats grew by cg_form (round 2); 3: by pairs_fp64 / pairs_fp32 / conv_launches (round 3); 4: shm_opts grew by step1_arith,
+                                * shm_grid_run_conv_arith and shm_grid_get_field_planes added (round 4); callers allocate shm_opts / shm_stats by this header */
 
 typedef struct shm_solver shm_solver; /* opaque */
 
@@ -94,7 +95,16 @@ typedef struct {
     int32_t check_every;      /* residual is inspected on the host every this many iterations; <=0 -> 32 (4 with the preconditioner) */
     int32_t preconditioner;   /* SHM_PRECOND_AUTO | _NONE | _DCT  (primal solver only) */
     int32_t solver;           /* SHM_SOLVER_AUTO | _PRIMAL | _DUAL | _DUAL_SLABS */
+    int32_t step1_arith;      /* SHM_STEP1_AUTO | SHM_STEP1_EXACT_F64: arithmetic of the Step-1 summation in an SHM_F64 handle (ignored by SHM_F32 handles) */
 } shm_opts;
+
+/* Arithmetic of Step 1 (the N*S direct summation, signed_heat_grid_solver.cpp:48-65 / :157-174; yukawaPotential, signed_heat_3d.cpp:45-49) in an SHM_F64 handle.
+ * AUTO:      error-budgeted precision tiers (csrc/shm_conv_tiered.hip.h): per block of 8 x 8 x 4 nodes, sources whose terms are below e^-8 of the block's
+ *            dominant terms are summed in packed fp32, sources whose terms all together stay below 2e-9 of it are dropped; everything else in fp64.
+ *            max|Y - Y_exact| < 1e-8 (asserted against the C oracle at the full sizes of BASELINE.json), phi inherits < 1e-9.
+ * EXACT_F64: every (node, source) pair in fp64 like the reference (~1.6x the Step-1 time); Y agrees with the serial loops to 1e-11.
+ * The environment variable SHM_CONV_EXACT=1 forces EXACT_F64 whatever the caller asks (A/B runs). */
+enum { SHM_STEP1_AUTO = 0, SHM_STEP1_EXACT_F64 = 1 };
 
 /* How the KKT system of signed_heat_grid_solver.cpp:101-107 is solved.
  * PRIMAL: projected (optionally DCT-preconditioned) CG on the N grid unknowns -- the matrix-free 7-point-stencil PCG.
@@ -181,9 +191,13 @@ typedef enum {
     SHM_FIELD_DIV = 3, /* divYt (:71-74) */
     SHM_FIELD_PHI = 4
 } shm_field;
-shm_status shm_grid_run_conv(shm_solver* s);                       /* Steps 1+2 only */
+shm_status shm_grid_run_conv(shm_solver* s);                       /* Steps 1+2 only (step1_arith = SHM_STEP1_AUTO) */
+shm_status shm_grid_run_conv_arith(shm_solver* s, int32_t step1_arith); /* the same with the arithmetic of shm_opts.step1_arith */
 shm_status shm_grid_run_divergence(shm_solver* s, int32_t scrub);  /* needs run_conv */
 shm_status shm_grid_get_field(shm_solver* s, shm_field f, double* out /* owned planes */);
+/* The same for the z-planes [k_begin, k_end) only (a sub-range of the owned planes): (k_end - k_begin) * n * n doubles.  What the full-size parity tests
+ * read: a few planes of Y at 512^3 / 1024^3 instead of three N-vectors. */
+shm_status shm_grid_get_field_planes(shm_solver* s, shm_field f, int32_t k_begin, int32_t k_end, double* out);
 /* out = L*u with the reference's Laplacian (signed_heat_grid_solver.cpp:278-334); u,out: n^3 doubles
  * on the host (world==1). */
 shm_status shm_grid_apply_laplacian(shm_solver* s, const double* u, double* out);

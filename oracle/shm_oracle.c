@@ -80,6 +80,33 @@ void shmo_conv_normalize(int n_, const double* bbox_min, double cell, int S, con
     }
 }
 
+/* The same loops for the z-planes [k0,k1) only, written to a COMPACT array Yp[3*((k-k0)*n*n + j*n + i) + p]: what the full-size parity tests
+ * compare sampled planes of the GPU's Y against at 512^3 / 1024^3, where a full-size AoS array would be 3-26 GB for two planes of use. */
+void shmo_conv_normalize_planes(int n_, const double* bbox_min, double cell, int S, const double* pos, const double* wn,
+                                double lambda, int k0, int k1, double* Yp) {
+    const size_t n = (size_t)n_;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < n_; i++) {
+        for (int j = 0; j < n_; j++) {
+            for (int k = k0; k < k1; k++) {
+                size_t idx = (size_t)i + (size_t)j * n + (size_t)(k - k0) * n * n;
+                double x0 = i * cell + bbox_min[0], x1 = j * cell + bbox_min[1], x2 = k * cell + bbox_min[2];
+                double a0 = 0., a1 = 0., a2 = 0.;
+                for (int s = 0; s < S; s++) {
+                    double g = yukawa(x0, x1, x2, pos[3 * s], pos[3 * s + 1], pos[3 * s + 2], lambda);
+                    a0 += wn[3 * s] * g;
+                    a1 += wn[3 * s + 1] * g;
+                    a2 += wn[3 * s + 2] * g;
+                }
+                double nrm = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+                Yp[3 * idx] = a0 / nrm;
+                Yp[3 * idx + 1] = a1 / nrm;
+                Yp[3 * idx + 2] = a2 / nrm;
+            }
+        }
+    }
+}
+
 /* divYt = D^T * Y with D from gradient() (signed_heat_grid_solver.cpp:336-402), applied as a literal
  * scatter of the six triplets of every node; scrub = the non-finite -> 0 pass of the mesh overload (:72-74). */
 void shmo_divergence(int n_, double cell, const double* Y, int scrub, double* b) {

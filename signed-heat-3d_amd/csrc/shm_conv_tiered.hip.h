@@ -14,6 +14,9 @@
 // bound of every node's distance to its nearest source -- and w_near the weight of s*: every term of s is then below e^-G of the dominant term
 // of every node of the block.
 // The same lane-parallel test with the skip threshold drops sources whose terms vanish against the budget altogether.
+// Exponent range: the far tier carries ONE offset d0_w per block, and r_hi_w - d0_w <= 2 rt_w (the block's diameter), so a far term that may not yet be
+// dropped reaches down to 2^-(2 lambda' rt_w + log2(S / budget)) of the offset.  Where that leaves the fp32 range (fine meshes over coarse grids, small
+// tCoef: lambda * cell >~ 3) the HOST switches the far tier off for the launch (P.tier_log = 3e38, Solver::launch_conv): everything not dropped is fp64.
 // What the far tier contributes to Y is bounded by eps32 * sum_far |term| / |X|; `tools/tier_budget.py` evaluates that on the host
 // and the GPU tests hold Y to the stated budget against the all-fp64 kernel (SHM_CONV_EXACT=1).
 #pragma once
@@ -284,7 +287,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                 for (int a = 0; a < 6; a++) {
                     const double pv = a < 3 ? P.bbox_min[a] - (double)P.n * P.cell : 0.0;   // the padding entry: >= one grid side from every node, zero weight
                     tile[(nnear + lane) * 6 + a] = pv;
-                    tile32[(nfar + lane) * 6 + a] = (float)pv;
+                    // (the far list holds SCALED positions; an unscaled padding point would land inside the grid, where coff - r' > 0 can overflow exp2f
+                    // and 0 * inf = NaN reaches the sums.  1e18 in every scaled coordinate: d2 = 3e36 is finite, r' = 1.7e18 > coff always, 2^(coff - r') = 0)
+                    tile32[(nfar + lane) * 6 + a] = a < 3 ? 1.0e18f : 0.f;
                 }
             }
             cnt_near += (unsigned)nnear;

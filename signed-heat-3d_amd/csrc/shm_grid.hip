@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -24,6 +25,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -131,39 +133,66 @@ struct Rccl {
 // Host -> device uploads go through pinned staging chunks: hipMemcpyAsync from pageable memory first waits for everything queued on its stream, and the
 // set-up stream's work cannot progress while a Step-1 kernel that fills the SIMDs runs (fp32 and all-fp64 Step 1) -- the host part of the constraint
 // set-up then stalled at its first upload until Step 1 had finished (rocker 512^3 fp32: 40 ms of exposed wait, 13 of them host work that had not started;
-// round 3).  A chunk is reused once the event recorded behind its copy has completed; the pool never shrinks (hundreds of MB for the 1024^3 set-up) and
-// falls back to the plain copy beyond kMaxBytes or when pinned memory cannot be had.
+// round 3).  A chunk is reused once the event recorded behind its copy has completed.  Chunks and their events belong to ONE device (an event must be
+// recorded on a stream of its own device): the pool is keyed by the device that is current at the upload, and a device's chunks are freed when the last
+// solver on it is destroyed (Solver's constructor / destructor hold the reference).  Beyond kMaxBytes per device, or when pinned memory cannot be had,
+// the plain copy is used.
 struct PinnedPool {
     struct Chunk {
         void* p;
         size_t cap;
         hipEvent_t ev;
         bool busy;
+        int device;
     };
-    static constexpr size_t kMaxBytes = (size_t)4 << 30;
+    static constexpr size_t kMaxBytes = (size_t)2 << 30;
     std::vector<Chunk> chunks;
-    size_t total = 0;
+    std::unordered_map<int, size_t> total;   // bytes pinned per device
+    std::unordered_map<int, int> users;      // solvers alive per device
     std::mutex mu;
     static PinnedPool& get() {
         static PinnedPool* P = new PinnedPool();   // (never destroyed: no HIP calls at process exit)
         return *P;
     }
+    void acquire(int device) {
+        std::lock_guard<std::mutex> lk(mu);
+        users[device]++;
+    }
+    // the caller has made `device` current
+    void release(int device) noexcept {
+        std::lock_guard<std::mutex> lk(mu);
+        if (--users[device] > 0) return;
+        size_t keep = 0;
+        for (Chunk& k : chunks) {
+            if (k.device != device) {
+                chunks[keep++] = k;
+                continue;
+            }
+            if (k.busy) (void)hipEventSynchronize(k.ev);
+            (void)hipEventDestroy(k.ev);
+            (void)hipHostFree(k.p);
+        }
+        chunks.resize(keep);
+        total[device] = 0;
+    }
     void upload(void* dst, const void* src, size_t bytes, hipStream_t st) {
+        int device = 0;
+        HIPCHK(hipGetDevice(&device));   // the stream's device: every caller runs under its solver's hipSetDevice
         std::lock_guard<std::mutex> lk(mu);
         Chunk* c = nullptr;
         for (Chunk& k : chunks) {
-            if (k.cap < bytes) continue;
+            if (k.device != device || k.cap < bytes) continue;
             if (k.busy) {
                 if (hipEventQuery(k.ev) == hipSuccess) k.busy = false;
                 else (void)hipGetLastError();   // hipErrorNotReady is not an error here
             }
             if (!k.busy && (!c || k.cap < c->cap)) c = &k;
         }
-        if (!c && total + bytes <= kMaxBytes) {
-            Chunk k{nullptr, std::max(bytes + bytes / 4, (size_t)1 << 20), nullptr, false};
-            if (hipHostMalloc(&k.p, k.cap, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&k.ev, hipEventDisableTiming) == hipSuccess) {
+        if (!c && users[device] > 0 && total[device] + bytes <= kMaxBytes) {
+            Chunk k{nullptr, std::max(bytes + bytes / 4, (size_t)1 << 20), nullptr, false, device};
+            if (hipHostMalloc(&k.p, k.cap, hipHostMallocPortable) == hipSuccess && hipEventCreateWithFlags(&k.ev, hipEventDisableTiming) == hipSuccess) {
                 chunks.push_back(k);
-                total += k.cap;
+                total[device] += k.cap;
                 c = &chunks.back();
             } else {
                 (void)hipGetLastError();
@@ -296,8 +325,9 @@ static void step1_plane_weights_host(int64_t S, const double* pos, const double*
     }
     const int tiles = (n + 7) / 8, layers = (n + bz - 1) / bz;
     const int K = std::min(tiles, 12);   // sampled blocks per axis and layer
-    std::vector<double> dist((size_t)S);
-    for (int L = 0; L < layers; L++) {
+    // the block layers are independent: spread over host threads (SprayBottle.pc 1024^3 fp64: 4e9 distance evaluations -- seconds on one core, inside
+    // set_problem on every rank)
+    auto do_layer = [&](int L, std::vector<double>& dist) {
         double acc = 0.;
         const double cz = (L * bz + half_z) * cell + bbox_min[2];
         for (int a = 0; a < K; a++)
@@ -322,7 +352,9 @@ static void step1_plane_weights_host(int64_t S, const double* pos, const double*
                         if (!(wmag[(size_t)s] > 0.)) continue;
                         const double lhs = lambda * (dist[(size_t)s] - rt - r_hi), rel = std::log(wmag[(size_t)s]) - ln_near;
                         if (lhs > skip_base + rel) continue;
-                        cost += lhs > tier_log + rel ? far_cost : 1.0;
+                        // (the exponent-range guard of the packed-fp32 tier, in bits: Solver::launch_conv)
+                        const bool far_ok = 1.4426950408889634 * (lambda * 2.0 * rt + std::min(skip_base, 44.36)) <= 90.;
+                        cost += lhs > tier_log + rel && far_ok ? far_cost : 1.0;
                     }
                 } else {
                     for (size_t c = 0; c < crad.size(); c++) {
@@ -335,7 +367,18 @@ static void step1_plane_weights_host(int64_t S, const double* pos, const double*
             }
         const double per_plane = acc / ((double)K * K * (double)S) + 1e-3;   // + a floor: the per-block source scan and the stores cost something everywhere
         for (int k = L * bz; k < std::min(n, (L + 1) * bz); k++) weights[k] = per_plane;
-    }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nthr = (int)std::max(1u, std::min({hw ? hw : 1u, 16u, (unsigned)layers, (unsigned)(((double)layers * K * K * (double)S) / 2e6 + 1.)}));
+    std::atomic<int> next{0};
+    auto worker = [&]() {
+        std::vector<double> dist((size_t)S);
+        for (int L = next.fetch_add(1); L < layers; L = next.fetch_add(1)) do_layer(L, dist);
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthr; t++) pool.emplace_back(worker);
+    worker();
+    for (std::thread& t : pool) t.join();
 }
 
 // Contiguous split of n planes into nslabs ranges whose boundaries are multiples of `granule` planes and whose weights are as equal as those boundaries allow
@@ -371,9 +414,10 @@ struct SolverBase {
     virtual void solve(const shm_opts&, shm_stats*) = 0;
     virtual void get_phi(double*, int32_t*, int32_t*) = 0;
     virtual void owned_planes(int32_t*, int32_t*) = 0;
-    virtual void run_conv() = 0;
+    virtual void run_conv(int step1_arith) = 0;
     virtual void run_divergence(int scrub) = 0;
     virtual void get_field(shm_field, double*) = 0;
+    virtual void get_field_planes(shm_field, int, int, double*) = 0;
     virtual void apply_laplacian(const double*, double*) = 0;
     virtual void get_constraints(int64_t*, double*, int32_t*) = 0;
     virtual void apply_projector(double*) = 0;
@@ -420,6 +464,7 @@ struct Solver final : SolverBase {
     size_t N = 0;
     double cell = 0., lambda = 0.;
     double bbox_min[3] = {0, 0, 0};
+    double conv_ctr[3] = {0, 0, 0};   // the grid's centre: origin of the coordinates Step 1 computes in
     int64_t S = 0;
     std::vector<double> h_pos, h_wn, h_area;
     double area_sum = 0., conv_far_gap = 0., conv_skip_base = 3.0e38, last_host_setup_ms = 0., last_setup_wall_ms = 0.;
@@ -501,6 +546,7 @@ struct Solver final : SolverBase {
     // world > 1: the whole-grid solver every rank runs after the right-hand side has been gathered (see solve_gathered)
     std::unique_ptr<Solver<T>> full;
     bool solve_only = false;  // this instance is such a whole-grid solver: it never runs Steps 1-2, so it owns no Y arrays
+    bool pool_held = false;   // this solver holds a reference on its device's pinned staging chunks (PinnedPool)
 
     explicit Solver(const shm_config& c, bool solve_only_ = false) : cfg(c), solve_only(solve_only_) {
         int ndev = 0;
@@ -534,6 +580,8 @@ struct Solver final : SolverBase {
             memcpy(&id, cfg.rccl_unique_id, sizeof id);
             R.chk(R.CommInitRank(&comm, cfg.world, id, cfg.rank), "ncclCommInitRank");
         }
+        PinnedPool::get().acquire(cfg.device);   // last: a constructor that throws runs no destructor
+        pool_held = true;
     }
     ~Solver() override {
         (void)hipSetDevice(cfg.device);
@@ -544,6 +592,7 @@ struct Solver final : SolverBase {
         if (stream2) (void)hipStreamDestroy(stream2);
         if (stream3) (void)hipStreamDestroy(stream3);
         if (stream_h) (void)hipStreamDestroy(stream_h);
+        if (pool_held) PinnedPool::get().release(cfg.device);
     }
 
     void log(const char* f, ...) {
@@ -622,6 +671,10 @@ struct Solver final : SolverBase {
                 order[(size_t)s] = {code, s};
             }
             std::sort(order.begin(), order.end());
+            // Step 1 only ever needs DIFFERENCES node - source.  Its device copies of the sources and its node coordinates are therefore taken relative to the
+            // grid's centre: the fp32 arithmetic (fp32 solve; packed-fp32 tier of the fp64 solve) then rounds coordinates of magnitude <= half the grid's
+            // diagonal instead of |centroid| + that -- a mesh that sits far from the origin loses nothing (tests: test_step1_is_translation_invariant).
+            for (int a = 0; a < 3; a++) conv_ctr[a] = bbox_min[a] + 0.5 * (double)(n - 1) * cell;
             constexpr int kConvCluster = conv_cluster<T>();
             n_clusters = (int)((S + kConvCluster - 1) / kConvCluster);
             const int64_t Spad = (int64_t)n_clusters * kConvCluster;
@@ -631,8 +684,8 @@ struct Solver final : SolverBase {
             for (int64_t t = 0; t < Spad; t++) {
                 const int64_t s = order[(size_t)std::min<int64_t>(t, S - 1)].second;  // padding repeats the last source with zero weight
                 for (int a = 0; a < 3; a++) {
-                    packed[6 * t + a] = (T)h_pos[3 * s + a];
-                    packed32[6 * t + a] = (float)h_pos[3 * s + a];
+                    packed[6 * t + a] = (T)(h_pos[3 * s + a] - conv_ctr[a]);
+                    packed32[6 * t + a] = (float)(h_pos[3 * s + a] - conv_ctr[a]);
                     if (t < S) {
                         packed[6 * t + 3 + a] = (T)h_wn[3 * s + a];
                         packed32[6 * t + 3 + a] = (float)h_wn[3 * s + a];
@@ -698,7 +751,7 @@ struct Solver final : SolverBase {
                 conv_tier_log = tl ? atof(tl) : 8.0;
                 const char* db = getenv("SHM_CONV_DROP_BUDGET");
                 conv_tier_skip_base = sk ? 3.0e38 : std::log((double)S / (db ? atof(db) : 2e-9));
-                conv_tiered = sizeof(T) == 8 && getenv("SHM_CONV_EXACT") == nullptr;
+                select_step1_arith(SHM_STEP1_AUTO);
             }
             d_src.upload(packed, stream);
             d_src32.upload(packed32, stream);
@@ -815,6 +868,11 @@ struct Solver final : SolverBase {
         log("[shm] problem set: n=%d N=%zu S=%lld slabs=%d(local %d) vec=%d", n, N, (long long)S, total_slabs, cfg.local_slabs, vec);
     }
 
+    // shm_opts.step1_arith: the tiered kernel unless the caller (or SHM_CONV_EXACT=1, read per call: tests flip it inside one process) asks for the reference's arithmetic
+    void select_step1_arith(int arith) {
+        if (arith != SHM_STEP1_AUTO && arith != SHM_STEP1_EXACT_F64) throw Error(SHM_ERR_INVALID, "unknown step1_arith");
+        conv_tiered = sizeof(T) == 8 && arith == SHM_STEP1_AUTO && getenv("SHM_CONV_EXACT") == nullptr;
+    }
     void need_problem() const {
         if (!have_problem) throw Error(SHM_ERR_STATE, "shm_grid_set_problem has not been called");
     }
@@ -835,7 +893,7 @@ struct Solver final : SolverBase {
             P.kk_begin = 1;  // owned planes only: the ghost planes of Y are exchanged (exchange_Y_halos), not recomputed -- a ghost plane
             P.kk_end = sl.nzl + 1;  // would cost a whole 16-plane tile layer of Step 1 (41 % extra on 8 GPUs at 256^3)
             P.k0 = sl.k0;
-            for (int a = 0; a < 3; a++) P.bbox_min[a] = bbox_min[a];
+            for (int a = 0; a < 3; a++) P.bbox_min[a] = bbox_min[a] - conv_ctr[a];   // Step 1 works in grid-centred coordinates (see set_problem)
             P.cell = cell;
             P.lambda = lambda;
             P.cexp = -lambda * 2954.639443740597;  // 2048 / ln 2
@@ -843,6 +901,11 @@ struct Solver final : SolverBase {
             P.n_clusters = n_clusters;
             P.far_gap = (float)conv_far_gap;
             P.tier_log = (float)conv_tier_log;
+            {   // exponent range of the packed-fp32 tier (one offset per 8 x 8 x 4 block; see shm_conv_tiered.hip.h): the spread of the nodes' dominant terms over a
+                // block (<= its diameter) plus the drop threshold must fit the fp32 exponent with 36 bits to spare for weight ratios, or the launch has no far tier
+                const double diam = 2.0 * std::sqrt(3.5 * 3.5 * 2 + 1.5 * 1.5) * cell;
+                if (1.4426950408889634 * (lambda * diam + std::min(conv_tier_skip_base, 44.36)) > 90.) P.tier_log = 3.0e38f;
+            }
             P.skip_base = (float)std::min(conv_tiered ? conv_tier_skip_base : conv_skip_base, 3.0e38);
             P.inv_lambda = (float)(1.0 / lambda);
             P.tiles_x = (n + kConvTile - 1) / kConvTile;
@@ -991,9 +1054,10 @@ struct Solver final : SolverBase {
         have_div = true;
     }
 
-    void run_conv() override {
+    void run_conv(int step1_arith) override {
         need_problem();
         HIPCHK(hipSetDevice(cfg.device));
+        select_step1_arith(step1_arith);
         launch_conv();
         HIPCHK(hipStreamSynchronize(stream));
     }
@@ -2762,7 +2826,7 @@ struct Solver final : SolverBase {
         shm_opts o = o_in;
         bool pre = false;
         if (o.preconditioner == SHM_PRECOND_DCT) {
-            if (!precond_available()) throw Error(SHM_ERR_INVALID, "DCT preconditioner needs n = 2^k in [16,1024] and a power-of-two number of z-slabs dividing n");
+            if (!precond_available()) throw Error(SHM_ERR_INVALID, "DCT preconditioner needs n = 2^k in [16,1024] and a power-of-two number of EQUAL z-slabs dividing n (shm_config.slab_plan = SHM_SLAB_PLAN_EQUAL)");
             pre = true;
         } else if (o.preconditioner == SHM_PRECOND_AUTO) {
             pre = precond_available();
@@ -2775,6 +2839,7 @@ struct Solver final : SolverBase {
 
         Event e_start, e_conv, e_div, e_setup, e_pcg, e_end, e_s2a, e_s2b;
         const auto wall0 = std::chrono::steady_clock::now();
+        select_step1_arith(o.step1_arith);
         e_start.record(stream);
         o_fast_hint = o.fast_integration != 0;
         launch_conv();
@@ -2798,7 +2863,7 @@ struct Solver final : SolverBase {
         e_s2b.record(stream2);
         bool dual = false;
         if (o.solver == SHM_SOLVER_DUAL || o.solver == SHM_SOLVER_DUAL_SLABS) {
-            if (!precond_available()) throw Error(SHM_ERR_INVALID, "the dual solver needs the DCT: n = 2^k in [16,1024] and a power-of-two number of z-slabs dividing n");
+            if (!precond_available()) throw Error(SHM_ERR_INVALID, "the dual solver needs the DCT: n = 2^k in [16,1024] and a power-of-two number of EQUAL z-slabs dividing n (shm_config.slab_plan = SHM_SLAB_PLAN_EQUAL)");
             dual = true;
         } else if (o.solver == SHM_SOLVER_AUTO) {
             dual = precond_available() && o.preconditioner != SHM_PRECOND_NONE;
@@ -2941,6 +3006,35 @@ struct Solver final : SolverBase {
     }
 
     // ------------------------------------------------------------------------------------------
+    // global planes [ka, kb) of a field, clipped to what this process owns, packed in ascending plane order
+    void copy_planes_to_host(int which, int ka, int kb, double* out) {
+        size_t off = 0;
+        for (Slab<T>& sl : slabs) {
+            const int a = std::max(ka, sl.k0), b = std::min(kb, sl.k1);
+            if (b <= a) continue;
+            const T* srcp = nullptr;
+            switch (which) {
+                case SHM_FIELD_Y0: srcp = sl.Y0.p; break;
+                case SHM_FIELD_Y1: srcp = sl.Y1.p; break;
+                case SHM_FIELD_Y2: srcp = sl.Y2.p; break;
+                case SHM_FIELD_DIV: srcp = sl.r.p; break;
+                default: srcp = sl.q.p; break;
+            }
+            srcp += sl.plane * (size_t)(a - sl.k0 + 1);
+            const size_t cnt = sl.plane * (size_t)(b - a);
+            if (sizeof(T) == 8) {
+                HIPCHK(hipMemcpyAsync(out + off, srcp, cnt * sizeof(double), hipMemcpyDeviceToHost, stream));
+            } else {
+                DevArray<double> tmp;
+                tmp.alloc(cnt);
+                hipLaunchKernelGGL((convert_kernel<T, double>), dim3(grid_for(cnt, 4096)), dim3(kBlock), 0, stream, cnt, srcp, tmp.p);
+                HIPCHK(hipMemcpyAsync(out + off, tmp.p, cnt * sizeof(double), hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+            }
+            off += cnt;
+        }
+        HIPCHK(hipStreamSynchronize(stream));
+    }
     void copy_owned_to_host(int which, double* out) {
         size_t off = 0;
         for (Slab<T>& sl : slabs) {
@@ -2988,6 +3082,16 @@ struct Solver final : SolverBase {
         if (f == SHM_FIELD_DIV && !have_div) throw Error(SHM_ERR_STATE, "divergence not computed");
         if (f == SHM_FIELD_PHI && !have_phi) throw Error(SHM_ERR_STATE, "phi not computed");
         copy_owned_to_host((int)f, out);
+    }
+
+    void get_field_planes(shm_field f, int ka, int kb, double* out) override {
+        need_problem();
+        HIPCHK(hipSetDevice(cfg.device));
+        if ((f == SHM_FIELD_Y0 || f == SHM_FIELD_Y1 || f == SHM_FIELD_Y2) && !have_conv) throw Error(SHM_ERR_STATE, "Y not computed");
+        if (f == SHM_FIELD_DIV && !have_div) throw Error(SHM_ERR_STATE, "divergence not computed");
+        if (f == SHM_FIELD_PHI && !have_phi) throw Error(SHM_ERR_STATE, "phi not computed");
+        if (ka < slabs.front().k0 || kb > slabs.back().k1 || kb < ka) throw Error(SHM_ERR_INVALID, "plane range outside the planes this process owns");
+        copy_planes_to_host((int)f, ka, kb, out);
     }
 
     void upload_owned(const double* in, int which) {
@@ -3116,7 +3220,7 @@ struct Solver final : SolverBase {
     void apply_preconditioner(const double* v, double* out) override {
         need_problem();
         if (cfg.world != 1) throw Error(SHM_ERR_INVALID, "apply_preconditioner is a single-process test entry point");
-        if (!precond_available()) throw Error(SHM_ERR_INVALID, "DCT preconditioner needs n = 2^k in [16,1024] and a power-of-two number of z-slabs dividing n");
+        if (!precond_available()) throw Error(SHM_ERR_INVALID, "DCT preconditioner needs n = 2^k in [16,1024] and a power-of-two number of EQUAL z-slabs dividing n (shm_config.slab_plan = SHM_SLAB_PLAN_EQUAL)");
         HIPCHK(hipSetDevice(cfg.device));
         setup_precond();
         upload_owned(v, 1);
@@ -3164,6 +3268,11 @@ extern "C" {
 int32_t shm_grid_abi_version(void) { return SHM_GRID_ABI_VERSION; }
 
 void shm_plan_slab(int32_t n, int32_t nslabs, int32_t slab, int32_t* k0, int32_t* k1) {
+    if (nslabs < 1 || n < 0 || slab < 0 || slab >= nslabs) {   // bad arguments: the empty range
+        if (k0) *k0 = 0;
+        if (k1) *k1 = 0;
+        return;
+    }
     // balanced contiguous split: the first (n % nslabs) slabs get one extra plane
     const int32_t q = n / nslabs, r = n % nslabs;
     const int32_t b = slab * q + (slab < r ? slab : r);
@@ -3176,15 +3285,28 @@ shm_status shm_step1_plane_weights(const shm_sources* src, const shm_grid* grid,
         (precision != SHM_F64 && precision != SHM_F32))
         return SHM_ERR_INVALID;
     const char* tl = getenv("SHM_CONV_TIER_LOG");
-    shm::step1_plane_weights_host(src->S, src->pos, src->wnormal, src->lambda, grid->n, grid->bbox_min, grid->cell, precision, tl ? atof(tl) : 8.0, weights);
+    try {
+        shm::step1_plane_weights_host(src->S, src->pos, src->wnormal, src->lambda, grid->n, grid->bbox_min, grid->cell, precision, tl ? atof(tl) : 8.0, weights);
+    } catch (const std::bad_alloc&) {
+        return SHM_ERR_NOMEM;
+    } catch (...) {
+        return SHM_ERR_INVALID;
+    }
     return SHM_OK;
 }
 
 void shm_plan_slab_weighted(int32_t n, int32_t nslabs, int32_t slab, const double* weights, int32_t granule, int32_t* k0, int32_t* k1) {
-    std::vector<int32_t> b;
-    shm::plan_slabs_weighted(n, nslabs, weights, granule, b);
-    if (k0) *k0 = b[(size_t)slab];
-    if (k1) *k1 = b[(size_t)slab + 1];
+    // bad arguments (n < nslabs, nslabs < 1, slab out of range) or a failed allocation: the empty range [0, 0) -- nothing throws across the boundary
+    if (k0) *k0 = 0;
+    if (k1) *k1 = 0;
+    if (nslabs < 1 || n < nslabs || slab < 0 || slab >= nslabs) return;
+    try {
+        std::vector<int32_t> b;
+        shm::plan_slabs_weighted(n, nslabs, weights, granule, b);   // weights == NULL: equal weights
+        if (k0) *k0 = b[(size_t)slab];
+        if (k1) *k1 = b[(size_t)slab + 1];
+    } catch (...) {
+    }
 }
 
 shm_status shm_grid_create(const shm_config* cfg, shm_solver** out) {
@@ -3264,12 +3386,19 @@ shm_status shm_grid_compute_distance(shm_solver* s, const shm_sources* src, cons
     return rc;
 }
 
-shm_status shm_grid_run_conv(shm_solver* s) { return guard(s, [&] { s->impl->run_conv(); }); }
+shm_status shm_grid_run_conv(shm_solver* s) { return guard(s, [&] { s->impl->run_conv(SHM_STEP1_AUTO); }); }
+shm_status shm_grid_run_conv_arith(shm_solver* s, int32_t step1_arith) { return guard(s, [&] { s->impl->run_conv(step1_arith); }); }
 shm_status shm_grid_run_divergence(shm_solver* s, int32_t scrub) { return guard(s, [&] { s->impl->run_divergence(scrub); }); }
 shm_status shm_grid_get_field(shm_solver* s, shm_field f, double* out) {
     return guard(s, [&] {
         if (!out) throw shm::Error(SHM_ERR_INVALID, "null out");
         s->impl->get_field(f, out);
+    });
+}
+shm_status shm_grid_get_field_planes(shm_solver* s, shm_field f, int32_t k_begin, int32_t k_end, double* out) {
+    return guard(s, [&] {
+        if (!out) throw shm::Error(SHM_ERR_INVALID, "null out");
+        s->impl->get_field_planes(f, k_begin, k_end, out);
     });
 }
 shm_status shm_grid_apply_laplacian(shm_solver* s, const double* u, double* out) {

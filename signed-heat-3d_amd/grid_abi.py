@@ -18,8 +18,8 @@ STATUS_NAMES = {0: "SHM_OK", 1: "SHM_ERR_INVALID", 2: "SHM_ERR_HIP", 3: "SHM_ERR
 
 # every symbol include/shm_grid.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = ["shm_grid_owned_planes", "shm_grid_create", "shm_grid_destroy", "shm_grid_last_error", "shm_grid_abi_version", "shm_grid_set_problem",
-               "shm_grid_solve", "shm_grid_get_phi", "shm_grid_compute_distance", "shm_grid_run_conv", "shm_grid_run_divergence",
-               "shm_grid_get_field", "shm_grid_apply_laplacian", "shm_grid_get_constraints", "shm_grid_get_schur", "shm_grid_apply_projector", "shm_grid_apply_preconditioner", "shm_grid_isosurface", "shm_grid_get_isosurface",
+               "shm_grid_solve", "shm_grid_get_phi", "shm_grid_compute_distance", "shm_grid_run_conv", "shm_grid_run_conv_arith", "shm_grid_run_divergence",
+               "shm_grid_get_field", "shm_grid_get_field_planes", "shm_grid_apply_laplacian", "shm_grid_get_constraints", "shm_grid_get_schur", "shm_grid_apply_projector", "shm_grid_apply_preconditioner", "shm_grid_isosurface", "shm_grid_get_isosurface",
                "shm_comm_unique_id", "shm_plan_slab", "shm_step1_plane_weights", "shm_plan_slab_weighted"]
 
 
@@ -44,7 +44,7 @@ class _Grid(C.Structure):
 
 class _Opts(C.Structure):
     _fields_ = [("fast_integration", C.c_int32), ("scrub_nonfinite", C.c_int32), ("tol", C.c_double), ("max_iters", C.c_int32),
-                ("check_every", C.c_int32), ("preconditioner", C.c_int32), ("solver", C.c_int32)]
+                ("check_every", C.c_int32), ("preconditioner", C.c_int32), ("solver", C.c_int32), ("step1_arith", C.c_int32)]
 
 
 class ShmStats(C.Structure):
@@ -87,8 +87,10 @@ def load_library():
     lib.shm_grid_compute_distance.argtypes = [C.c_void_p, C.POINTER(_Sources), C.POINTER(_Grid), C.POINTER(_Opts), C.c_void_p,
                                               C.POINTER(ShmStats)]
     lib.shm_grid_run_conv.argtypes = [C.c_void_p]
+    lib.shm_grid_run_conv_arith.argtypes = [C.c_void_p, C.c_int32]
     lib.shm_grid_run_divergence.argtypes = [C.c_void_p, C.c_int32]
     lib.shm_grid_get_field.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.shm_grid_get_field_planes.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_void_p]
     lib.shm_grid_apply_laplacian.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.shm_grid_get_constraints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
     lib.shm_grid_get_schur.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
@@ -203,8 +205,10 @@ class GridSolver:
 
     SOLVER = {"auto": 0, "primal": 1, "dual": 2, "dual_slabs": 3}
 
-    def solve(self, tol=0.0, max_iters=0, check_every=0, scrub=True, fast=False, allow_noconv=False, precond="auto", solver="auto"):
-        o = _Opts(int(fast), int(scrub), float(tol), int(max_iters), int(check_every), self.PRECOND[precond], self.SOLVER[solver])
+    STEP1 = {"auto": 0, "exact_f64": 1}
+
+    def solve(self, tol=0.0, max_iters=0, check_every=0, scrub=True, fast=False, allow_noconv=False, precond="auto", solver="auto", step1="auto"):
+        o = _Opts(int(fast), int(scrub), float(tol), int(max_iters), int(check_every), self.PRECOND[precond], self.SOLVER[solver], self.STEP1[step1])
         st = ShmStats()
         self._chk(self._lib.shm_grid_solve(self._h, C.byref(o), C.byref(st)), allow=(5,) if allow_noconv else ())
         return st
@@ -219,8 +223,11 @@ class GridSolver:
         self._chk(self._lib.shm_grid_get_phi(self._h, out.ctypes.data, C.byref(k0), C.byref(k1)))
         return out, (k0.value, k1.value)
 
-    def run_conv(self):
-        self._chk(self._lib.shm_grid_run_conv(self._h))
+    def run_conv(self, step1="auto"):
+        if step1 == "auto":
+            self._chk(self._lib.shm_grid_run_conv(self._h))
+        else:
+            self._chk(self._lib.shm_grid_run_conv_arith(self._h, self.STEP1[step1]))
 
     def run_divergence(self, scrub=True):
         self._chk(self._lib.shm_grid_run_divergence(self._h, int(scrub)))
@@ -228,6 +235,12 @@ class GridSolver:
     def get_field(self, which):
         out = np.empty(self._owned_count(), dtype=np.float64)
         self._chk(self._lib.shm_grid_get_field(self._h, int(which), out.ctypes.data))
+        return out
+
+    def get_field_planes(self, which, k_begin, k_end):
+        """z-planes [k_begin, k_end) of a field (shm_grid_get_field_planes): (k_end - k_begin) * n * n values."""
+        out = np.empty((int(k_end) - int(k_begin)) * self.n * self.n, dtype=np.float64)
+        self._chk(self._lib.shm_grid_get_field_planes(self._h, int(which), int(k_begin), int(k_end), out.ctypes.data))
         return out
 
     def apply_laplacian(self, u):

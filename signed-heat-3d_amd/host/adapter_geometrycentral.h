@@ -84,6 +84,7 @@ class SignedHeatGridSolver {
     }
 
     bool VERBOSE = true;
+    bool exactStep1 = false;   // backend knob (no counterpart in the reference): Step 1 entirely in fp64, shm_opts.step1_arith
 
   private:
     shm_solver* handle = nullptr;
@@ -126,6 +127,7 @@ class SignedHeatGridSolver {
         shm_opts opts{};
         opts.fast_integration = options.fastIntegration;
         opts.scrub_nonfinite = scrub;
+        opts.step1_arith = exactStep1 ? SHM_STEP1_EXACT_F64 : SHM_STEP1_AUTO;
         Vector<double> phi(nx * ny * nz);
         if (VERBOSE) std::cerr << "Steps 1 & 2... Step 3..." << std::endl;
         if (shm_grid_compute_distance(handle, &src, &grid, &opts, phi.data(), nullptr) != SHM_OK)

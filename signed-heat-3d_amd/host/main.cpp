@@ -21,6 +21,7 @@ static void usage() {
                  "      --f, --fast       Less accurate, faster integration (BFS)\n      --V, --verbose    Verbose output\n"
                  "      --h <hCoef>       Grid resolution: n = 2*2^(hCoef+3) nodes per side (default 0 -> 16^3)\n"
                  "      --t <tCoef>       Diffusion time coefficient (default 1)\n      --fp32            Compute in fp32 (default fp64)\n"
+                 "      --exact-step1     fp64 only: every (node, source) pair of Step 1 in fp64 like the reference (default: error-budgeted tiers)\n"
                  "      --tol <x>         Projected-CG relative residual tolerance\n      --device <i>      HIP device ordinal\n"
                  "      --out <file>      Write phi as raw little-endian float64 (n^3 values, x fastest)\n"
                  "      --iso <value>     Contour phi at this value (default 0) and export the isosurface\n"
@@ -49,6 +50,7 @@ int main(int argc, char** argv) {
         else if (s == "--h") opts.hCoef = atof(need("--h"));
         else if (s == "--t") opts.tCoef = atof(need("--t"));
         else if (s == "--fp32") backend.precision = 32;
+        else if (s == "--exact-step1") backend.exactStep1 = true;
         else if (s == "--tol") backend.tol = atof(need("--tol"));
         else if (s == "--device") backend.device = atoi(need("--device"));
         else if (s == "--out") out = need("--out");

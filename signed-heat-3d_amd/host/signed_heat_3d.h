@@ -25,6 +25,7 @@ struct GridBackendOptions {
     double tol = 0.;      // <=0: library default
     int maxIters = 0;
     int localSlabs = 1;
+    bool exactStep1 = false;   // shm_opts.step1_arith = SHM_STEP1_EXACT_F64: every (node, source) pair of Step 1 in the reference's fp64 arithmetic
 };
 
 Vector3 centroid(const VertexPositionGeometry& geometry);                       // signed_heat_3d.cpp:3-12

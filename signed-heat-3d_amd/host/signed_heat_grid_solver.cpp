@@ -61,6 +61,7 @@ VectorXd SignedHeatGridSolver::solveOnDevice(bool scrub, const SignedHeat3DOptio
     opts.scrub_nonfinite = scrub ? 1 : 0;
     opts.tol = backend.tol;
     opts.max_iters = backend.maxIters;
+    opts.step1_arith = backend.exactStep1 ? SHM_STEP1_EXACT_F64 : SHM_STEP1_AUTO;
     VectorXd phi(nx * ny * nz);
     if (VERBOSE) std::cerr << "Steps 1 & 2..." << std::endl;
     const shm_status rc = shm_grid_compute_distance(handle, &src, &grid, &opts, phi.data(), &stats);

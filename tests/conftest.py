@@ -37,6 +37,8 @@ def oracle_c():
     ci, cd = ctypes.c_int, ctypes.c_double
     lib.shmo_conv_normalize.argtypes = [ci, f64, cd, ci, f64, f64, cd, ci, ci, f64]
     lib.shmo_conv_normalize.restype = None
+    lib.shmo_conv_normalize_planes.argtypes = [ci, f64, cd, ci, f64, f64, cd, ci, ci, f64]
+    lib.shmo_conv_normalize_planes.restype = None
     lib.shmo_divergence.argtypes = [ci, cd, f64, ci, f64]
     lib.shmo_divergence.restype = None
     lib.shmo_laplacian_apply.argtypes = [ci, cd, f64, f64]

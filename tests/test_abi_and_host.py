@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol(shm):
     assert declared == set(ABI_SYMBOLS), declared ^ set(ABI_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.shm_grid_abi_version() == 3
+    assert lib.shm_grid_abi_version() == 4
 
 
 def test_no_cpu_fallback(shm):
