@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SHM_GRID_ABI_VERSION 4 /* 2: shm_stats grew by cg_form (round 2); 3: by pairs_fp64 / pairs_fp32 / conv_launches (round 3); 4: shm_opts grew by step1_arith,
+#define SHM_GRID_ABI_VERSION 4 /* 2: shm_stats grew by cg_form (round 2); 3: by pairs_fp64 / pairs_fp32 / conv_launches (round 3); 4: shm_opts grew by step1_arith, shm_stats by pairs_redone,
                                 * shm_grid_run_conv_arith and shm_grid_get_field_planes added (round 4); callers allocate shm_opts / shm_stats by this header */
 
 typedef struct shm_solver shm_solver; /* opaque */
@@ -100,8 +100,10 @@ typedef struct {
 
 /* Arithmetic of Step 1 (the N*S direct summation, signed_heat_grid_solver.cpp:48-65 / :157-174; yukawaPotential, signed_heat_3d.cpp:45-49) in an SHM_F64 handle.
  * AUTO:      error-budgeted precision tiers (csrc/shm_conv_tiered.hip.h): per block of 8 x 8 x 4 nodes, sources whose terms are below e^-8 of the block's
- *            dominant terms are summed in packed fp32, sources whose terms all together stay below 2e-9 of it are dropped; everything else in fp64.
- *            max|Y - Y_exact| < 1e-8 (asserted against the C oracle at the full sizes of BASELINE.json), phi inherits < 1e-9.
+ *            dominant terms are summed in packed fp32, sources whose terms all together stay below 2e-9 of it are dropped; everything else in fp64.  The
+ *            kernel checks the packed-fp32 sums against |X| at every node and re-evaluates a block's far sources in fp64 where they could move Y by more than
+ *            the budget (cancellation regions; shm_stats.pairs_redone).  max|Y - Y_exact| < 1e-8 (asserted against the C oracle at the full sizes of
+ *            BASELINE.json), phi inherits < 1e-9.
  * EXACT_F64: every (node, source) pair in fp64 like the reference (~1.6x the Step-1 time); Y agrees with the serial loops to 1e-11.
  * The environment variable SHM_CONV_EXACT=1 forces EXACT_F64 whatever the caller asks (A/B runs). */
 enum { SHM_STEP1_AUTO = 0, SHM_STEP1_EXACT_F64 = 1 };
@@ -109,7 +111,7 @@ enum { SHM_STEP1_AUTO = 0, SHM_STEP1_EXACT_F64 = 1 };
 /* How the KKT system of signed_heat_grid_solver.cpp:101-107 is solved.
  * PRIMAL: projected (optionally DCT-preconditioned) CG on the N grid unknowns -- the matrix-free 7-point-stencil PCG.
  * DUAL:   CG on the m x m Schur complement S = A K^+ A^T (K^+ = DCT fast Poisson solve) for the multipliers, preconditioned by
- *         (A A^T)^-1 (A K A^T) (A A^T)^-1; needs the DCT (n = 2^k).  Same solution, ~2x fewer and ~2x cheaper iterations.
+ *         (A A^T)^-1 (A K A^T) (A A^T)^-1; needs the DCT (see SHM_PRECOND_DCT).  Same solution, ~2x fewer and ~2x cheaper iterations.
  * AUTO:   DUAL when the DCT is available, else PRIMAL.
  * With several processes (world > 1) Steps 1-2 and the divergence always run on the rank's z-slab.  DUAL / AUTO then gather the
  * right-hand side D^T Y (one N-vector, grouped ncclSend/ncclRecv) and every rank runs the single-GPU dual solve on the whole grid
@@ -119,8 +121,10 @@ enum { SHM_STEP1_AUTO = 0, SHM_STEP1_EXACT_F64 = 1 };
 enum { SHM_SOLVER_AUTO = 0, SHM_SOLVER_PRIMAL = 1, SHM_SOLVER_DUAL = 2, SHM_SOLVER_DUAL_SLABS = 3 };
 
 /* Preconditioner of the projected CG.  DCT = exact fast Poisson solve (3-D DCT-II diagonalises the reference's
- * Neumann Laplacian, signed_heat_grid_solver.cpp:278-334) sandwiched between constraint projections; needs n = 2^k,
- * 16 <= n <= 1024 and a single z-slab.  AUTO picks DCT when available, otherwise NONE (plain projected CG). */
+ * Neumann Laplacian, signed_heat_grid_solver.cpp:278-334) sandwiched between constraint projections.  n = 2^k in [16,1024]:
+ * O(n log n) line transforms, also on a power-of-two number of equal z-slabs dividing n.  Any other n in [4,1024] (the reference's
+ * nx = (size_t)(2 * 2^(hCoef+3)) with a fractional hCoef, :24): dense products with the DCT matrix on the fp64 matrix cores, single z-slab.
+ * AUTO picks DCT when available, otherwise NONE (plain projected CG). */
 enum { SHM_PRECOND_AUTO = 0, SHM_PRECOND_NONE = 1, SHM_PRECOND_DCT = 2 };
 
 typedef struct {
@@ -158,6 +162,8 @@ typedef struct {
     double pairs_fp32;        /* ... and in (packed) fp32: the tiers of shm_conv_tiered.hip.h; culled / dropped pairs are in neither.
                                * Nominal work is N*S; the Step-1 roofline fraction is computed from these, not from N*S. */
     int32_t conv_launches;    /* kernel launches Step 1 took on this rank in the last solve (its duration ms_conv spans all of them) */
+    double pairs_redone;      /* tiered Step 1: pairs first summed in packed fp32 and then evaluated AGAIN in fp64 because the a-posteriori test of their node
+                               * block failed (the packed-fp32 sums exceeded 1e-2 of |X| at a node: cancellation regions); counted in pairs_fp64 and pairs_fp32 too */
 } shm_stats;
 
 /* --- life cycle -------------------------------------------------------------------------------- */
@@ -203,7 +209,7 @@ shm_status shm_grid_get_field_planes(shm_solver* s, shm_field f, int32_t k_begin
 shm_status shm_grid_apply_laplacian(shm_solver* s, const double* u, double* out);
 /* Constraint rows (signed_heat_grid_solver.cpp:80-98): nodes/coeffs hold 8*S entries; *m rows written. */
 shm_status shm_grid_get_constraints(shm_solver* s, int64_t* nodes, double* coeffs, int32_t* m);
-/* The explicit Schur complement S = A K^+ A^T the dual solver iterates on when the problem qualifies (one slab, n = 2^k <= 512, m <= 8192): m x m
+/* The explicit Schur complement S = A K^+ A^T the dual solver iterates on when the problem qualifies (one slab; n = 2^k <= 512 and m <= 8192, or any other n and m <= 16384): m x m
  * doubles, row-major; *m rows.  SHM_ERR_STATE when the solver applies S through the grid instead.  Test entry point (world==1). */
 shm_status shm_grid_get_schur(shm_solver* s, double* out, int32_t* m);
 /* v <- v - A^T (A A^T)^-1 A v on the device (the projector inside the CG); v: n^3 doubles, world==1. */

@@ -14,9 +14,19 @@
 // bound of every node's distance to its nearest source -- and w_near the weight of s*: every term of s is then below e^-G of the dominant term
 // of every node of the block.
 // The same lane-parallel test with the skip threshold drops sources whose terms vanish against the budget altogether.
-// Exponent range: the far tier carries ONE offset d0_w per block, and r_hi_w - d0_w <= 2 rt_w (the block's diameter), so a far term that may not yet be
-// dropped reaches down to 2^-(2 lambda' rt_w + log2(S / budget)) of the offset.  Where that leaves the fp32 range (fine meshes over coarse grids, small
-// tCoef: lambda * cell >~ 3) the HOST switches the far tier off for the launch (P.tier_log = 3e38, Solver::launch_conv): everything not dropped is fp64.
+// Exponent range: the far tier carries ONE offset d0_w per block.  Over the block's nodes a source's exponent lambda' (r - d0_w) reaches up to
+// lambda' (dist(b_s, box_w) + 2 rt_w - d0_w); a source that is neither dropped nor guaranteed to stay a normal fp32 number there -- that bound, plus
+// log2(w_max / w_s) (the weights are staged relative to the largest one) and 13 bits for the factor 1 / r' and the accumulation -- is evaluated in fp64
+// whatever its size (`in_range` below).  Bites on fine meshes over coarse grids and with small tCoef (lambda * cell >~ 2); a few sources per block otherwise.
+//
+// The budget is ENFORCED, not assumed (round 4).  Y = X / |X| amplifies any error of X by (sum of |terms|) / |X|, which is unbounded where the sheets of the
+// source geometry cancel (medial axis): measured at 512^3 / 1024^3 the tiered result left the 1e-8 budget exactly there (|X| / L1 = 2e-3 ... 8e-3, max|dY|
+// 1.1e-8 ... 3.3e-8) and nowhere else (tools/tier_worst_nodes.py, profiles/r04_tier_worst_nodes.txt).  So the far loop also accumulates, per node,
+// L1_far = sum_far |w_s|_1 e^{-lambda r} / r, and when the block is done every node is tested:
+//     eps_far * L1_far  <=  budget * |X|          (P.far_redo_ratio = budget / eps_far)
+// with eps_far the calibrated relative error of a packed-fp32 term as it shows up in X (1e-6: twice the largest |dY| |X| / L1_far observed over ten data
+// files at up to 1024^3; the rounding errors of the terms are independent, their sum grows slower than L1_far).  A block with a failing node walks the
+// sources a second time and evaluates its far sources in fp64 on top of the near sums it already holds -- no packed-fp32 term is left in it.
 // What the far tier contributes to Y is bounded by eps32 * sum_far |term| / |X|; `tools/tier_budget.py` evaluates that on the host
 // and the GPU tests hold Y to the stated budget against the all-fp64 kernel (SHM_CONV_EXACT=1).
 #pragma once
@@ -84,11 +94,16 @@ __device__ __forceinline__ float uniform_f32(float v) { return __int_as_float(__
 #define SHM_TIER_TX 8
 #endif
 constexpr int kTierTX = SHM_TIER_TX, kTierTY = 64 / kTierTX;   // a wave's block of nodes is kTierTX x kTierTY x NPT (one z-column of NPT nodes per lane)
+// The budget of the tiers on the normalised field Y (what tests/test_gpu_parity.py asserts against the C oracle at BASELINE.json's full sizes), and the
+// calibrated relative error of a packed-fp32 term as it shows up in X: twice the largest max|dY| |X| / L1_far measured (4.8e-7: bunny_small 512^3,
+// profiles/r04_tier_worst_nodes.txt).  A block where eps_far L1_far > budget |X| at any node re-evaluates its far sources in fp64.
+constexpr double kTierBudget = 1.0e-8, kTierEpsFar = 1.0e-6;
 constexpr int kTierCluster = 64;                    // sources per cluster = lanes per wave: one source per lane in the classification
 constexpr int kTierChunk = 4;                       // clusters per LDS fill
 constexpr int kTierFill = kTierCluster * kTierChunk;
 
-// counters (optional, may be null): [0] (node, source) pairs evaluated in fp64, [1] in packed fp32 -- what `roofline.frac` is computed from.
+// counters (optional, may be null): [0] (node, source) pairs evaluated in fp64, [1] in packed fp32 -- what `roofline.frac` is computed from --
+// [2] pairs evaluated a second time in fp64 by the a-posteriori check (they are part of [0] as well).
 //
 // Work distribution: the unit of work is one wave's sub-tile (8 x 8 x NPT nodes).  Waves are independent -- each pulls the next unit from a global
 // counter (one atomic per ~1 ms of work), scans the sources for its own bounds, stages 64 sources at a time into its own LDS region (lane l loads
@@ -99,7 +114,13 @@ constexpr int kTierFill = kTierCluster * kTierChunk;
 #define SHM_TIER_NEAR_UNROLL 1
 #endif
 #ifndef SHM_TIER_FAR_UNROLL
-#define SHM_TIER_FAR_UNROLL 4
+#define SHM_TIER_FAR_UNROLL 3   // (4 until round 4; 3 keeps the kernel at 181 registers with the per-node L1 sums of the a-posteriori test: 187 with 4)
+#endif
+#ifndef SHM_TIER_CHECK
+#define SHM_TIER_CHECK 1        // the a-posteriori test of the packed-fp32 sums (per-node L1 sums + second pass); 0: A/B builds only
+#endif
+#ifndef SHM_TIER_LDS_FETCH
+#define SHM_TIER_LDS_FETCH 1    // the next cluster's sources travel global -> LDS directly; 0: through 12 registers per lane (rounds 2-3)
 #endif
 #ifndef SHM_TIER_NEAR_BFS
 #define SHM_TIER_NEAR_BFS 1
@@ -121,6 +142,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
     constexpr int kPad = kNearUnroll > kFarUnroll ? kNearUnroll : kFarUnroll;   // staged entries behind the last real one: zero weight, far away -- they pad the
     __shared__ double stage64[kWaves][(kTierCluster + kPad) * 6];              // compacted lists to whole groups of sources in flight
     __shared__ float stage32[kWaves][(kTierCluster + kPad) * 6];
+    // the next cluster's sources travel global -> LDS directly (global_load_lds_dwordx4: three 16-byte pieces of every lane's 48-byte record, each piece
+    // landing at wave base + lane * 16), not through 12 registers per lane held across the two loops: those registers are what the per-node L1 sums of the
+    // a-posteriori test now live in (the kernel must stay within 184 VGPRs for the set-up kernels to run beside it)
+#if SHM_TIER_LDS_FETCH
+    __shared__ double2 raw[kWaves][3][kTierCluster];
+#endif
     __shared__ double exp_tab[2048];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
     double* const tile = stage64[wave];
@@ -131,12 +158,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
     const size_t plane = (size_t)n * n;
     const float lam_l2 = (float)(P.lambda * 1.4426950408889634);     // lambda in powers of two per unit length
     const float g_l2 = P.tier_log * 1.4426950408889634f, skip_l2 = P.skip_base * 1.4426950408889634f;
+    const float cellq = (float)(P.cell * (P.lambda * 1.4426950408889634));   // the cell size in the far tier's scaled units
+    const float lws = (float)log2(P.wscale);                                   // log2 of the weights' scale factor (a power of two)
     constexpr double kHalfZ = 0.5 * (NPT - 1);
     constexpr double kHalfX = 0.5 * (kTierTX - 1), kHalfY = 0.5 * (kTierTY - 1);
     const float rt_w = (float)(sqrt(kHalfX * kHalfX + kHalfY * kHalfY + kHalfZ * kHalfZ) * P.cell) * 1.000001f;
     const float hx = uniform_f32((float)(kHalfX * P.cell) * 1.000001f), hy = uniform_f32((float)(kHalfY * P.cell) * 1.000001f),
                 hz = uniform_f32((float)(kHalfZ * P.cell) * 1.000001f);   // half extents of a block
-    unsigned long long cnt_near = 0, cnt_far = 0;
+    unsigned long long cnt_near = 0, cnt_far = 0, cnt_redo = 0;
     // Eight queue heads, one per XCD (workgroup b runs on XCD b % 8): the units -- x fastest, then y, then z -- are cut into eight contiguous ranges, so
     // that the two 64-byte halves of a 128-byte line of Y (x-adjacent blocks) are written through the same L2 and leave it as one line; an XCD
     // whose range is exhausted takes units from the others' (work stealing keeps the end of the kernel balanced).
@@ -163,9 +192,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
         const int ty = trem / P.tiles_x, tx = trem - ty * P.tiles_x;
         const int i0 = tx * kTierTX, j0 = ty * kTierTY, kk0 = P.kk_begin + tz * NPT;
 
-        double pz[NPT], ax[NPT], ay[NPT], az[NPT];
-        float qz[NPT], fx[NPT], fy[NPT], fz[NPT];
-        bool live[NPT];
+        double pz0 = 0., ax[NPT], ay[NPT], az[NPT];
+        float qz0 = 0.f, fx[NPT], fy[NPT], fz[NPT];
         const int li = i0 + (lane % kTierTX), lj = j0 + (lane / kTierTX);
         const int ci = min(li, n - 1), cj = min(lj, n - 1);
         // indicesToNodePosition: (i,j,k)*cellSize + bboxMin, evaluated in double like the reference (:510-514)
@@ -173,15 +201,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
         const float qx = (float)(px * (P.lambda * 1.4426950408889634)), qy = (float)(py * (P.lambda * 1.4426950408889634));   // far tier: scaled coordinates (see the far loop)
 #pragma unroll
         for (int e = 0; e < NPT; e++) {
-            int kk = kk0 + e;   // the wave's nodes form a compact kTierTX x kTierTY x NPT block
-            live[e] = li < n && lj < n && kk < P.kk_end;
-            kk = min(kk, P.kk_end - 1);
-            const double z = (P.k0 + kk - 1) * P.cell + P.bbox_min[2];
-            pz[e] = z;
-            qz[e] = (float)(z * (P.lambda * 1.4426950408889634));
             ax[e] = ay[e] = az[e] = 0.;
             fx[e] = fy[e] = fz[e] = 0.f;
         }
+        // the wave's nodes form a compact kTierTX x kTierTY x NPT block: a lane keeps the z of its first node, the others follow by the cell size (planes past the
+        // end of the launch are evaluated like the others and not stored)
+        pz0 = (P.k0 + kk0 - 1) * P.cell + P.bbox_min[2];
+        qz0 = (float)(pz0 * (P.lambda * 1.4426950408889634));
+        const bool live_xy = li < n && lj < n;
         // nearest source of the block's centre (and its weight): one source per lane and step, butterfly minimum
         const float cx = (float)((i0 + kHalfX) * P.cell + P.bbox_min[0]), cy = (float)((j0 + kHalfY) * P.cell + P.bbox_min[1]);
         const float cz = (float)((P.k0 + kk0 - 1 + kHalfZ) * P.cell + P.bbox_min[2]);
@@ -189,7 +216,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
         for (int s = lane; s < P.S; s += kWave) {
             const double* q = src + (size_t)s * 6;
             const float dx = cx - (float)q[0], dy = cy - (float)q[1], dz = cz - (float)q[2];
-            const float w0 = (float)q[3], w1 = (float)q[4], w2c = (float)q[5];
+            const float w0 = (float)(q[3] * P.wscale), w1 = (float)(q[4] * P.wscale), w2c = (float)(q[5] * P.wscale);   // (scaled: see the staging below)
             const float d2 = dx * dx + dy * dy + dz * dz, w2 = w0 * w0 + w1 * w1 + w2c * w2c;
             if (d2 < dmin || (d2 == dmin && w2 > wnear)) {   // ties (the zero-weight padding repeats a source) go to the larger weight
                 dmin = d2;
@@ -220,67 +247,95 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
         const float d0_w = uniform_f32(fmaxf(0.f, dmin * 0.999999f - rt_w));                      // no source is closer than this to any node of the block
         const float coff = lam_l2 * d0_w;   // far tier: e^{-lambda (r - d0)} = 2^(coff - lambda log2 e r), folded back in by e^{-lambda d0} at the end
 
-        // the lane's source of the next cluster, loaded one cluster ahead
-        double nq[6];
-        {
-            const double* q = src + (size_t)lane * 6;
+        const double e0 = YukawaMath<double>::exp_neg(-P.lambda * (double)d0_w) * (P.lambda * 1.4426950408889634) / P.wscale;   // (the far sums hold w_scaled / (lambda log2 e r))
+        float fl[NPT];   // per node: sum over the far sources of |w|_1 e^{-lambda (r - d0)} / (lambda' r) -- the L1 norm of what the packed-fp32 tier contributed
 #pragma unroll
-            for (int a = 0; a < 6; a++) nq[a] = q[a];
-        }
+        for (int e = 0; e < NPT; e++) fl[e] = 0.f;
+        // constant of the exponent-range test of a far source: lambda' (dist + 2 rt_w) - coff - log2(w_s / w_max) <= 113  (see the header)
+        const float range_c = uniform_f32(2.f * rt_w * lam_l2 - 113.f - coff);
+        // pass 0: near sources in fp64, far ones in packed fp32.  pass 1 (only when the a-posteriori test failed): the far sources again, in fp64.
+#pragma unroll 1
+        for (int pass = 0; pass < 2; pass++) {
+        // the lane's source of cluster c: fetched into the wave's raw LDS region one cluster ahead (issued once cluster c - 1 has been read out of it, in flight
+        // while that cluster's two loops run; a skipped cluster's fetch is simply overwritten by the next: loads return in order)
+#if SHM_TIER_LDS_FETCH
+        auto fetch_cluster = [&](int c) {
+            const char* g = reinterpret_cast<const char*>(src + ((size_t)c * kTierCluster + lane) * 6);
+            __builtin_amdgcn_global_load_lds(g, &raw[wave][0][0], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(g + 16, &raw[wave][1][0], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(g + 32, &raw[wave][2][0], 16, 0, 0);
+        };
+#else
+        double nq[6];
+        auto fetch_cluster = [&](int c) {
+            const double* qn = src + ((size_t)c * kTierCluster + lane) * 6;
+#pragma unroll
+            for (int a = 0; a < 6; a++) nq[a] = qn[a];
+        };
+#endif
+        fetch_cluster(0);
 #pragma unroll 1
         for (int c = 0; c < P.n_clusters; c++) {
-            double q[6];
-#pragma unroll
-            for (int a = 0; a < 6; a++) q[a] = nq[a];
-            auto prefetch_next = [&]() {   // the lane's source of the next cluster: issued once this cluster is staged, in flight while its two loops run
-                if (c + 1 < P.n_clusters) {
-                    const double* qn = src + ((size_t)(c + 1) * kTierCluster + lane) * 6;
-#pragma unroll
-                    for (int a = 0; a < 6; a++) nq[a] = qn[a];
-                }
-            };
             {   // the whole cluster against the block (bounding sphere, scalar loads): dropped before anything is staged
                 const float* rec = clusters + (size_t)c * kConvClusterRec;
                 const float gdx = cx - rec[0], gdy = cy - rec[1], gdz = cz - rec[2];
                 const float gap = sqrtf(gdx * gdx + gdy * gdy + gdz * gdz) * 0.999999f - rt_w - rec[3] - r_hi_w;
-                if (gap * lam_l2 > skip_l2 + rec[4] * 1.4426950408889634f - lnear_w) {
-                    prefetch_next();
+                if (gap * lam_l2 > skip_l2 + (rec[4] * 1.4426950408889634f + lws) - lnear_w) {   // (rec[4]: ln of the cluster's largest UNscaled weight)
+                    if (c + 1 < P.n_clusters) fetch_cluster(c + 1);
                     continue;
                 }
             }
+            double q[6];
+#if SHM_TIER_LDS_FETCH
+            {
+                __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the fetch of this cluster has landed in LDS
+                const double2 r0 = raw[wave][0][lane], r1 = raw[wave][1][lane], r2 = raw[wave][2][lane];
+                q[0] = r0.x; q[1] = r0.y; q[2] = r1.x; q[3] = r1.y; q[4] = r2.x; q[5] = r2.y;
+                __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the reads are done before the next fetch may overwrite the region
+            }
+#else
+#pragma unroll
+            for (int a = 0; a < 6; a++) q[a] = nq[a];
+#endif
+            if (c + 1 < P.n_clusters) fetch_cluster(c + 1);
             // one source per lane: near / far / dropped for this wave's block of nodes
             unsigned long long nearmask, farmask;
             {
+                // (the fp32 copies carry the weights relative to the largest one -- times P.wscale, a power of two: exact -- so that the exponent-range test
+                // below and the packed-fp32 sums see weights in (0, 1] whatever the mesh's units; the fp64 list keeps the reference's own weights)
                 float q32[6];
 #pragma unroll
-                for (int a = 0; a < 6; a++) q32[a] = (float)q[a];
+                for (int a = 0; a < 6; a++) q32[a] = a < 3 ? (float)q[a] : (float)(q[a] * P.wscale);
                 // no node of the block is closer to the source than the source is to the block's box
                 const float dx = fmaxf(fabsf(cx - q32[0]) - hx, 0.f), dy = fmaxf(fabsf(cy - q32[1]) - hy, 0.f), dz = fmaxf(fabsf(cz - q32[2]) - hz, 0.f);
                 const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
                 const float w2 = q32[3] * q32[3] + q32[4] * q32[4] + q32[5] * q32[5];
-                const float rel = 0.5f * __log2f(w2) + 1e-5f - lnear_w;                    // log2(|w_s| / |w_near|), rounded up (w = 0: -inf)
+                const float lw = 0.5f * __log2f(w2);                                       // log2(|w_s| / w_max) <= 0 (w = 0: -inf)
+                const float rel = lw + 1e-5f - lnear_w;                                    // log2(|w_s| / |w_near|), rounded up
                 const float lhs = (dist * 0.999999f - r_hi_w) * lam_l2;                    // lower bound of lambda (r(x, s) - r_near(x)) / ln 2
                 const bool valid = w2 > 0.f;                                              // the zero-weight padding is never evaluated
-                const bool far = lhs > g_l2 + rel;
+                const bool in_range = fmaf(dist, lam_l2, range_c) <= lw;                   // every term of the source stays a normal fp32 number over the block
+                const bool far = lhs > g_l2 + rel && in_range;
                 const bool drop = lhs > skip_l2 + rel;
-                nearmask = __ballot(valid && !far);
-                farmask = __ballot(valid && far && !drop);
+                const bool to64 = valid && (pass == 0 ? !far : (far && !drop));
+                const bool to32 = valid && pass == 0 && far && !drop;
+                nearmask = __ballot(to64);
+                farmask = __ballot(to32);
                 // stage the cluster for the broadcast reads below (wave-private region: no barrier), COMPACTED: the near sources in fp64 and the far ones in fp32
                 // each as a dense list in mask order, so that the two loops below walk consecutive entries with a plain counter (a bit scan per source cost
                 // ~10 scalar instructions on the wave's in-order instruction stream)
                 const unsigned long long below = (1ull << lane) - 1ull;
-                if (valid && !far) {
+                if (to64) {
                     const int rnk = __builtin_popcountll(nearmask & below);
 #pragma unroll
                     for (int a = 0; a < 6; a++) tile[rnk * 6 + a] = q[a];
-                } else if (valid && !drop) {
+                } else if (to32) {
                     const int rnk = __builtin_popcountll(farmask & below);
                     // positions in units of 1 / (lambda log2 e): the far loop then gets lambda r log2 e = d2' rsq(d2') without a multiplication of its own
 #pragma unroll
                     for (int a = 0; a < 6; a++) tile32[rnk * 6 + a] = a < 3 ? q32[a] * lam_l2 : q32[a];
                 }
             }
-            prefetch_next();
             const int nnear = __builtin_popcountll(nearmask), nfar = __builtin_popcountll(farmask);
             if (lane < kPad) {
 #pragma unroll
@@ -294,6 +349,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
             }
             cnt_near += (unsigned)nnear;
             cnt_far += (unsigned)nfar;
+            if (pass) cnt_redo += (unsigned)nnear;
             // ---- near tier: fp64, kNearUnroll sources in flight ----
             for (int i0 = 0; i0 < nnear; i0 += kNearUnroll) {
                 // breadth-first over the pairs in flight: every stage of e^{-lambda r}/r for all of them before the next stage, so that
@@ -308,9 +364,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                     wz[u] = tile[6 * s + 5];
                     const double dx = px - tile[6 * s], dy = py - tile[6 * s + 1];
                     const double dxy2 = dx * dx + dy * dy;
+                    const double dz0 = pz0 - sz;
 #pragma unroll
                     for (int e = 0; e < NPT; e++) {
-                        const double dz = pz[e] - sz;
+                        const double dz = e ? dz0 + e * P.cell : dz0;   // (the block's nodes are consecutive planes: one z per lane, the others by the cell size)
                         x[u][e] = fma(dz, dz, dxy2);
                     }
                 }
@@ -341,12 +398,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                     const int s = i0 + u;
                     const float sz = tile32[6 * s + 2];
                     const float wx = tile32[6 * s + 3], wy = tile32[6 * s + 4], wz = tile32[6 * s + 5];
+#if SHM_TIER_CHECK
+                    const float wl1 = fabsf(wx) + fabsf(wy) + fabsf(wz);
+#endif
+                    const float dz0 = qz0 - sz;
                     const float dx = qx - tile32[6 * s], dy = qy - tile32[6 * s + 1];   // (scaled coordinates: qx, qy, qz and the staged positions are x lambda log2 e)
                     const float dxy2 = dx * dx + dy * dy;
 #pragma unroll
                     for (int e = 0; e < NPT; e += 2) {
-                        const float2v z2 = {qz[e], qz[e + 1]};
-                        const float2v dz = z2 - sz;
+                        const float2v dz = float2v{e * cellq, (e + 1) * cellq} + dz0;   // (consecutive planes: one scaled z per lane, the others by the scaled cell size)
                         const float2v d2 = __builtin_elementwise_fma(dz, dz, float2v{dxy2, dxy2});
                         const float2v rinv = {__builtin_amdgcn_rsqf(d2.x), __builtin_amdgcn_rsqf(d2.y)};   // 1 / (lambda log2 e r)
                         const float2v arg = __builtin_elementwise_fma(-d2, rinv, float2v{coff, coff});     // -lambda log2 e (r - d0)
@@ -356,14 +416,31 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                         a = __builtin_elementwise_fma(float2v{wx, wx}, g, float2v{fx[e], fx[e + 1]}); fx[e] = a.x; fx[e + 1] = a.y;
                         a = __builtin_elementwise_fma(float2v{wy, wy}, g, float2v{fy[e], fy[e + 1]}); fy[e] = a.x; fy[e + 1] = a.y;
                         a = __builtin_elementwise_fma(float2v{wz, wz}, g, float2v{fz[e], fz[e + 1]}); fz[e] = a.x; fz[e + 1] = a.y;
+#if SHM_TIER_CHECK
+                        a = __builtin_elementwise_fma(float2v{wl1, wl1}, g, float2v{fl[e], fl[e + 1]}); fl[e] = a.x; fl[e + 1] = a.y;
+#endif
                     }
                 }
             }
         }
-        const double e0 = YukawaMath<double>::exp_neg(-P.lambda * (double)d0_w) * (P.lambda * 1.4426950408889634);   // (the far sums hold 1 / (lambda log2 e r))
+        if (!SHM_TIER_CHECK) break;
+        if (pass == 0) {
+            // a-posteriori test of the far tier's contribution (see the header): eps_far L1_far <= budget |X| at every node of the block, or the far sources
+            // are evaluated again in fp64 (pass 1) and the packed-fp32 sums discarded
+            bool fail = false;
+#pragma unroll
+            for (int e = 0; e < NPT; e++) {
+                const double x0 = ax[e] + (double)fx[e] * e0, x1 = ay[e] + (double)fy[e] * e0, x2 = az[e] + (double)fz[e] * e0;
+                fail = fail || (live_xy && kk0 + e < P.kk_end && (double)fl[e] * e0 > (double)P.far_redo_ratio * sqrt(x0 * x0 + x1 * x1 + x2 * x2));
+            }
+            if (__ballot(fail) == 0ull) break;
+#pragma unroll
+            for (int e = 0; e < NPT; e++) fx[e] = fy[e] = fz[e] = 0.f;
+        }
+        }  // pass loop
 #pragma unroll
         for (int e = 0; e < NPT; e++) {
-            if (!live[e]) continue;
+            if (!(live_xy && kk0 + e < P.kk_end)) continue;
             const double x0 = ax[e] + (double)fx[e] * e0, x1 = ay[e] + (double)fy[e] * e0, x2 = az[e] + (double)fz[e] * e0;
             const double nrm = sqrt(x0 * x0 + x1 * x1 + x2 * x2);
             const size_t vi = (size_t)(kk0 + e) * plane + (size_t)cj * n + ci;   // (live: kk0 + e is a plane of the launch)
@@ -384,6 +461,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
     if (counters && lane == 0) {
         atomicAdd(&counters[0], cnt_near * (unsigned long long)(64 * NPT));
         atomicAdd(&counters[1], cnt_far * (unsigned long long)(64 * NPT));
+        if (cnt_redo) atomicAdd(&counters[2], cnt_redo * (unsigned long long)(64 * NPT));
     }
 }
 

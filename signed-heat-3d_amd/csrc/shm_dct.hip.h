@@ -207,7 +207,11 @@ template <int LOG2N, int CPLX_BYTES> constexpr int dct_waves_per_simd() {
     constexpr int want = LOG2N <= 8 ? (SHM_DCT_WAVES_256 > 0 ? SHM_DCT_WAVES_256 : 1) : (CPLX_BYTES == 8 ? SHM_DCT_WAVES_F32 : 2);
     return by_lds >= want ? want : (by_lds >= 1 ? by_lds : 1);
 }
-template <typename TP, typename TIn, typename TOut, int MODE, bool DOT, int LOG2N, bool XPASS, bool SEG>
+// PF (round 4, dense sweeps of the long transforms): the NEXT tile's input is loaded into registers (n L / 256 values per thread: 16 at n = 512 fp64)
+// before the current tile's FFT, so that its HBM latency runs under the FFT passes and the store phase instead of in front of them.  Without it a
+// workgroup alternates load -> FFT -> store, and the two or three workgroups a CU holds keep ~15-20 KB in flight per CU where 8 TB/s needs ~30:
+// 0.46-0.47 of the HBM peak at 512^3 (profiles/r03_bench_512_primal_dct.json).  Dense sweeps only (no tile list, no element mask, plain layout).
+template <typename TP, typename TIn, typename TOut, int MODE, bool DOT, int LOG2N, bool XPASS, bool SEG, bool PF = false>
 __global__ __launch_bounds__(kBlock, ((LOG2N >= SHM_DCT_WAVES_HINT || SHM_DCT_WAVES_256 > 0) && !(SHM_DCT_SEG9_ONE_WAVE && SEG && LOG2N == 9 && sizeof(TP) == 8) ? dct_waves_per_simd<LOG2N, (int)sizeof(Cplx<TP>)>() : 1)) void dct_lines_kernel(DctParams P, const TIn* __restrict__ in, TOut* __restrict__ out,
                                                            const Cplx<TP>* __restrict__ tw_g, const Cplx<TP>* __restrict__ om_g,
                                                            const TP* __restrict__ lam_g, const TOut* __restrict__ dot_with,
@@ -240,6 +244,33 @@ __global__ __launch_bounds__(kBlock, ((LOG2N >= SHM_DCT_WAVES_HINT || SHM_DCT_WA
         }
     }
     if (MODE == DCT_FUSED) sp_lam_n = (TP)2 * lam_g[n / 2];   // lam_n = 4/h^2 = 2 lam_{n/2}
+    static_assert(!PF || !SEG, "the prefetching variant serves plain layouts");
+    // PF: this thread's share of the next tile, in flight while the current one is transformed and stored
+    TP pf[PF ? EPT : 1];
+    auto pf_issue = [&](int lbx) {
+        if constexpr (PF) {
+            const int tx = lbx;
+            const long long bin = (long long)(tx % P.tiles_a) * P.in.a_stride + (long long)(tx / P.tiles_a) * P.in.b_stride;
+            const unsigned to = XPASS ? (n >= kBlock ? (unsigned)(tid * P.in.elem_stride) : (unsigned)((tid >> LOG2N) * P.in.line_stride + (tid & (n - 1)) * P.in.elem_stride))
+                                      : (unsigned)((tid & (L - 1)) * P.in.line_stride + (tid >> LOG2L) * P.in.elem_stride);
+#pragma unroll
+            for (int a = 0; a < EPT; a++) {
+                long long u;
+                if (XPASS) {
+                    constexpr int per = n >= kBlock ? n / kBlock : 1, lp = n >= kBlock ? 1 : kBlock / n;
+                    u = n >= kBlock ? (long long)(a / per) * P.in.line_stride + (long long)((a % per) * kBlock) * P.in.elem_stride : (long long)(a * lp) * P.in.line_stride;
+                } else {
+                    u = (long long)(a * (kBlock / L)) * P.in.elem_stride;
+                }
+                pf[a] = (TP) * ((in + (P.in.off + bin + u)) + to);
+            }
+        }
+    };
+    static_assert(!PF || total % kBlock == 0, "the prefetching variant serves full tiles");
+    if (PF) {
+        const int lb0 = (int)xcd_remap(blockIdx.x, gridDim.x);
+        if (lb0 < P.ntiles) pf_issue(lb0);
+    }
     // concurrently running workgroups take neighbouring tiles (adjacent x chunks of the same rows share an XCD's L2)
     for (int lb = (int)xcd_remap(blockIdx.x, gridDim.x); lb < P.ntiles; lb += (int)gridDim.x) {
     __syncthreads();                                       // the previous tile's LDS reads are done (and the twiddle table is in place)
@@ -277,6 +308,16 @@ __global__ __launch_bounds__(kBlock, ((LOG2N >= SHM_DCT_WAVES_HINT || SHM_DCT_WA
     };
 
     // ---------------- load: global -> registers (CH loads in flight) -> LDS ----------------
+    if constexpr (PF) {
+#pragma unroll
+        for (int a = 0; a < EPT; a++) {
+            const int idx = tid + a * kBlock;
+            const int l = line_of(idx), j = elem_of(idx);
+            const int slot = (MODE == DCT_INV) ? j : makhoul_slot(j, n);
+            reinterpret_cast<TP*>(&buf[slot * kFftRow + (l >> 1)])[l & 1] = pf[a];
+        }
+        if (lb + (int)gridDim.x < P.ntiles) pf_issue(lb + (int)gridDim.x);   // in flight until the next iteration's LDS writes
+    } else
 #pragma unroll 1
     for (int a0 = 0; a0 < EPT; a0 += CH) {
         TP v[CH];

@@ -37,6 +37,7 @@
 #include "shm_twolevel.hip.h"
 #include "shm_schur.hip.h"
 #include "shm_dct.hip.h"
+#include "shm_dct_gemm.hip.h"
 
 namespace shm {
 
@@ -278,7 +279,14 @@ static void step1_plane_weights_host(int64_t S, const double* pos, const double*
     const double skip_base = std::log((double)S / (f64 ? 2e-9 : 6.0e-8));   // (the kernels' drop thresholds: Solver::set_sources)
     const double far_cost = 0.43;
     std::vector<double> wmag((size_t)S);
-    for (int64_t s = 0; s < S; s++) wmag[(size_t)s] = std::sqrt(wn[3 * s] * wn[3 * s] + wn[3 * s + 1] * wn[3 * s + 1] + wn[3 * s + 2] * wn[3 * s + 2]);
+    double wlo = 1e300, whi = 0.;
+    for (int64_t s = 0; s < S; s++) {
+        wmag[(size_t)s] = std::sqrt(wn[3 * s] * wn[3 * s] + wn[3 * s + 1] * wn[3 * s + 1] + wn[3 * s + 2] * wn[3 * s + 2]);
+        if (wmag[(size_t)s] > 0.) wlo = std::min(wlo, wmag[(size_t)s]);
+        whi = std::max(whi, wmag[(size_t)s]);
+    }
+    // (the kernel's per-source exponent-range test of the packed-fp32 tier, shm_conv_tiered.hip.h `in_range`, as a per-source rule on the block's centre)
+    const double range_c = 1.4426950408889634 * lambda * 2.0 * rt - 113.0, lwhi = std::log2(std::max(whi, 1e-300));
     // fp32: the kernel's clusters (Morton order of the sources, 32 per cluster, bounding sphere about the mean, largest weight)
     constexpr int kCl = 32;
     std::vector<double> ccen, crad, clnw;
@@ -352,9 +360,9 @@ static void step1_plane_weights_host(int64_t S, const double* pos, const double*
                         if (!(wmag[(size_t)s] > 0.)) continue;
                         const double lhs = lambda * (dist[(size_t)s] - rt - r_hi), rel = std::log(wmag[(size_t)s]) - ln_near;
                         if (lhs > skip_base + rel) continue;
-                        // (the exponent-range guard of the packed-fp32 tier, in bits: Solver::launch_conv)
-                        const bool far_ok = 1.4426950408889634 * (lambda * 2.0 * rt + std::min(skip_base, 44.36)) <= 90.;
-                        cost += lhs > tier_log + rel && far_ok ? far_cost : 1.0;
+                        const double d_box = std::max(0., dist[(size_t)s] - rt), d0 = std::max(0., dmin - rt);
+                        const bool in_range = 1.4426950408889634 * lambda * (d_box - d0) + range_c <= std::log2(wmag[(size_t)s]) - lwhi;
+                        cost += lhs > tier_log + rel && in_range ? far_cost : 1.0;
                     }
                 } else {
                     for (size_t c = 0; c < crad.size(); c++) {
@@ -465,12 +473,13 @@ struct Solver final : SolverBase {
     double cell = 0., lambda = 0.;
     double bbox_min[3] = {0, 0, 0};
     double conv_ctr[3] = {0, 0, 0};   // the grid's centre: origin of the coordinates Step 1 computes in
+    double conv_wscale = 1.;          // power of two that brings the largest source weight into (0.5, 1]
     int64_t S = 0;
     std::vector<double> h_pos, h_wn, h_area;
     double area_sum = 0., conv_far_gap = 0., conv_skip_base = 3.0e38, last_host_setup_ms = 0., last_setup_wall_ms = 0.;
     double conv_tier_log = 0., conv_tier_skip_base = 3.0e38;   // tiered fp64 Step 1: far threshold G (nats) and its drop threshold
     bool conv_tiered = false;                                  // fp64 only; SHM_CONV_EXACT=1 selects the all-fp64 kernel
-    DevArray<unsigned long long> d_pair_counters;              // [0] fp64 pairs, [1] fp32 pairs evaluated by the last Step 1
+    DevArray<unsigned long long> d_pair_counters;              // [0] fp64 pairs, [1] fp32 pairs evaluated by the last Step 1, [2] pairs evaluated again in fp64 (a-posteriori test)
     DevArray<unsigned> d_unit_counters;                        // tiered Step 1: eight work-queue heads (one per XCD) per launch (zeroed at the start of every Step 1)
     static constexpr int kMaxConvLaunches = 256;
     int conv_launch_index = 0;
@@ -522,6 +531,7 @@ struct Solver final : SolverBase {
     DevArray<Cplx<TP>> d_tw, d_om;
     DevArray<TP> d_lam;
     DevArray<double> d_lam64;  // the same eigenvalues in double (zsolve_sparse_kernel computes in double whatever T)
+    DevArray<double> gd_Cm, gd_Ct, gd_W1, gd_W2;   // n not a power of two (shm_dct_gemm.hip.h): the orthonormal DCT-II matrix, its transpose, two n^3 work arrays
     // explicit Schur complement S = A K^+ A^T of the dual solver (shm_schur.hip.h): image-sum Green's table T and its work arrays, the per-row cells /
     // trilinear parameters, S itself (mp x mp, zero-padded)
     DevArray<double> gs_lam, gs_ctab, gs_Cm, gs_Ct, gs_W0, gs_W1, gs_T, Sdense, d_rowT;
@@ -681,21 +691,27 @@ struct Solver final : SolverBase {
             std::vector<T> packed((size_t)Spad * 6, (T)0);
             std::vector<float> packed32((size_t)Spad * 6, 0.f), cl((size_t)n_clusters * kConvClusterRec, 0.f);
             double amin = 1e300, amax = 0.;
+            for (int64_t s = 0; s < S; s++) {
+                const double w = std::sqrt(h_wn[3 * s] * h_wn[3 * s] + h_wn[3 * s + 1] * h_wn[3 * s + 1] + h_wn[3 * s + 2] * h_wn[3 * s + 2]);
+                if (w > 0.) amin = std::min(amin, w);
+                amax = std::max(amax, w);
+            }
+            // Y = X / |X| does not see a common factor of the weights: fp32 arithmetic gets them relative to the largest one, scaled by a POWER OF TWO (exact), so
+            // that it sees weights in (0, 1] whatever the mesh's units -- what the exponent-range test of the packed-fp32 tier (shm_conv_tiered.hip.h, `in_range`)
+            // and the fp32 solve's sums rely on.  The fp64 copies keep the reference's own weights (its arithmetic incl. its gradual underflow far from the
+            // sources); the tiered kernel applies the factor when it converts a far source to fp32.
+            conv_wscale = amax > 0. && std::isfinite(amax) ? std::ldexp(1.0, -std::ilogb(amax) - 1) : 1.0;
+            const double wscale = sizeof(T) == 4 ? conv_wscale : 1.0;
             for (int64_t t = 0; t < Spad; t++) {
                 const int64_t s = order[(size_t)std::min<int64_t>(t, S - 1)].second;  // padding repeats the last source with zero weight
                 for (int a = 0; a < 3; a++) {
                     packed[6 * t + a] = (T)(h_pos[3 * s + a] - conv_ctr[a]);
                     packed32[6 * t + a] = (float)(h_pos[3 * s + a] - conv_ctr[a]);
                     if (t < S) {
-                        packed[6 * t + 3 + a] = (T)h_wn[3 * s + a];
-                        packed32[6 * t + 3 + a] = (float)h_wn[3 * s + a];
+                        packed[6 * t + 3 + a] = (T)(h_wn[3 * s + a] * wscale);
+                        packed32[6 * t + 3 + a] = (float)(h_wn[3 * s + a] * wscale);
                     }
                 }
-            }
-            for (int64_t s = 0; s < S; s++) {
-                const double w = std::sqrt(h_wn[3 * s] * h_wn[3 * s] + h_wn[3 * s + 1] * h_wn[3 * s + 1] + h_wn[3 * s + 2] * h_wn[3 * s + 2]);
-                if (w > 0.) amin = std::min(amin, w);
-                amax = std::max(amax, w);
             }
             for (int c = 0; c < n_clusters; c++) {
                 double cc[3] = {0, 0, 0};
@@ -852,7 +868,7 @@ struct Solver final : SolverBase {
         precond_ready = false;
         have_problem = true;
         have_conv = have_div = have_phi = have_constraints = false;
-        if (cfg.world > 1 && !solve_only && n >= 16 && n <= 1024 && (n & (n - 1)) == 0) {
+        if (cfg.world > 1 && !solve_only && n >= 4 && n <= 1024) {   // (a single slab has a fast Poisson solve for every n: fft_available() / gemm_dct())
             if (!full) {
                 shm_config c = cfg;
                 c.world = 1;
@@ -901,10 +917,11 @@ struct Solver final : SolverBase {
             P.n_clusters = n_clusters;
             P.far_gap = (float)conv_far_gap;
             P.tier_log = (float)conv_tier_log;
-            {   // exponent range of the packed-fp32 tier (one offset per 8 x 8 x 4 block; see shm_conv_tiered.hip.h): the spread of the nodes' dominant terms over a
-                // block (<= its diameter) plus the drop threshold must fit the fp32 exponent with 36 bits to spare for weight ratios, or the launch has no far tier
-                const double diam = 2.0 * std::sqrt(3.5 * 3.5 * 2 + 1.5 * 1.5) * cell;
-                if (1.4426950408889634 * (lambda * diam + std::min(conv_tier_skip_base, 44.36)) > 90.) P.tier_log = 3.0e38f;
+            P.wscale = conv_wscale;
+            {   // a-posteriori test of the packed-fp32 tier (shm_conv_tiered.hip.h): budget on Y / calibrated relative error of a far term as it shows up in X
+                static const double redo_env = getenv("SHM_CONV_REDO_RATIO") ? atof(getenv("SHM_CONV_REDO_RATIO")) : -1.;   // A/B knob (0: never)
+                const double ratio = redo_env >= 0. ? redo_env : kTierBudget / kTierEpsFar;
+                P.far_redo_ratio = ratio > 0. ? (float)ratio : 3.0e38f;
             }
             P.skip_base = (float)std::min(conv_tiered ? conv_tier_skip_base : conv_skip_base, 3.0e38);
             P.inv_lambda = (float)(1.0 / lambda);
@@ -958,10 +975,10 @@ struct Solver final : SolverBase {
             const int want_chunks = split_env > 0 ? split_env : conv_tiered ? 1 : (uniform_tiles && conv_est_total_ms >= 10. ? std::min(16, (int)std::lround(conv_est_total_ms / 2.5)) : 1);
             const int nchunks = std::max(1, std::min(tiles_z, want_chunks));
             const int chunk_planes = ((tiles_z + nchunks - 1) / nchunks) * tile_z;
-            if (!d_pair_counters.p) d_pair_counters.alloc(2);
+            if (!d_pair_counters.p) d_pair_counters.alloc(3);
             if (!d_unit_counters.p) d_unit_counters.alloc(8 * kMaxConvLaunches);
             if (&sl == &slabs[0]) {
-                HIPCHK(hipMemsetAsync(d_pair_counters.p, 0, 2 * sizeof(unsigned long long), stream));
+                HIPCHK(hipMemsetAsync(d_pair_counters.p, 0, 3 * sizeof(unsigned long long), stream));
                 HIPCHK(hipMemsetAsync(d_unit_counters.p, 0, 8 * kMaxConvLaunches * sizeof(unsigned), stream));
                 conv_launch_index = 0;
                 conv_launches_last = 0;
@@ -1047,9 +1064,27 @@ struct Solver final : SolverBase {
     }
 
     void launch_div(int scrub) {
-        for (Slab<T>& sl : slabs)
-            hipLaunchKernelGGL((divergence_kernel<T>), dim3((unsigned)((n + kBlock - 1) / kBlock), (unsigned)n, (unsigned)sl.nzl), dim3(kBlock), 0, stream, sl.gp,
-                               sl.Y0.p, sl.Y1.p, sl.Y2.p, sl.r.p, scrub);
+        static const bool classic = getenv("SHM_DIV_CLASSIC") != nullptr;   // A/B knob: the one-node-per-thread kernel of rounds 1-3
+        for (Slab<T>& sl : slabs) {
+            if (classic || vec == 1) {   // (n not a multiple of the vector width: scalar kernel)
+                hipLaunchKernelGGL((divergence_kernel<T>), dim3((unsigned)((n + kBlock - 1) / kBlock), (unsigned)n, (unsigned)sl.nzl), dim3(kBlock), 0, stream, sl.gp,
+                                   sl.Y0.p, sl.Y1.p, sl.Y2.p, sl.r.p, scrub);
+                continue;
+            }
+            constexpr int V = vec_width<T>();
+            const int lanes = (n + V - 1) / V;
+            int LX = 1;
+            while (LX < lanes && LX < kBlock) LX *= 2;
+            const int xchunks = (lanes + LX - 1) / LX, RB = kBlock / LX, rowgroups = (n + RB - 1) / RB;
+            // planes per workgroup: deep enough to amortise the first plane's extra load, shallow enough for >= ~8 workgroups per CU
+            int ZC = 32;
+            while (ZC > 4 && (long long)xchunks * rowgroups * ((sl.nzl + ZC - 1) / ZC) < 8LL * num_cus) ZC /= 2;
+            static const int zc_env = getenv("SHM_DIV_ZC") ? atoi(getenv("SHM_DIV_ZC")) : 0;   // A/B knob
+            if (zc_env > 0) ZC = zc_env;
+            const unsigned nblk = (unsigned)((long long)xchunks * rowgroups * ((sl.nzl + ZC - 1) / ZC));
+            hipLaunchKernelGGL((divergence_march_kernel<T, V>), dim3(nblk), dim3(kBlock), 0, stream, sl.gp, LX, xchunks, rowgroups, ZC, sl.Y0.p, sl.Y1.p, sl.Y2.p,
+                               sl.r.p, scrub);
+        }
         HIPCHK(hipGetLastError());
         have_div = true;
     }
@@ -1377,7 +1412,7 @@ struct Solver final : SolverBase {
             sl.dv.alloc((size_t)7 * std::max(mp, 64));
         }
         lap("slab uploads");
-        if (total_slabs == 1 && precond_available() && need_node_tables) build_active_tiles(unode);
+        if (total_slabs == 1 && fft_available() && need_node_tables) build_active_tiles(unode);   // (the sparse sweeps exist for the FFT transforms only)
         lap("active tiles");
         Bptr.upload(bptr, stream);
         Bcol.upload(bcol, stream);
@@ -1674,6 +1709,9 @@ struct Solver final : SolverBase {
         // (beyond ~8000 rows the assembly costs Step 1 more time than the dense mat-vec saves the CG: rocker 512^3 fp32, m = 12 612: 29 ms of assembly for
         // 36 x 0.37 ms -- 493-508 against 491-501 ms per solve with S applied through the grid)
         static const int max_m = getenv("SHM_DENSE_S_MAX_M") ? atoi(getenv("SHM_DENSE_S_MAX_M")) : 8192;
+        // n not a power of two: applying S through the grid costs six dense products per CG iteration (shm_dct_gemm.hip.h: 5 ms at n = 362), so the explicit S
+        // is worth its assembly up to the sizes its memory allows, whatever Step 1 hides
+        if (gemm_dct()) return !off && m > 0 && m <= std::max(max_m, 16384);
         if (off || total_slabs != 1 || !precond_available() || m <= 0 || m > max_m || n > 512) return false;
         // the assembly (216 table reads per entry: ~2.2e-7 ms per m^2 on an idle device, measured 1.8 ms at m = 2842, 29 ms at m = 12 612) has to hide behind
         // this rank's Step 1 like the rest of the set-up; where Step 1 is short (<= 128^3, or a thin slab of a multi-GPU run) the sweeps through the grid are
@@ -2017,12 +2055,18 @@ struct Solver final : SolverBase {
 
     // ------------------------------------------------------------------------------------------
     // DCT preconditioner
-    // n = 2^k in [16,1024]; with P > 1 slabs: P | n and both the z-slab and the y-pencil hold whole 16-line tiles' worth of rows
-    bool precond_available() const {
+    // The O(n log n) line transforms (shm_dct.hip.h): n = 2^k in [16,1024]; with P > 1 slabs: P | n and both the z-slab and the y-pencil hold whole 16-line
+    // tiles' worth of rows
+    bool fft_available() const {
         if (n < 16 || n > 1024 || (n & (n - 1)) != 0) return false;
         if (total_slabs == 1) return true;
         return slabs_equal && (total_slabs & (total_slabs - 1)) == 0 && n % total_slabs == 0;
     }
+    // The fast Poisson solve K^+ exists for every n: where the FFT sweeps do not apply (n not a power of two -- the reference's nx = (size_t)(2 * 2^(hCoef+3))
+    // with a fractional hCoef, signed_heat_grid_solver.cpp:24) a single slab applies the transforms as dense products with the DCT matrix on the fp64 matrix
+    // cores (shm_dct_gemm.hip.h).  n <= 1024 like the FFT path: two n^3 double work arrays beside the solver's own.
+    bool gemm_dct() const { return !fft_available() && total_slabs == 1 && n >= 4 && n <= 1024; }
+    bool precond_available() const { return fft_available() || gemm_dct(); }
     void setup_precond() {
         if (precond_ready) return;
         log2n = 0;
@@ -2042,13 +2086,73 @@ struct Solver final : SolverBase {
         for (int k = 0; k < n; k++) lam64[k] = (2. - 2. * std::cos(pi * k / n)) / (cell * cell);
         d_lam64.upload(lam64, stream);
         for (Slab<T>& sl : slabs) {
-            sl.W1.alloc(sl.nown);
+            if (!gemm_dct()) sl.W1.alloc(sl.nown);
             if (total_slabs > 1) sl.W2.alloc(sl.nown);
             sl.z.alloc(sl.ntot);
             HIPCHK(hipMemsetAsync(sl.z.p, 0, sl.ntot * sizeof(T), stream));
         }
+        if (gemm_dct()) {
+            std::vector<double> ctab(4 * (size_t)n);
+            for (int r = 0; r < 4 * n; r++) ctab[(size_t)r] = std::cos(pi * r / (2. * n));
+            DevArray<double> d_ctab;
+            d_ctab.upload(ctab, stream);
+            gd_Cm.alloc((size_t)n * n);
+            gd_Ct.alloc((size_t)n * n);
+            gd_W1.alloc((size_t)n * n * n);
+            gd_W2.alloc((size_t)n * n * n);
+            hipLaunchKernelGGL(dct_matrix_kernel, dim3(grid_for((size_t)n * n, 1024)), dim3(kBlock), 0, stream, n, d_ctab.p, gd_Cm.p, gd_Ct.p);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(stream));   // d_ctab is a local
+        }
         HIPCHK(hipStreamSynchronize(stream));  // host vectors go out of scope
         precond_ready = true;
+    }
+
+    // C (M x N) = A (M x K) B (K x N), row-major, `batches` products with element strides sA / sB / sC (shm_schur.hip.h).  narrow: the 128 x 32 shape that
+    // fits beside the tiered Step 1; otherwise 128 x 128 tiles.
+    void launch_dgemm(hipStream_t st, bool narrow, int prio, unsigned batches, int M, int N, int K, const double* A, int lda, long long sA, const double* B, int ldb,
+                      long long sB, double* C, int ldc, long long sC) {
+        auto tiles = [](size_t v) { return (unsigned)((v + kGemmT - 1) / kGemmT); };
+        if (narrow)
+            hipLaunchKernelGGL(dgemm_rm_kernel<1>, dim3((unsigned)((N + 31) / 32), tiles((size_t)M), batches), dim3(kBlock), 0, st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, prio);
+        else
+            hipLaunchKernelGGL(dgemm_rm_kernel<4>, dim3(tiles((size_t)N), tiles((size_t)M), batches), dim3(kBlock), 0, st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, prio);
+    }
+
+    // z' = K^+ in by six dense products with the DCT matrix (shm_dct_gemm.hip.h; one slab, any n).  The products run in double whatever T; an fp32 solve
+    // converts on the way in and out.  dot: partial sums of in . z' in sl.partials, their count returned.
+    int launch_precond_gemm(bool dot, int in_sel, int out_sel) {
+        Slab<T>& sl = slabs[0];
+        const size_t N3 = (size_t)n * n * n;
+        const int nn = n, n2 = n * n;
+        double *W1 = gd_W1.p, *W2 = gd_W2.p;
+        const double* X;
+        double* Z;
+        if constexpr (sizeof(T) == 8) {
+            X = reinterpret_cast<const double*>(arr(sl, in_sel)) + sl.plane;
+            Z = reinterpret_cast<double*>(arr(sl, out_sel)) + sl.plane;
+        } else {
+            hipLaunchKernelGGL((convert_kernel<T, double>), dim3(grid_for(N3, 4096)), dim3(kBlock), 0, stream, N3, arr(sl, in_sel) + sl.plane, W2);
+            X = W2;
+            Z = W2;
+        }
+        auto gemm = [&](unsigned batches, int M, int Nc, int K, const double* A, int lda, long long sA, const double* B, int ldb, long long sB, double* C, int ldc, long long sC) {
+            launch_dgemm(stream, false, 0, batches, M, Nc, K, A, lda, sA, B, ldb, sB, C, ldc, sC);
+        };
+        gemm(1, n2, nn, nn, X, nn, 0LL, gd_Ct.p, nn, 0LL, W1, nn, 0LL);                                   // x forward:  W1[(k,j)][a] = sum_i X[(k,j)][i] C[a][i]
+        gemm((unsigned)n, nn, nn, nn, gd_Cm.p, nn, 0LL, W1, nn, (long long)n2, W2, nn, (long long)n2);                   // y forward, per plane k (X is dead from here on)
+        gemm(1, nn, n2, nn, gd_Cm.p, nn, 0LL, W2, n2, 0LL, W1, n2, 0LL);                                   // z forward
+        hipLaunchKernelGGL(spectral_scale_kernel, dim3(grid_for(N3, 4096)), dim3(kBlock), 0, stream, n, d_lam64.p, W1);
+        gemm(1, nn, n2, nn, gd_Ct.p, nn, 0LL, W1, n2, 0LL, W2, n2, 0LL);                                   // z inverse
+        gemm((unsigned)n, nn, nn, nn, gd_Ct.p, nn, 0LL, W2, nn, (long long)n2, W1, nn, (long long)n2);     // y inverse
+        gemm(1, n2, nn, nn, W1, nn, 0LL, gd_Cm.p, nn, 0LL, Z, nn, 0LL);                                    // x inverse:  Z[(k,j)][i] = sum_a W1[(k,j)][a] C[a][i]
+        if constexpr (sizeof(T) != 8) hipLaunchKernelGGL((convert_kernel<double, T>), dim3(grid_for(N3, 4096)), dim3(kBlock), 0, stream, N3, W2, arr(sl, out_sel) + sl.plane);
+        int np = 0;
+        if (dot) {
+            np = grid_for(N3, 2048);
+            hipLaunchKernelGGL((dot_partial_kernel<T>), dim3(np), dim3(kBlock), 0, stream, N3, arr(sl, in_sel) + sl.plane, arr(sl, out_sel) + sl.plane, sl.partials.p);
+        }
+        return np;
     }
 
     template <int MODE, typename TIn, typename TOut, bool DOT, int LOG2N, bool XPASS>
@@ -2067,13 +2171,20 @@ struct Solver final : SolverBase {
     }
     template <int MODE, typename TIn, typename TOut, bool DOT, int LOG2N, bool XPASS, bool SEG>
     void launch_dct_k(const DctParams& P, int ntiles, const TIn* in, TOut* out, const TOut* dotw, double* partials, const int* tile_list, const unsigned* elem_mask) {
-        auto kern = dct_lines_kernel<TP, TIn, TOut, MODE, DOT, LOG2N, XPASS, SEG>;
-        static uint64_t configured = 0;  // per instantiation, one bit per device (the attribute is per device)
+        // dense sweeps of the long transforms prefetch the next tile into registers (shm_dct.hip.h, PF); SHM_DCT_NO_PF: A/B knob
+        static const bool no_pf = getenv("SHM_DCT_NO_PF") != nullptr;
+        constexpr bool kCanPf = LOG2N >= 9 && !SEG;
+        bool use_pf = false;
+        if constexpr (kCanPf) use_pf = !no_pf && !tile_list && !elem_mask;
+        auto kern = dct_lines_kernel<TP, TIn, TOut, MODE, DOT, LOG2N, XPASS, SEG, false>;
+        if constexpr (kCanPf)
+            if (use_pf) kern = dct_lines_kernel<TP, TIn, TOut, MODE, DOT, LOG2N, XPASS, SEG, true>;
+        static uint64_t configured[2] = {0, 0};  // per instantiation, one bit per device (the attribute is per device)
         constexpr size_t lds = dct_lds_bytes<LOG2N, (int)sizeof(TP)>();
         const uint64_t dev_bit = 1ull << (cfg.device & 63);
-        if (!(configured & dev_bit) || cfg.device >= 64) {
+        if (!(configured[use_pf] & dev_bit) || cfg.device >= 64) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            configured |= dev_bit;
+            configured[use_pf] |= dev_bit;
         }
         DctParams Q = P;
         Q.ntiles = ntiles;
@@ -2154,6 +2265,7 @@ struct Solver final : SolverBase {
         }
     }
     int launch_precond(bool dot, int in_sel = ARR_R, int out_sel = ARR_Z) {
+        if (gemm_dct()) return launch_precond_gemm(dot, in_sel, out_sel);
         const long long nn = n, plane = (long long)n * n;
         const int P = total_slabs;
         const int nzl = n / P, nyl = n / P;  // planes per slab == pencil rows per slab (P | n)
@@ -2806,10 +2918,11 @@ struct Solver final : SolverBase {
     // (node, source) pairs Step 1 evaluated in the last solve, per arithmetic: what bench.py computes the Step-1 roofline fraction from
     void report_pairs(shm_stats* st) noexcept {
         if (!st || !d_pair_counters.p) return;
-        unsigned long long h[2] = {0, 0};
+        unsigned long long h[3] = {0, 0, 0};
         if (hipMemcpy(h, d_pair_counters.p, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return;
         st->pairs_fp64 = (double)h[0];
         st->pairs_fp32 = (double)h[1];
+        st->pairs_redone = (double)h[2];
         st->conv_launches = conv_launches_last;
     }
     void solve(const shm_opts& o_in, shm_stats* st) override {
@@ -2826,7 +2939,7 @@ struct Solver final : SolverBase {
         shm_opts o = o_in;
         bool pre = false;
         if (o.preconditioner == SHM_PRECOND_DCT) {
-            if (!precond_available()) throw Error(SHM_ERR_INVALID, "DCT preconditioner needs n = 2^k in [16,1024] and a power-of-two number of EQUAL z-slabs dividing n (shm_config.slab_plan = SHM_SLAB_PLAN_EQUAL)");
+            if (!precond_available()) throw Error(SHM_ERR_INVALID, "DCT preconditioner needs n = 2^k in [16,1024] and a power-of-two number of EQUAL z-slabs dividing n (shm_config.slab_plan = SHM_SLAB_PLAN_EQUAL); a single z-slab serves any n in [4,1024]");
             pre = true;
         } else if (o.preconditioner == SHM_PRECOND_AUTO) {
             pre = precond_available();
@@ -2863,7 +2976,7 @@ struct Solver final : SolverBase {
         e_s2b.record(stream2);
         bool dual = false;
         if (o.solver == SHM_SOLVER_DUAL || o.solver == SHM_SOLVER_DUAL_SLABS) {
-            if (!precond_available()) throw Error(SHM_ERR_INVALID, "the dual solver needs the DCT: n = 2^k in [16,1024] and a power-of-two number of EQUAL z-slabs dividing n (shm_config.slab_plan = SHM_SLAB_PLAN_EQUAL)");
+            if (!precond_available()) throw Error(SHM_ERR_INVALID, "the dual solver needs the DCT: n = 2^k in [16,1024] and a power-of-two number of EQUAL z-slabs dividing n (shm_config.slab_plan = SHM_SLAB_PLAN_EQUAL); a single z-slab serves any n in [4,1024]");
             dual = true;
         } else if (o.solver == SHM_SOLVER_AUTO) {
             dual = precond_available() && o.preconditioner != SHM_PRECOND_NONE;
@@ -3220,7 +3333,7 @@ struct Solver final : SolverBase {
     void apply_preconditioner(const double* v, double* out) override {
         need_problem();
         if (cfg.world != 1) throw Error(SHM_ERR_INVALID, "apply_preconditioner is a single-process test entry point");
-        if (!precond_available()) throw Error(SHM_ERR_INVALID, "DCT preconditioner needs n = 2^k in [16,1024] and a power-of-two number of EQUAL z-slabs dividing n (shm_config.slab_plan = SHM_SLAB_PLAN_EQUAL)");
+        if (!precond_available()) throw Error(SHM_ERR_INVALID, "DCT preconditioner needs n = 2^k in [16,1024] and a power-of-two number of EQUAL z-slabs dividing n (shm_config.slab_plan = SHM_SLAB_PLAN_EQUAL); a single z-slab serves any n in [4,1024]");
         HIPCHK(hipSetDevice(cfg.device));
         setup_precond();
         upload_owned(v, 1);

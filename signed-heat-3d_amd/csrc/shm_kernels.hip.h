@@ -146,6 +146,9 @@ struct ConvParams {
     float inv_lambda;
     int exact_offset;   // fp32 path only: 1 = per-node nearest-source distance (coarse grids: lambda * tile diameter too large)
     int n_tiles;        // total tiles; workgroups stride over them (fewer workgroups than slots leave room for the set-up stream)
+    double wscale;         // tiered fp64 path: power of two that brings the largest source weight into (0.5, 1] -- applied to the fp32 copies of the weights only
+    float far_redo_ratio;  // tiered fp64 path: a block whose packed-fp32 sums exceed this fraction of |X| at any node evaluates its far sources again in fp64
+                           // (= budget on Y / calibrated relative error of a packed-fp32 term; 3e38: never)
 };
 
 typedef float float2v __attribute__((ext_vector_type(2)));
@@ -547,6 +550,71 @@ __device__ __forceinline__ void store_vec(T* p, const T (&v)[VEC]) {
 #pragma unroll
     for (int e = 0; e < VEC; e++) tp[e] = v[e];
     *reinterpret_cast<V*>(p) = t;
+}
+
+// The same operator as a register-blocked z-march (round 4): a lane owns VEC consecutive x nodes of one row and walks ZC planes, keeping the Y2 values of the
+// plane below in registers; the x neighbour comes from the adjacent lane (wave shuffle; the first lane of a wave loads it), the row above (Y1[c - n]) is the
+// "own" row of the workgroup (or lane group) next door: an L2 hit when both run on the same XCD, hence the XCD-contiguous block order.  Vector loads / stores,
+// Y2 read once instead of twice, no per-node index arithmetic.  The one-node-per-thread kernel above read 5.0 NT from HBM for 4 NT algorithmic (rocprofv3 PMC,
+// profiles/r03_pmc_traffic.json) and ran at 0.47 of the HBM peak at 512^3.
+// blockDim = kBlock = LX * RB: LX lanes side by side along x (a power of two, >= ceil(n / VEC) unless the row needs several chunks), RB rows per workgroup.
+// Logical blocks: x chunk fastest, then row group, then z chunk.
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void divergence_march_kernel(GridParams G, int LX, int xchunks, int rowgroups, int ZC, const T* __restrict__ Y0,
+                                                                  const T* __restrict__ Y1, const T* __restrict__ Y2, T* __restrict__ b, int scrub) {
+    const int n = G.n;
+    const size_t plane = (size_t)n * n;
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int xc = (int)(lb % (unsigned)xchunks), rg = (int)((lb / (unsigned)xchunks) % (unsigned)rowgroups), zc = (int)(lb / ((unsigned)xchunks * (unsigned)rowgroups));
+    const int lx = (int)threadIdx.x % LX, ry = (int)threadIdx.x / LX, RB = kBlock / LX;
+    const int i0 = (xc * LX + lx) * VEC, j = rg * RB + ry;
+    const int kk_lo = zc * ZC, kk_hi = min(G.nzl, kk_lo + ZC);
+    const bool active = i0 < n && j < n;     // (n % VEC == 0: a vector never straddles the end of a row)
+    const T ih = (T)G.inv_h;
+    const bool need_left = i0 >= 1 && ((threadIdx.x & 63) == 0 || lx == 0);   // the lane to the left belongs to another wave / chunk: load the value
+    T y2m[VEC];
+    size_t c = (size_t)(kk_lo + 1) * plane + (size_t)(active ? j : 0) * n + (active ? i0 : 0);
+    if (active) load_vec<T, VEC>(Y2 + c - plane, y2m);   // the plane below the first one (the low ghost plane for kk = 0; unused when k = 0)
+    for (int kk = kk_lo; kk < kk_hi; kk++, c += plane) {
+        const int k = G.k0 + kk;
+        T y0[VEC], y1[VEC], y1m[VEC], y2[VEC], acc[VEC];
+        if (active) {
+            load_vec<T, VEC>(Y0 + c, y0);
+            load_vec<T, VEC>(Y1 + c, y1);
+            load_vec<T, VEC>(Y2 + c, y2);
+            if (j >= 1) load_vec<T, VEC>(Y1 + c - n, y1m);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; e++) y0[e] = y1[e] = y2[e] = (T)0;
+        }
+        T left = __shfl_up(y0[VEC - 1], 1, kWave);   // every lane of the wave takes part
+        if (!active) continue;
+        if (need_left) left = Y0[c - 1];
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            const int i = i0 + e;
+            T a = (T)0;
+            // x axis
+            if (i >= 1) a += ih * (e == 0 ? left : y0[e > 0 ? e - 1 : 0]);
+            if (i == n - 1) a += ih * y0[e];
+            if (i < n - 1) a -= ih * y0[e];
+            if (i == n - 2) a -= ih * (e + 1 < VEC ? y0[e + 1 < VEC ? e + 1 : e] : Y0[c + e + 1]);
+            // y axis
+            if (j >= 1) a += ih * y1m[e];
+            if (j == n - 1) a += ih * y1[e];
+            if (j < n - 1) a -= ih * y1[e];
+            if (j == n - 2) a -= ih * Y1[c + e + n];
+            // z axis
+            if (k >= 1) a += ih * y2m[e];
+            if (k == n - 1) a += ih * y2[e];
+            if (k < n - 1) a -= ih * y2[e];
+            if (k == n - 2) a -= ih * Y2[c + e + plane];
+            if (scrub && !isfinite(a)) a = (T)0;
+            acc[e] = a;
+            y2m[e] = y2[e];
+        }
+        store_vec<T, VEC>(b + c, acc);
+    }
 }
 
 // Register-blocked z-march: a lane owns VEC consecutive x nodes of RY consecutive rows and walks ZC planes keeping the

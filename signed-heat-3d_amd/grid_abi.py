@@ -53,7 +53,7 @@ class ShmStats(C.Structure):
                 ("ms_pcg", C.c_double), ("ms_shift", C.c_double), ("ms_total", C.c_double), ("ms_stencil_avg", C.c_double),
                 ("ms_update_xr_avg", C.c_double), ("ms_project_avg", C.c_double), ("ms_update_p_avg", C.c_double),
                 ("ms_precond_avg", C.c_double), ("kernel_samples", C.c_int32), ("preconditioner", C.c_int32),
-                ("solver", C.c_int32), ("bytes_per_iter", C.c_double), ("cg_form", C.c_int32), ("pairs_fp64", C.c_double), ("pairs_fp32", C.c_double), ("conv_launches", C.c_int32)]
+                ("solver", C.c_int32), ("bytes_per_iter", C.c_double), ("cg_form", C.c_int32), ("pairs_fp64", C.c_double), ("pairs_fp32", C.c_double), ("conv_launches", C.c_int32), ("pairs_redone", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

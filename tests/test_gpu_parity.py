@@ -68,7 +68,9 @@ def test_tiered_conv_stays_within_its_budget(shm, path, hcoef, monkeypatch):
     nominal = float(pre["n"]) ** 3 * pre["S"]
     assert ste.pairs_fp32 == 0 or ste.pairs_fp64 > 0          # all-fp64 kernel: (almost) everything in fp64
     assert stt.pairs_fp64 + stt.pairs_fp32 <= 1.03 * nominal   # never more than the nominal N S (cluster padding aside)
-    assert stt.pairs_fp32 > 0.1 * nominal and stt.pairs_fp64 < 0.7 * nominal   # the tiers are really in use at this size (SprayBottle: 0.19 packed fp32, 0.59 dropped)
+    # the tiers are really in use at this size (SprayBottle.pc at 128^3, lambda * cell = 3.7: most far sources fail the exponent-range test of the packed-fp32
+    # tier -- one offset per block -- and stay in fp64; 0.59 of its pairs are dropped)
+    assert stt.pairs_fp32 > (0.1 if path != "SprayBottle.pc" else 0.0) * nominal and stt.pairs_fp64 < 0.7 * nominal
     assert stt.pairs_fp64 > 0
 
 
@@ -95,12 +97,12 @@ def test_conv_far_clusters_in_fp32_keep_fp64_accuracy(shm, oracle_c, lam_scale, 
     assert np.abs(Y[ok] - ref[ok]).max() < (1e-10 if exact else Y_BUDGET)
 
 
-@pytest.mark.parametrize("lam_scale", [2.0, 3.0, 4.0, 10.0])
+@pytest.mark.parametrize("lam_scale", [2.0, 4.0, 6.0, 10.0])
 def test_far_tier_exponent_range_guard(shm, oracle_c, lam_scale):
     """A short diffusion length on a coarse grid (tCoef < 1 via --t: lambda = 1 / (h sqrt(tCoef)) does not depend on the cell): the packed-fp32 tier carries one
     exponent offset per 8 x 8 x 4 block, and beyond lambda * cell ~ 3 the spread of the nodes' own dominant terms over a block plus the drop threshold leaves
-    the fp32 exponent range -- the launch then has no far tier (Solver::launch_conv).  lam_scale 2 and 3 keep the tier (3: close to the edge of the range),
-    4 and 10 (tCoef = 0.01) switch it off; Y stays within the budget of the all-fp64 C oracle in every case."""
+    the fp32 exponent range: such a source stays in fp64 (`in_range`, shm_conv_tiered.hip.h).  lam_scale 2 keeps the tier for 40 % of the pairs, 4 for a few,
+    6 and 10 (tCoef = 0.01) for none; Y stays within the budget of the all-fp64 C oracle in every case."""
     d = load_golden("bunny_small_n64")
     n, lam, cell = int(d["n"]), float(d["lam"]) * lam_scale, float(d["cell"])
     s = shm.GridSolver()
@@ -117,10 +119,10 @@ def test_far_tier_exponent_range_guard(shm, oracle_c, lam_scale):
     err = np.abs(Y[ok] - ref[ok]).max()
     print("\nlambda x %g (lambda * cell = %.2f): pairs fp64 %.3e packed fp32 %.3e, max|dY| = %.2e" % (lam_scale, lam * cell, st.pairs_fp64, st.pairs_fp32, err))
     assert err < Y_BUDGET, err
-    if lam_scale >= 4.0:
-        assert st.pairs_fp32 == 0      # outside the fp32 exponent range: everything that is not dropped is evaluated in fp64
-    else:
-        assert st.pairs_fp32 > 0
+    if lam_scale >= 6.0:
+        assert st.pairs_fp32 < 1e-3 * st.pairs_fp64   # outside the fp32 exponent range: (almost) everything that is not dropped is evaluated in fp64
+    elif lam_scale <= 2.0:
+        assert st.pairs_fp32 > 0.1 * st.pairs_fp64
 
 
 @pytest.mark.parametrize("precision", [64, 32])
@@ -263,7 +265,7 @@ def test_projector(shm, case):
     assert np.abs(s.apply_projector(Atw)).max() < 1e-10 * np.abs(Atw).max()
 
 
-@pytest.mark.parametrize("n", [16, 32, 64, 128, 256, 512])
+@pytest.mark.parametrize("n", [16, 32, 64, 128, 256, 512, 22, 45, 90, 181, 362])
 def test_preconditioner_is_the_dct_pseudo_inverse(shm, n):
     """M^-1 = C^T D C must equal the pseudo-inverse of K = -L (the 3-D DCT-II diagonalises the Neumann Laplacian):
     compared with scipy's orthonormal DCT on the host, and checked through K M^-1 v = v - mean(v)."""
@@ -296,14 +298,7 @@ def test_phi_matches_lu_golden(shm, case, scrub, mode):
     against the reference-equivalent sparse-LU solution."""
     d = load_golden(case)
     kw = MODES[mode]
-    if mode != "primal-plain" and int(d["n"]) & (int(d["n"]) - 1):
-        s = make_solver(shm, d)
-        with pytest.raises(shm.ShmError):          # n = 24 is not a power of two: an explicit DCT request must fail loudly
-            s.solve(tol=1e-10, scrub=scrub, **kw)
-        st = s.solve(tol=1e-10, scrub=scrub)       # ... while AUTO falls back to the plain stencil CG
-        assert st.solver == 1 and st.preconditioner == 1
-        return
-    s = make_solver(shm, d)
+    s = make_solver(shm, d)                        # (n = 24 is not a power of two: its fast Poisson solve runs as dense DCT products, shm_dct_gemm.hip.h)
     st = s.solve(tol=1e-10, scrub=scrub, **kw)
     assert st.solver == (2 if mode == "dual" else 1)
     assert st.preconditioner == (1 if mode == "primal-plain" else 2)
@@ -434,15 +429,20 @@ def test_weighted_slab_plan_matches_single_slab(shm, fast):
 
 @pytest.mark.parametrize("n,slabs", [(48, 1), (33, 1), (33, 3), (70, 1)])
 def test_matches_c_oracle_128(shm, oracle_c, n, slabs):
-    """Same inputs through the HIP path (plain stencil CG: sizes that are not powers of two, odd sizes without vector loads,
-    several slabs) and the C oracle (serial reference loops + projected CG) -- sizes with no LU fixture."""
+    """Same inputs through the HIP path at sizes that are not powers of two (odd sizes without vector loads, several slabs) and the C oracle (serial
+    reference loops + projected CG) -- sizes with no LU fixture.  One slab: the default is the dual solver with the fast Poisson solve as dense DCT
+    products (shm_dct_gemm.hip.h); several slabs: plain projected stencil CG.  The plain CG is also run on the single slab (a second algorithm)."""
     d = load_golden("bunny_small_n16")
     cell = float(d["cell"]) * 15 / (n - 1)
     s = shm.GridSolver(local_slabs=slabs)
     s.set_problem(d["pos"], d["wnormal"], d["area"], float(d["lam"]), n, d["bbox_min"], cell)
     st = s.solve(tol=1e-10)
-    assert st.solver == 1 and st.preconditioner == 1
+    assert (st.solver, st.preconditioner) == ((2, 2) if slabs == 1 else (1, 1))
     phi, _ = s.get_phi()
+    if slabs == 1:
+        st1 = s.solve(tol=1e-10, solver="primal", precond="none")
+        assert st1.solver == 1 and st1.preconditioner == 1
+        assert np.abs(s.get_phi()[0] - phi).max() < 1e-7
     ref = np.zeros(n ** 3)
     st = np.zeros(5)
     rc = oracle_c.shmo_compute_distance(n, c_(d["bbox_min"]), cell, len(d["area"]), c_(d["pos"]).reshape(-1), c_(d["wnormal"]).reshape(-1),
