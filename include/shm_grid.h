@@ -163,7 +163,7 @@ typedef struct {
                                * Nominal work is N*S; the Step-1 roofline fraction is computed from these, not from N*S. */
     int32_t conv_launches;    /* kernel launches Step 1 took on this rank in the last solve (its duration ms_conv spans all of them) */
     double pairs_redone;      /* tiered Step 1: pairs first summed in packed fp32 and then evaluated AGAIN in fp64 because the a-posteriori test of their node
-                               * block failed (the packed-fp32 sums exceeded 1e-2 of |X| at a node: cancellation regions); counted in pairs_fp64 and pairs_fp32 too */
+                               * block failed (the packed-fp32 sums exceeded 3.3e-3 of |X| at a node: cancellation regions); counted in pairs_fp64 and pairs_fp32 too */
 } shm_stats;
 
 /* --- life cycle -------------------------------------------------------------------------------- */

@@ -24,7 +24,7 @@
 // 1.1e-8 ... 3.3e-8) and nowhere else (tools/tier_worst_nodes.py, profiles/r04_tier_worst_nodes.txt).  So the far loop also accumulates, per node,
 // L1_far = sum_far |w_s|_1 e^{-lambda r} / r, and when the block is done every node is tested:
 //     eps_far * L1_far  <=  budget * |X|          (P.far_redo_ratio = budget / eps_far)
-// with eps_far the calibrated relative error of a packed-fp32 term as it shows up in X (1e-6: twice the largest |dY| |X| / L1_far observed over ten data
+// with eps_far the calibrated relative error of a packed-fp32 term as it shows up in X (3e-6: five times the largest |dY| |X| / L1_far observed over ten data
 // files at up to 1024^3; the rounding errors of the terms are independent, their sum grows slower than L1_far).  A block with a failing node walks the
 // sources a second time and evaluates its far sources in fp64 on top of the near sums it already holds -- no packed-fp32 term is left in it.
 // What the far tier contributes to Y is bounded by eps32 * sum_far |term| / |X|; `tools/tier_budget.py` evaluates that on the host
@@ -95,9 +95,11 @@ __device__ __forceinline__ float uniform_f32(float v) { return __int_as_float(__
 #endif
 constexpr int kTierTX = SHM_TIER_TX, kTierTY = 64 / kTierTX;   // a wave's block of nodes is kTierTX x kTierTY x NPT (one z-column of NPT nodes per lane)
 // The budget of the tiers on the normalised field Y (what tests/test_gpu_parity.py asserts against the C oracle at BASELINE.json's full sizes), and the
-// calibrated relative error of a packed-fp32 term as it shows up in X: twice the largest max|dY| |X| / L1_far measured (4.8e-7: bunny_small 512^3,
-// profiles/r04_tier_worst_nodes.txt).  A block where eps_far L1_far > budget |X| at any node re-evaluates its far sources in fp64.
-constexpr double kTierBudget = 1.0e-8, kTierEpsFar = 1.0e-6;
+// calibrated relative error of a packed-fp32 term as it shows up in X.  Measured max|dY| |X| / L1_far (L1_far by a per-pair e^-8 rule, an upper bound of the
+// kernel's own): 4.8e-7 (bunny_small 512^3), 6e-7 (SprayBottle.pc 1024^3, lambda r = 28: the error of a term grows with lambda r); 3e-6 = five times that.
+// A block where eps_far L1_far > budget |X| at any node re-evaluates its far sources in fp64: 0.03-0.13 % of the packed-fp32 pairs on the shipped data at
+// 256^3 ... 1024^3, +0.3 % of Step 1 (profiles/r04_redo_sweep.txt: thresholds 1e-2 ... 2e-3 against max|dY| and the re-evaluated share).
+constexpr double kTierBudget = 1.0e-8, kTierEpsFar = 3.0e-6;
 constexpr int kTierCluster = 64;                    // sources per cluster = lanes per wave: one source per lane in the classification
 constexpr int kTierChunk = 4;                       // clusters per LDS fill
 constexpr int kTierFill = kTierCluster * kTierChunk;
@@ -114,13 +116,19 @@ constexpr int kTierFill = kTierCluster * kTierChunk;
 #define SHM_TIER_NEAR_UNROLL 1
 #endif
 #ifndef SHM_TIER_FAR_UNROLL
-#define SHM_TIER_FAR_UNROLL 3   // (4 until round 4; 3 keeps the kernel at 181 registers with the per-node L1 sums of the a-posteriori test: 187 with 4)
+#define SHM_TIER_FAR_UNROLL 4
 #endif
 #ifndef SHM_TIER_CHECK
 #define SHM_TIER_CHECK 1        // the a-posteriori test of the packed-fp32 sums (per-node L1 sums + second pass); 0: A/B builds only
 #endif
+#ifndef SHM_TIER_CHECK_ALL
+#define SHM_TIER_CHECK_ALL 0    // 1: the L1 sums of the a-posteriori test run over every far source; 0: over every other one, doubled
+#endif
 #ifndef SHM_TIER_LDS_FETCH
 #define SHM_TIER_LDS_FETCH 1    // the next cluster's sources travel global -> LDS directly; 0: through 12 registers per lane (rounds 2-3)
+#endif
+#ifndef SHM_TIER_FAR_STRIDE
+#define SHM_TIER_FAR_STRIDE 8   // floats per staged far source: 8 = x', y', z', |w|_1 | wx, wy, wz, pad (two 16-byte reads); 6 = x', y', z', wx, wy, wz (|w|_1 per lane)
 #endif
 #ifndef SHM_TIER_NEAR_BFS
 #define SHM_TIER_NEAR_BFS 1
@@ -141,7 +149,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
     constexpr int kNearUnroll = SHM_TIER_NEAR_UNROLL, kFarUnroll = SHM_TIER_FAR_UNROLL;
     constexpr int kPad = kNearUnroll > kFarUnroll ? kNearUnroll : kFarUnroll;   // staged entries behind the last real one: zero weight, far away -- they pad the
     __shared__ double stage64[kWaves][(kTierCluster + kPad) * 6];              // compacted lists to whole groups of sources in flight
-    __shared__ float stage32[kWaves][(kTierCluster + kPad) * 6];
+    constexpr int kFS = SHM_TIER_FAR_STRIDE;
+    __shared__ __attribute__((aligned(16))) float stage32[kWaves][(kTierCluster + kPad) * kFS];
     // the next cluster's sources travel global -> LDS directly (global_load_lds_dwordx4: three 16-byte pieces of every lane's 48-byte record, each piece
     // landing at wave base + lane * 16), not through 12 registers per lane held across the two loops: those registers are what the per-node L1 sums of the
     // a-posteriori test now live in (the kernel must stay within 184 VGPRs for the set-up kernels to run beside it)
@@ -332,8 +341,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                 } else if (to32) {
                     const int rnk = __builtin_popcountll(farmask & below);
                     // positions in units of 1 / (lambda log2 e): the far loop then gets lambda r log2 e = d2' rsq(d2') without a multiplication of its own
+#if SHM_TIER_FAR_STRIDE == 8
+                    *reinterpret_cast<float4*>(&tile32[rnk * 8]) = float4{q32[0] * lam_l2, q32[1] * lam_l2, q32[2] * lam_l2, fabsf(q32[3]) + fabsf(q32[4]) + fabsf(q32[5])};
+                    *reinterpret_cast<float4*>(&tile32[rnk * 8 + 4]) = float4{q32[3], q32[4], q32[5], 0.f};
+#else
 #pragma unroll
                     for (int a = 0; a < 6; a++) tile32[rnk * 6 + a] = a < 3 ? q32[a] * lam_l2 : q32[a];
+#endif
                 }
             }
             const int nnear = __builtin_popcountll(nearmask), nfar = __builtin_popcountll(farmask);
@@ -344,7 +358,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                     tile[(nnear + lane) * 6 + a] = pv;
                     // (the far list holds SCALED positions; an unscaled padding point would land inside the grid, where coff - r' > 0 can overflow exp2f
                     // and 0 * inf = NaN reaches the sums.  1e18 in every scaled coordinate: d2 = 3e36 is finite, r' = 1.7e18 > coff always, 2^(coff - r') = 0)
-                    tile32[(nfar + lane) * 6 + a] = a < 3 ? 1.0e18f : 0.f;
+                    tile32[(nfar + lane) * kFS + a] = a < 3 ? 1.0e18f : 0.f;
+                    if (kFS == 8 && a < 2) tile32[(nfar + lane) * kFS + 6 + a] = 0.f;
                 }
             }
             cnt_near += (unsigned)nnear;
@@ -396,13 +411,22 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
 #pragma unroll
                 for (int u = 0; u < kFarUnroll; u++) {
                     const int s = i0 + u;
-                    const float sz = tile32[6 * s + 2];
+#if SHM_TIER_FAR_STRIDE == 8
+                    const float4 pa = *reinterpret_cast<const float4*>(&tile32[8 * s]), pb = *reinterpret_cast<const float4*>(&tile32[8 * s + 4]);
+                    const float wx = pb.x, wy = pb.y, wz = pb.z;
+#if SHM_TIER_CHECK
+                    const float wl1 = pa.w;
+#endif
+                    const float dz0 = qz0 - pa.z;
+                    const float dx = qx - pa.x, dy = qy - pa.y;   // (scaled coordinates: qx, qy, qz and the staged positions are x lambda log2 e)
+#else
                     const float wx = tile32[6 * s + 3], wy = tile32[6 * s + 4], wz = tile32[6 * s + 5];
 #if SHM_TIER_CHECK
                     const float wl1 = fabsf(wx) + fabsf(wy) + fabsf(wz);
 #endif
-                    const float dz0 = qz0 - sz;
-                    const float dx = qx - tile32[6 * s], dy = qy - tile32[6 * s + 1];   // (scaled coordinates: qx, qy, qz and the staged positions are x lambda log2 e)
+                    const float dz0 = qz0 - tile32[6 * s + 2];
+                    const float dx = qx - tile32[6 * s], dy = qy - tile32[6 * s + 1];
+#endif
                     const float dxy2 = dx * dx + dy * dy;
 #pragma unroll
                     for (int e = 0; e < NPT; e += 2) {
@@ -417,7 +441,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                         a = __builtin_elementwise_fma(float2v{wy, wy}, g, float2v{fy[e], fy[e + 1]}); fy[e] = a.x; fy[e + 1] = a.y;
                         a = __builtin_elementwise_fma(float2v{wz, wz}, g, float2v{fz[e], fz[e + 1]}); fz[e] = a.x; fz[e + 1] = a.y;
 #if SHM_TIER_CHECK
-                        a = __builtin_elementwise_fma(float2v{wl1, wl1}, g, float2v{fl[e], fl[e + 1]}); fl[e] = a.x; fl[e + 1] = a.y;
+                        // (every other far source of the compacted list, counted twice: the list follows the Morton order of the sources, neighbours in it are
+                        // neighbours in space with terms of like size, and the threshold carries a factor of five -- half the cost of the sum)
+                        if (SHM_TIER_CHECK_ALL || (u & 1) == 0) { a = __builtin_elementwise_fma(float2v{wl1, wl1}, g, float2v{fl[e], fl[e + 1]}); fl[e] = a.x; fl[e + 1] = a.y; }
 #endif
                     }
                 }
@@ -431,7 +457,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
 #pragma unroll
             for (int e = 0; e < NPT; e++) {
                 const double x0 = ax[e] + (double)fx[e] * e0, x1 = ay[e] + (double)fy[e] * e0, x2 = az[e] + (double)fz[e] * e0;
-                fail = fail || (live_xy && kk0 + e < P.kk_end && (double)fl[e] * e0 > (double)P.far_redo_ratio * sqrt(x0 * x0 + x1 * x1 + x2 * x2));
+                fail = fail || (live_xy && kk0 + e < P.kk_end && (double)fl[e] * (SHM_TIER_CHECK_ALL ? 1.0 : 2.0) * e0 > (double)P.far_redo_ratio * sqrt(x0 * x0 + x1 * x1 + x2 * x2));
             }
             if (__ballot(fail) == 0ull) break;
 #pragma unroll

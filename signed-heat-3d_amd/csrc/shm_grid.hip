@@ -1076,9 +1076,9 @@ struct Solver final : SolverBase {
             int LX = 1;
             while (LX < lanes && LX < kBlock) LX *= 2;
             const int xchunks = (lanes + LX - 1) / LX, RB = kBlock / LX, rowgroups = (n + RB - 1) / RB;
-            // planes per workgroup: deep enough to amortise the first plane's extra load, shallow enough for >= ~8 workgroups per CU
-            int ZC = 32;
-            while (ZC > 4 && (long long)xchunks * rowgroups * ((sl.nzl + ZC - 1) / ZC) < 8LL * num_cus) ZC /= 2;
+            // planes per workgroup: 4 measured best at 256^3 and 512^3 in both precisions (512^3 fp64: 0.79 ms against 0.84 with 32 and 0.80 with 2 --
+            // many short marches keep more loads in flight than few deep ones; the first plane's extra load is a fifth of a march)
+            int ZC = 4;
             static const int zc_env = getenv("SHM_DIV_ZC") ? atoi(getenv("SHM_DIV_ZC")) : 0;   // A/B knob
             if (zc_env > 0) ZC = zc_env;
             const unsigned nblk = (unsigned)((long long)xchunks * rowgroups * ((sl.nzl + ZC - 1) / ZC));
@@ -2171,9 +2171,15 @@ struct Solver final : SolverBase {
     }
     template <int MODE, typename TIn, typename TOut, bool DOT, int LOG2N, bool XPASS, bool SEG>
     void launch_dct_k(const DctParams& P, int ntiles, const TIn* in, TOut* out, const TOut* dotw, double* partials, const int* tile_list, const unsigned* elem_mask) {
-        // dense sweeps of the long transforms prefetch the next tile into registers (shm_dct.hip.h, PF); SHM_DCT_NO_PF: A/B knob
+        // Prefetching variant of the dense sweeps (shm_dct.hip.h, PF: the next tile's loads in flight under this tile's FFT): measured SLOWER than two or three
+        // plain workgroups per CU out of phase -- 512^3 fp64 0.466 -> 0.449 of the HBM peak, fp32 0.447 -> 0.390 (the 16-32 registers of the prefetch cost a
+        // workgroup of occupancy in three of the five sweeps; profiles/r04_dct_prefetch_rejected.txt) -- so it is compiled only into -DSHM_DCT_PF A/B builds
         static const bool no_pf = getenv("SHM_DCT_NO_PF") != nullptr;
+#ifdef SHM_DCT_PF
         constexpr bool kCanPf = LOG2N >= 9 && !SEG;
+#else
+        constexpr bool kCanPf = false;
+#endif
         bool use_pf = false;
         if constexpr (kCanPf) use_pf = !no_pf && !tile_list && !elem_mask;
         auto kern = dct_lines_kernel<TP, TIn, TOut, MODE, DOT, LOG2N, XPASS, SEG, false>;

@@ -197,7 +197,7 @@ def test_kernel_register_schedules():
     # the tiered fp64 Step 1 must leave room on every SIMD for a wave of the set-up kernels (two of its waves + one of theirs <= 512 registers, LDS likewise):
     # that is what lets the constraint set-up run WHILE Step 1 runs instead of in the gaps between its launches
     tier = by_name["void shm::conv_tiered_kernel<4>"]
-    assert tier["VGPRs"] <= 184 and tier["LDS Size"] <= 48 * 1024, tier      # (two of its workgroups per CU + a set-up workgroup of <= 40 KB: 136 of 160 KB)
+    assert tier["VGPRs"] <= 184 and tier["LDS Size"] <= 52 * 1024, tier      # (two of its workgroups per CU + a set-up workgroup of <= 40 KB: 144 of 160 KB)
     room = 512 - 2 * ((tier["VGPRs"] + 7) // 8 * 8)
     for k in ("void shm::dgemm_rm_kernel<1>", "shm::gj_pivot_block4_kernel", "shm::gj_panels_kernel", "void shm::gj_update_kernel<0>", "shm::schur_assemble_kernel", "shm::green_symbol_kernel"):
         v = by_name[k]

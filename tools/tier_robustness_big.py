@@ -19,6 +19,9 @@ CASES = [("bunny_small.obj", 4.0), ("knot.obj", 4.0), ("bunny_small.obj", 5.0), 
          ("SprayBottle.pc", 5.0), ("SprayBottle.pc", 6.0), ("knot.obj", 6.0)]
 if "--skip-1024" in sys.argv:
     CASES = [c for c in CASES if c[1] < 6.0]
+if "--cases" in sys.argv:   # --cases file hCoef file hCoef ...
+    a = sys.argv[sys.argv.index("--cases") + 1:]
+    CASES = [(a[i], float(a[i + 1])) for i in range(0, len(a) - 1, 2)]
 worst = 0.0
 for f, hc in CASES:
     pre = HostSolver(os.path.join(ROOT, "data", f)).preprocess(hCoef=hc)
