@@ -58,7 +58,11 @@ typedef struct {
     int32_t slab_plan;   /* SHM_SLAB_PLAN_EQUAL (0): n / slabs planes each (shm_plan_slab).  SHM_SLAB_PLAN_STEP1: planes weighted by the Step-1 work the
                           * culling / precision tiers leave in them (shm_step1_plane_weights + shm_plan_slab_weighted; every rank derives the same plan from
                           * the sources).  The weighted plan serves the default multi-rank solve (Steps 1-2 on slabs, D^T Y gathered, whole-grid dual solve)
-                          * and the plain stencil CG; the slab-distributed transforms (DUAL_SLABS, PRIMAL + DCT) need equal slabs and are refused with it. */
+                          * and the plain stencil CG; the slab-distributed transforms (DUAL_SLABS, PRIMAL + DCT) need equal slabs and are refused with it:
+                          * their two all-to-alls turn P z-slabs into P y-pencils by exchanging P x P congruent blocks of (n/P) x (n/P) x n elements, addressed
+                          * in the sweeps by shift / mask (segment = n/P rows, a power of two).  Unequal slabs would need unequal pencils, per-pair counts in the
+                          * exchange and division-based addressing in the y sweeps -- for a solve phase that is 3-10 % of a multi-rank solve, while the weighted
+                          * plan exists to balance Step 1 (80-97 %).  A caller that wants both runs the default (gathered) solve, which has both. */
 } shm_config;
 enum { SHM_SLAB_PLAN_EQUAL = 0, SHM_SLAB_PLAN_STEP1 = 1 };
 

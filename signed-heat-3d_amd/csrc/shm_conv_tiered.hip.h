@@ -122,7 +122,7 @@ constexpr int kTierFill = kTierCluster * kTierChunk;
 #define SHM_TIER_CHECK 1        // the a-posteriori test of the packed-fp32 sums (per-node L1 sums + second pass); 0: A/B builds only
 #endif
 #ifndef SHM_TIER_CHECK_ALL
-#define SHM_TIER_CHECK_ALL 0    // 1: the L1 sums of the a-posteriori test run over every far source; 0: over every other one, doubled
+#define SHM_TIER_CHECK_ALL 1    // 1: the L1 sums of the a-posteriori test run over every far source; 0 (A/B: -0.2 ms of 27.9 at 256^3): over every other one, doubled
 #endif
 #ifndef SHM_TIER_LDS_FETCH
 #define SHM_TIER_LDS_FETCH 1    // the next cluster's sources travel global -> LDS directly; 0: through 12 registers per lane (rounds 2-3)
@@ -441,8 +441,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                         a = __builtin_elementwise_fma(float2v{wy, wy}, g, float2v{fy[e], fy[e + 1]}); fy[e] = a.x; fy[e + 1] = a.y;
                         a = __builtin_elementwise_fma(float2v{wz, wz}, g, float2v{fz[e], fz[e + 1]}); fz[e] = a.x; fz[e + 1] = a.y;
 #if SHM_TIER_CHECK
-                        // (every other far source of the compacted list, counted twice: the list follows the Morton order of the sources, neighbours in it are
-                        // neighbours in space with terms of like size, and the threshold carries a factor of five -- half the cost of the sum)
                         if (SHM_TIER_CHECK_ALL || (u & 1) == 0) { a = __builtin_elementwise_fma(float2v{wl1, wl1}, g, float2v{fl[e], fl[e + 1]}); fl[e] = a.x; fl[e + 1] = a.y; }
 #endif
                     }

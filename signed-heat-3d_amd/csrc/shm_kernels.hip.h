@@ -552,9 +552,6 @@ __device__ __forceinline__ void store_vec(T* p, const T (&v)[VEC]) {
     *reinterpret_cast<V*>(p) = t;
 }
 
-template <typename T, int VEC> __device__ __forceinline__ void load_vec_nt(const T* p, T (&v)[VEC]);    // (shm_cg_fused.hip.h)
-template <typename T, int VEC> __device__ __forceinline__ void store_vec_nt(T* p, const T (&v)[VEC]);
-
 // The same operator as a register-blocked z-march (round 4): a lane owns VEC consecutive x nodes of one row and walks ZC planes, keeping the Y2 values of the
 // plane below in registers; the x neighbour comes from the adjacent lane (wave shuffle; the first lane of a wave loads it), the row above (Y1[c - n]) is the
 // "own" row of the workgroup (or lane group) next door: an L2 hit when both run on the same XCD, hence the XCD-contiguous block order.  Vector loads / stores,
@@ -582,15 +579,9 @@ __global__ __launch_bounds__(kBlock) void divergence_march_kernel(GridParams G, 
         const int k = G.k0 + kk;
         T y0[VEC], y1[VEC], y1m[VEC], y2[VEC], acc[VEC];
         if (active) {
-#ifdef SHM_DIV_NT   // A/B: Y0 / Y2 (read once) and b (written once) with non-temporal accesses
-            load_vec_nt<T, VEC>(Y0 + c, y0);
-            load_vec<T, VEC>(Y1 + c, y1);
-            load_vec_nt<T, VEC>(Y2 + c, y2);
-#else
-            load_vec<T, VEC>(Y0 + c, y0);
+            load_vec<T, VEC>(Y0 + c, y0);   // (non-temporal loads of Y0 / Y2 and stores of b: measured no faster, 0.85 against 0.83 ms at 512^3 fp64)
             load_vec<T, VEC>(Y1 + c, y1);
             load_vec<T, VEC>(Y2 + c, y2);
-#endif
             if (j >= 1) load_vec<T, VEC>(Y1 + c - n, y1m);
         } else {
 #pragma unroll
@@ -622,11 +613,7 @@ __global__ __launch_bounds__(kBlock) void divergence_march_kernel(GridParams G, 
             acc[e] = a;
             y2m[e] = y2[e];
         }
-#ifdef SHM_DIV_NT
-        store_vec_nt<T, VEC>(b + c, acc);
-#else
         store_vec<T, VEC>(b + c, acc);
-#endif
     }
 }
 
