@@ -99,6 +99,8 @@ constexpr int kTierTX = SHM_TIER_TX, kTierTY = 64 / kTierTX;   // a wave's block
 // kernel's own): 4.8e-7 (bunny_small 512^3), 6e-7 (SprayBottle.pc 1024^3, lambda r = 28: the error of a term grows with lambda r); 3e-6 = five times that.
 // A block where eps_far L1_far > budget |X| at any node re-evaluates its far sources in fp64: 0.03-0.13 % of the packed-fp32 pairs on the shipped data at
 // 256^3 ... 1024^3, +0.3 % of Step 1 (profiles/r04_redo_sweep.txt: thresholds 1e-2 ... 2e-3 against max|dY| and the re-evaluated share).
+// (A threshold that grows with the block's exponent offset -- eps_far proportional to lambda' r, as the 1-ulp error of v_rsq_f32 suggests -- was measured
+// too: SprayBottle.pc 1024^3 8.3e-9 -> 7.7e-9 for +9 % of its Step 1, knot 1024^3 +6.5 %; profiles/r04_eps_sweep.txt.  Not adopted.)
 constexpr double kTierBudget = 1.0e-8, kTierEpsFar = 3.0e-6;
 constexpr int kTierCluster = 64;                    // sources per cluster = lanes per wave: one source per lane in the classification
 constexpr int kTierChunk = 4;                       // clusters per LDS fill

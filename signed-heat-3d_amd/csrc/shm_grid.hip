@@ -443,6 +443,7 @@ struct Slab {
     size_t plane = 0, nown = 0, ntot = 0;
     DevArray<T> Y0, Y1, Y2, r /* also divYt */, x, p, q /* also phi */, z /* preconditioned residual (DCT path only) */;
     DevArray<double> partials, red /* [1+m] */, pq /* [1] */, u /* [m] */, sc;
+    DevArray<unsigned> proj_ticket;   // arrival counter of the projection's u.w reduction (scatter_nodes_kernel)
     // constraint pieces restricted to owned nodes
     DevArray<int> row_ptr, ent_row, node_ptr;
     DevArray<uint32_t> ent_node, node_id;
@@ -468,6 +469,7 @@ struct Solver final : SolverBase {
     hipStream_t stream3 = nullptr;  // explicit Schur complement of the dual solver: beside the inversion of G (stream2) and Step 1 (created on first use)
     std::unique_ptr<Event> e_sch_in, e_sch_done;
     hipStream_t stream_h = nullptr;  // halo exchange of the fused primal CG, overlapped with the interior z chunks of its DIR sweep (created on first use)
+    hipStream_t stream_x = nullptr;  // x update of the fused primal CG beside the projection (one GPU; created on first use)
     int n = 0, alloc_n = -1;
     size_t N = 0;
     double cell = 0., lambda = 0.;
@@ -511,7 +513,8 @@ struct Solver final : SolverBase {
     struct TwoLevel {
         bool on = false;
         int box = 16, P = 0, nI = 0, nS = 0, nSp = 0, ysz = 0;
-        DevArray<int> ptrI, ptrS, rowsI, colsS, sepRow, adj_ptr, adj_idx, colour_list;
+        DevArray<int> ptrI, ptrS, rowsI, colsS, sepRow, adj_ptr, adj_idx, colour_list, rowBox, chunkBox, chunkCol;
+        int nChunks = 0;
         DevArray<size_t> offD, offE;
         DevArray<double> D, E, Tm, tbuf, ybuf, vS, uS;
         DevArray<float> D32, E32, T32;
@@ -602,6 +605,7 @@ struct Solver final : SolverBase {
         if (stream2) (void)hipStreamDestroy(stream2);
         if (stream3) (void)hipStreamDestroy(stream3);
         if (stream_h) (void)hipStreamDestroy(stream_h);
+        if (stream_x) (void)hipStreamDestroy(stream_x);
         if (pool_held) PinnedPool::get().release(cfg.device);
     }
 
@@ -1576,6 +1580,20 @@ struct Solver final : SolverBase {
         tl.ptrI.upload(ptrI, stream);
         tl.ptrS.upload(ptrS, stream);
         tl.rowsI.upload(rowsI, stream);
+        {   // row -> box map and the (box, 64-column chunk) list of the row- / column-parallel application kernels
+            std::vector<int> rowBox(rowsI.size()), chunkBox, chunkCol;
+            for (int a = 0; a < P; a++) {
+                for (int t = ptrI[(size_t)a]; t < ptrI[(size_t)a + 1]; t++) rowBox[(size_t)t] = a;
+                for (int l0 = 0; l0 < ptrS[(size_t)a + 1] - ptrS[(size_t)a]; l0 += kWave) {
+                    chunkBox.push_back(a);
+                    chunkCol.push_back(l0);
+                }
+            }
+            tl.nChunks = (int)chunkBox.size();
+            tl.rowBox.upload(rowBox, stream);
+            tl.chunkBox.upload(chunkBox, stream);
+            tl.chunkCol.upload(chunkCol, stream);
+        }
         tl.colsS.upload(colsS, stream);
         tl.sepRow.upload(sepRow, stream);
         tl.adj_ptr.upload(adj_ptr, stream);
@@ -1631,15 +1649,20 @@ struct Solver final : SolverBase {
             return;
         }
         const TlBoxes V = tl.view();
-        if (f32) hipLaunchKernelGGL((tl_apply_boxes_kernel<float>), dim3((unsigned)tl.P), dim3(kBlock), 0, st, V, tl.D32.p, tl.E32.p, w, tl.tbuf.p, tl.ybuf.p);
-        else hipLaunchKernelGGL((tl_apply_boxes_kernel<double>), dim3((unsigned)tl.P), dim3(kBlock), 0, st, V, tl.D.p, tl.E.p, w, tl.tbuf.p, tl.ybuf.p);
+        const unsigned grows = (unsigned)((tl.nI + kBlock / kWave - 1) / (kBlock / kWave));
+        if (f32) hipLaunchKernelGGL((tl_rows_kernel<float>), dim3(grows), dim3(kBlock), 0, st, V, tl.rowBox.p, tl.nI, tl.D32.p, w, tl.tbuf.p);
+        else hipLaunchKernelGGL((tl_rows_kernel<double>), dim3(grows), dim3(kBlock), 0, st, V, tl.rowBox.p, tl.nI, tl.D.p, w, tl.tbuf.p);
+        if (tl.nChunks > 0) {
+            if (f32) hipLaunchKernelGGL((tl_cols_kernel<float>), dim3((unsigned)tl.nChunks), dim3(kBlock), 0, st, V, tl.chunkBox.p, tl.chunkCol.p, tl.E32.p, tl.tbuf.p, tl.ybuf.p);
+            else hipLaunchKernelGGL((tl_cols_kernel<double>), dim3((unsigned)tl.nChunks), dim3(kBlock), 0, st, V, tl.chunkBox.p, tl.chunkCol.p, tl.E.p, tl.tbuf.p, tl.ybuf.p);
+        }
         hipLaunchKernelGGL(tl_gather_sep_kernel, dim3((unsigned)((tl.nS + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, tl.nS, tl.sepRow.p, tl.adj_ptr.p, tl.adj_idx.p, w,
                            tl.ybuf.p, tl.vS.p);
         if (f32) hipLaunchKernelGGL(ginv_matvec_kernel<float>, dim3(tl.nS), dim3(kBlock), 0, st, tl.nS, tl.nSp, Ginv32.p, tl.vS.p, tl.uS.p);
         else hipLaunchKernelGGL(ginv_matvec_kernel<double>, dim3(tl.nS), dim3(kBlock), 0, st, tl.nS, tl.nSp, Ginv.p, tl.vS.p, tl.uS.p);
-        const unsigned gfin = (unsigned)(tl.P + (tl.nS + kBlock - 1) / kBlock);
-        if (f32) hipLaunchKernelGGL((tl_finish_kernel<float>), dim3(gfin), dim3(kBlock), 0, st, V, tl.P, tl.nS, tl.sepRow.p, tl.T32.p, tl.tbuf.p, tl.uS.p, u);
-        else hipLaunchKernelGGL((tl_finish_kernel<double>), dim3(gfin), dim3(kBlock), 0, st, V, tl.P, tl.nS, tl.sepRow.p, tl.Tm.p, tl.tbuf.p, tl.uS.p, u);
+        const unsigned gfin = grows + (unsigned)((tl.nS + kBlock - 1) / kBlock);
+        if (f32) hipLaunchKernelGGL((tl_finish_kernel<float>), dim3(gfin), dim3(kBlock), 0, st, V, tl.rowBox.p, tl.nI, tl.nS, tl.sepRow.p, tl.T32.p, tl.tbuf.p, tl.uS.p, u);
+        else hipLaunchKernelGGL((tl_finish_kernel<double>), dim3(gfin), dim3(kBlock), 0, st, V, tl.rowBox.p, tl.nI, tl.nS, tl.sepRow.p, tl.Tm.p, tl.tbuf.p, tl.uS.p, u);
     }
 
     // in-place inverse of the SPD matrix M (mp x mp, mp a multiple of 64, identity tail) on the set-up stream: blocked Gauss-Jordan (shm_kernels.hip.h)
@@ -2024,13 +2047,14 @@ struct Solver final : SolverBase {
         else launch_fused_w<MODE, vec_width<T>(), 2>(sl, c, slot_old, slot_new, init, use_uw, alpha_slot, zsrc, pin, pout);
         return c.yblocks * c.zchunks;
     }
-    void launch_x_update2(Slab<T>& sl, int use_a, int use_b) {
+    void launch_x_update2(Slab<T>& sl, int use_a, int use_b, hipStream_t st = nullptr) {
+        if (!st) st = stream;
         const size_t nvec = sl.nown / vec;
         const unsigned g = (unsigned)((nvec + (size_t)kXuTiles * kBlock - 1) / ((size_t)kXuTiles * kBlock));
         if (vec == 1)
-            hipLaunchKernelGGL((cg_x_update2_kernel<T, 1>), dim3(g), dim3(kBlock), 0, stream, nvec, sl.plane, sl.sc.p, use_a, use_b, sl.p.p, sl.q.p, sl.x.p);
+            hipLaunchKernelGGL((cg_x_update2_kernel<T, 1>), dim3(g), dim3(kBlock), 0, st, nvec, sl.plane, sl.sc.p, use_a, use_b, sl.p.p, sl.q.p, sl.x.p);
         else
-            hipLaunchKernelGGL((cg_x_update2_kernel<T, vec_width<T>()>), dim3(g), dim3(kBlock), 0, stream, nvec, sl.plane, sl.sc.p, use_a, use_b, sl.p.p, sl.q.p,
+            hipLaunchKernelGGL((cg_x_update2_kernel<T, vec_width<T>()>), dim3(g), dim3(kBlock), 0, st, nvec, sl.plane, sl.sc.p, use_a, use_b, sl.p.p, sl.q.p,
                                sl.x.p);
     }
 
@@ -2047,9 +2071,14 @@ struct Solver final : SolverBase {
         allreduce(0, 1 + m);
         for (Slab<T>& sl : slabs) {
             apply_Ginv(sl.red.p + 1, sl.u.p, false, stream);
-            hipLaunchKernelGGL((scatter_nodes_kernel<T>), dim3(1 + (sl.n_touched + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sl.n_touched,
+            const int nred = std::max(1, std::min(16, m / 1024));   // workgroups of the u.w reduction (one per ~1000 rows)
+            if (!sl.proj_ticket.p) {
+                sl.proj_ticket.alloc(1);
+                HIPCHK(hipMemsetAsync(sl.proj_ticket.p, 0, sizeof(unsigned), stream));
+            }
+            hipLaunchKernelGGL((scatter_nodes_kernel<T>), dim3(nred + (sl.n_touched + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sl.n_touched,
                                sl.node_id.p, sl.node_ptr.p, sl.ent_row.p, sl.nent_coef.p, sl.u.p, sl.red.p + 1, m, sl.sc.p, save_rr,
-                               on_z ? sl.z.p : sl.r.p);
+                               on_z ? sl.z.p : sl.r.p, nred, sl.partials.p, sl.proj_ticket.p);   // (the partials were consumed by gather_rows_kernel above)
         }
     }
 
@@ -2825,6 +2854,12 @@ struct Solver final : SolverBase {
         if (st) for (int a = 0; a < kEvPer * kMaxSamples; a++) ev.emplace_back(new Event());
         int nsamples = 0;
         const int sample_stride = pre ? 2 : 8;
+        static const bool no_xoverlap = getenv("SHM_CG_NO_XOVERLAP") != nullptr;   // A/B knob
+        // (only beside the two-level projector, whose seven launches take ~0.08 ms: beside the dense one -- 0.04 ms -- the concurrent update costs the sweeps
+        // more than it hides; 512^3: rocker fp64 0.703 -> 0.710, fp32 0.672 -> 0.684 of the roofline, bunny fp32 0.712 -> 0.703; profiles/r04_projection.txt)
+        const bool xoverlap = !no_xoverlap && total_slabs == 1 && !comm && tl.on;
+        Event e_xfork, e_xjoin;
+        if (xoverlap && !stream_x) HIPCHK(hipStreamCreateWithFlags(&stream_x, hipStreamNonBlocking));
 
         int it = 0;
         double rr0 = 0., rr = 0.;
@@ -2842,13 +2877,24 @@ struct Solver final : SolverBase {
                     nparts[s] = launch_fused<CGF_RES>(slabs[s], slot_old, slot_new, 0, 0, (it & 1) ? SC_ALPHA_B : SC_ALPHA_A, (const T*)nullptr,
                                                       dirbuf(slabs[s], it), (T*)nullptr);
                 mark(1);
+                // x += a_{k-1} p_{k-1} + a_k p_k (odd k) needs nothing of the projection, and the projection's kernels are m-sized and latency-bound: on one GPU the
+                // update runs beside them on a second stream (fork after RES, which fixes a_k; join before DIR, which overwrites p_{k-1}).  Sampled iterations keep
+                // everything on one stream so that the per-kernel durations of shm_stats stay what they say.
+                const bool fork_x = xoverlap && (it & 1) && !sample;
+                if (fork_x) {
+                    e_xfork.record(stream);
+                    HIPCHK(hipStreamWaitEvent(stream_x, e_xfork.e, 0));
+                    launch_x_update2(slabs[0], 1, 1, stream_x);
+                    e_xjoin.record(stream_x);
+                }
                 launch_projection(nparts, false, 1);
                 mark(2);
                 if (pre) launch_precond(true);
                 mark(3);
                 if (pre) launch_projection(zparts, true, 0);
                 mark(4);
-                if (it & 1)
+                if (fork_x) HIPCHK(hipStreamWaitEvent(stream, e_xjoin.e, 0));
+                else if (it & 1)
                     for (Slab<T>& sl : slabs) launch_x_update2(sl, 1, 1);
                 mark(5);
                 run_dir(it, slot_old, slot_new, 0);

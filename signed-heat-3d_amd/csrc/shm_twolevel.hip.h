@@ -13,8 +13,8 @@
 // Set-up: batched in-place Gauss-Jordan of the D_a (one workgroup each), T_a and the Schur update per box (boxes of one colour -- box
 // coordinates of equal parity -- touch disjoint separator rows, so eight passes need no atomics and the sums have a fixed order),
 // then the existing blocked Gauss-Jordan on the |Sigma| x |Sigma| Schur complement: (3/b)^3 of the flops of the full inversion.
-// Application (4 launches): per-box mat-vecs with D_a^-1 and E_a^T, the gather of w_S - E^T t, the dense S^-1 mat-vec, per-box
-// mat-vecs with T_a.  Exact up to rounding, so the projector and the dual preconditioner are the same operators as with the dense
+// Application (5 launches): row-parallel mat-vecs with D_a^-1, column-parallel ones with E_a^T, the gather of w_S - E^T t, the dense S^-1 mat-vec,
+// row-parallel mat-vecs with T_a.  Exact up to rounding, so the projector and the dual preconditioner are the same operators as with the dense
 // inverse (same iteration counts); matrices in double for the projector, an fp32 copy for the dual preconditioner.
 #pragma once
 #include "shm_kernels.hip.h"
@@ -93,33 +93,39 @@ __global__ __launch_bounds__(kBlock) void tl_schur_kernel(TlBoxes B, const int* 
         }
 }
 
-// Application, step 1 (one workgroup per box):  t = D_a^-1 w_I  ->  tbuf ;  y = E_a^T t  ->  ybuf
+// Application, step 1a (round 4):  t = D_a^-1 w_I  ->  tbuf, a WAVE per interior row over all boxes at once (rowBox: box of an interior slot).
+// (Rounds 2-3 ran steps 1 and 4 with one workgroup per box: ~80 workgroups on 256 CUs for rocker at 512^3, 50 + 30 us per application -- 0.13 ms of
+// projection per stencil-CG iteration, which held the loop of configs[2] at 0.64-0.68 of the HBM roofline; profiles/r04_bench_default.json.)
 template <typename TM>
-__global__ __launch_bounds__(kBlock) void tl_apply_boxes_kernel(TlBoxes B, const TM* __restrict__ Dinv, const TM* __restrict__ E, const double* __restrict__ w,
-                                                                double* __restrict__ tbuf, double* __restrict__ ybuf) {
-    __shared__ double wl[kTlMaxBox], tl[kTlMaxBox];
-    const int a = blockIdx.x;
+__global__ __launch_bounds__(kBlock) void tl_rows_kernel(TlBoxes B, const int* __restrict__ rowBox, int nI, const TM* __restrict__ Dinv, const double* __restrict__ w,
+                                                         double* __restrict__ tbuf) {
+    const int lane = threadIdx.x & 63, i = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (i >= nI) return;
+    const int a = rowBox[i], i0 = B.ptrI[a], s = B.ptrI[a + 1] - i0;
+    const TM* Di = Dinv + B.offD[a] + (size_t)(i - i0) * s;
+    const int* rows = B.rowsI + i0;
+    double acc = 0.;
+    for (int j = lane; j < s; j += kWave) acc += (double)Di[j] * w[rows[j]];
+    acc = wave_sum(acc);
+    if (lane == 0) tbuf[i] = acc;
+}
+
+// step 1b:  y = E_a^T t  ->  ybuf.  One workgroup per (box, chunk of 64 separator columns): lanes = consecutive columns (coalesced rows of E), the four
+// waves split the box's rows and their partial sums meet in LDS in a fixed order.
+template <typename TM>
+__global__ __launch_bounds__(kBlock) void tl_cols_kernel(TlBoxes B, const int* __restrict__ chunkBox, const int* __restrict__ chunkCol, const TM* __restrict__ E,
+                                                         const double* __restrict__ tbuf, double* __restrict__ ybuf) {
+    __shared__ double part[kBlock / kWave][kWave];
+    const int a = chunkBox[blockIdx.x], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i0 = B.ptrI[a], s = B.ptrI[a + 1] - i0, c0 = B.ptrS[a], c = B.ptrS[a + 1] - c0;
-    const TM* Di = Dinv + B.offD[a];
+    const int l = chunkCol[blockIdx.x] + lane;
     const TM* Ea = E + B.offE[a];
-    for (int j = threadIdx.x; j < s; j += kBlock) wl[j] = w[B.rowsI[i0 + j]];
+    double acc = 0.;
+    if (l < c)
+        for (int i = wave; i < s; i += kBlock / kWave) acc += (double)Ea[(size_t)i * c + l] * tbuf[i0 + i];
+    part[wave][lane] = acc;
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = wave; i < s; i += kBlock / kWave) {   // a wave per row: lanes stride the columns
-        double acc = 0.;
-        for (int j = lane; j < s; j += kWave) acc += (double)Di[(size_t)i * s + j] * wl[j];
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            tl[i] = acc;
-            tbuf[i0 + i] = acc;
-        }
-    }
-    __syncthreads();
-    for (int l = threadIdx.x; l < c; l += kBlock) {    // a thread per separator column: consecutive threads read consecutive l
-        double acc = 0.;
-        for (int i = 0; i < s; i++) acc += (double)Ea[(size_t)i * c + l] * tl[i];
-        ybuf[c0 + l] = acc;
-    }
+    if (wave == 0 && l < c) ybuf[c0 + l] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
 
 // step 2: v_S = w_S - E^T t, gathered per separator row from the boxes that border it (fixed order); the padded tail stays 0
@@ -132,28 +138,26 @@ __global__ __launch_bounds__(kBlock) void tl_gather_sep_kernel(int nS, const int
     vS[g] = v;
 }
 
-// step 4: u_I = t - T_a u_S (one workgroup per box), u_S copied to its rows (workgroups beyond the boxes)
+// step 4: u_I = t - T_a u_S, a wave per interior row (workgroups [0, ceil(nI / 4))); u_S copied to its rows (the workgroups beyond)
 template <typename TM>
-__global__ __launch_bounds__(kBlock) void tl_finish_kernel(TlBoxes B, int P, int nS, const int* __restrict__ sepRow, const TM* __restrict__ Tm,
+__global__ __launch_bounds__(kBlock) void tl_finish_kernel(TlBoxes B, const int* __restrict__ rowBox, int nI, int nS, const int* __restrict__ sepRow, const TM* __restrict__ Tm,
                                                            const double* __restrict__ tbuf, const double* __restrict__ uS, double* __restrict__ u) {
-    __shared__ double ul[kTlMaxBox];
-    const int a = blockIdx.x;
-    if (a >= P) {
-        const int g = (a - P) * kBlock + threadIdx.x;
+    const int nrb = (nI + kBlock / kWave - 1) / (kBlock / kWave);
+    if ((int)blockIdx.x >= nrb) {
+        const int g = ((int)blockIdx.x - nrb) * kBlock + threadIdx.x;
         if (g < nS) u[sepRow[g]] = uS[g];
         return;
     }
-    const int i0 = B.ptrI[a], s = B.ptrI[a + 1] - i0, c0 = B.ptrS[a], c = B.ptrS[a + 1] - c0;
-    const TM* Ta = Tm + B.offE[a];
-    for (int l = threadIdx.x; l < c; l += kBlock) ul[l] = uS[B.colsS[c0 + l]];
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = wave; i < s; i += kBlock / kWave) {
-        double acc = 0.;
-        for (int l = lane; l < c; l += kWave) acc += (double)Ta[(size_t)i * c + l] * ul[l];
-        acc = wave_sum(acc);
-        if (lane == 0) u[B.rowsI[i0 + i]] = tbuf[i0 + i] - acc;
-    }
+    const int lane = threadIdx.x & 63, i = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (i >= nI) return;
+    const int a = rowBox[i], i0 = B.ptrI[a], s = B.ptrI[a + 1] - i0, c0 = B.ptrS[a], c = B.ptrS[a + 1] - c0;
+    (void)s;
+    const TM* Ti = Tm + B.offE[a] + (size_t)(i - i0) * c;
+    const int* cols = B.colsS + c0;
+    double acc = 0.;
+    for (int l = lane; l < c; l += kWave) acc += (double)Ti[l] * uS[cols[l]];
+    acc = wave_sum(acc);
+    if (lane == 0) u[B.rowsI[i]] = tbuf[i] - acc;
 }
 
 }  // namespace shm
