@@ -173,14 +173,15 @@ def test_step1_full_size_against_c_oracle(shm, oracle_c, fname, hCoef, precision
     pre = _preprocess(fname, hCoef)
     n, S = pre["n"], pre["S"]
     cores = os.cpu_count() or 1
-    # one plane of the serial loops costs n^2 S pair evaluations at ~20 ns: keep the oracle's share of the test below ~2 minutes on this box's cores
-    per_plane_s = n * n * S * 20e-9 / max(1, cores)
+    # one plane of the serial loops costs n^2 S pair evaluations at ~170 ns per pair and hardware thread (measured on the 256-thread host of the GPU boxes: exp, sqrt
+    # and a division per pair): keep the oracle's share of the test at about a minute on this box's cores
+    per_plane_s = n * n * S * 170e-9 / max(1, cores)
     if per_plane_s > 120.0:
         pytest.skip("one oracle plane would take %.0f s on %d cores" % (per_plane_s, cores))
     if n >= 1024 and (os.environ.get("SHM_SKIP_1024") or psutil.virtual_memory().available < 24 * 2 ** 30):
         pytest.skip("1024^3 skipped (SHM_SKIP_1024 / host memory)")
     want = [n // 2, n // 4, 0, n - 1]          # centre, quarter, the planes through the bbox corners
-    ks = want[:max(1, min(len(want), int(120.0 / max(per_plane_s, 1e-3))))]
+    ks = want[:max(1, min(len(want), int(60.0 / max(per_plane_s, 1e-3))))]
     t0 = time.time()
     ref = _oracle_planes(oracle_c, pre, ks)
     t_or = time.time() - t0
@@ -427,7 +428,7 @@ def test_weighted_slab_plan_matches_single_slab(shm, fast):
     assert np.abs(out[3] - out[1]).max() < 1e-8 * max(1.0, np.abs(out[1]).max())
 
 
-@pytest.mark.parametrize("n,slabs", [(48, 1), (33, 1), (33, 3), (70, 1)])
+@pytest.mark.parametrize("n,slabs", [(48, 1), (33, 1), (33, 3), (70, 1), (11, 1)])
 def test_matches_c_oracle_128(shm, oracle_c, n, slabs):
     """Same inputs through the HIP path at sizes that are not powers of two (odd sizes without vector loads, several slabs) and the C oracle (serial
     reference loops + projected CG) -- sizes with no LU fixture.  One slab: the default is the dual solver with the fast Poisson solve as dense DCT

@@ -43,7 +43,7 @@ def main():
         d = json.loads(text.splitlines()[-1])     # raw bench.py output: the JSON line is the last one
     ph, cfg = d["phases_ms"], d["config"]
     n = int(cfg["grid"].split("^")[0])
-    T = 8 if d["dtype"] == "f64" else 4
+    T = 8 if str(d["dtype"]).startswith("f64") else 4
     N = n ** 3
     m = cfg["constraint_rows"]
     host_ms = 0.6e-3 * m + 0.3
