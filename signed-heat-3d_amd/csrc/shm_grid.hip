@@ -2060,13 +2060,14 @@ struct Solver final : SolverBase {
 
     // v <- P v on all slabs (v = r, or z when on_z); leaves red[0] = sum of the first nparts[s] `partials`,
     // sc[SC_UW] = u.w and optionally sc[SC_RR] (= red[0] - u.w = ||P v||^2 when the partials were those of ||v||^2).
-    void launch_projection(const std::vector<int>& nparts, bool on_z = false, int save_rr = 0) {
+    void launch_projection(const std::vector<int>& nparts, bool on_z = false, int save_rr = 0, hipStream_t st = nullptr) {
+        hipStream_t stream = st ? st : this->stream;   // (another stream only on one slab without a communicator: no all-reduce below)
         for (size_t s = 0; s < slabs.size(); s++) {
             Slab<T>& sl = slabs[s];
             hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(1 + (m + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, m, sl.row_ptr.p, sl.ent_node.p,
                                sl.ent_coef.p, on_z ? sl.z.p : sl.r.p, sl.partials.p, nparts[s], sl.red.p);
         }
-        allreduce(0, 1 + m);
+        if (!st) allreduce(0, 1 + m);
         for (Slab<T>& sl : slabs) {
             apply_Ginv(sl.red.p + 1, sl.u.p, false, stream);
             const int nred = std::max(1, std::min(16, m / 1024));   // workgroups of the u.w reduction (one per ~1000 rows)
@@ -2853,13 +2854,13 @@ struct Solver final : SolverBase {
         int nsamples = 0;
         const int sample_stride = pre ? 2 : 8;
         static const bool no_xoverlap = getenv("SHM_CG_NO_XOVERLAP") != nullptr;   // A/B knob
-        // (only beside the two-level projector, whose seven launches take ~0.08 ms: beside the dense one -- 0.04 ms -- the concurrent update costs the sweeps
-        // more than it hides; 512^3: rocker fp64 0.703 -> 0.710, fp32 0.672 -> 0.684 of the roofline, bunny fp32 0.712 -> 0.703; profiles/r04_projection.txt)
-        const bool xoverlap = !no_xoverlap && total_slabs == 1 && !comm && tl.on;
+        // (512^3, same box: rocker fp64 0.706 -> 0.717, fp32 0.680 -> 0.691 of the roofline, bunny fp64 0.720 -> 0.725, fp32 0.710 -> 0.722; profiles/r04_projection.txt)
+        const bool xoverlap = !no_xoverlap && total_slabs == 1 && !comm;
         Event e_xfork, e_xjoin;
-        // The update runs on the set-up stream (idle during the loop, and known to run beside `stream`: the whole set-up does).  A stream of its own -- of
-        // the same or of the lowest priority -- was measured to serialise with the main stream in every solver but the first of a process (HIP deals its few
-        // hardware queues out per process; the projection then queued up behind the update: 0.31 instead of 0.08 ms per iteration, every sweep 15 % slower).
+        // The second stream is the set-up stream (idle during the loop, of the highest priority -- the projection's short kernels get their CUs at once -- and
+        // known to run beside `stream`: the whole set-up does).  A stream of its own, of the same or of the lowest priority, was measured to serialise with the
+        // main stream in every solver but the first of a process (HIP deals its few hardware queues out per process; the projection then queued up behind the
+        // update: 0.31 instead of 0.08 ms per iteration, every sweep 15 % slower).
         hipStream_t const stream_x = stream2;
         int it = 0;
         double rr0 = 0., rr = 0.;
@@ -2878,23 +2879,26 @@ struct Solver final : SolverBase {
                                                       dirbuf(slabs[s], it), (T*)nullptr);
                 mark(1);
                 // x += a_{k-1} p_{k-1} + a_k p_k (odd k) needs nothing of the projection, and the projection's kernels are m-sized and latency-bound: on one GPU the
-                // update runs beside them on a second stream (fork after RES, which fixes a_k; join before DIR, which overwrites p_{k-1}).  Sampled iterations keep
-                // everything on one stream so that the per-kernel durations of shm_stats stay what they say.
-                const bool fork_x = xoverlap && (it & 1) && !sample;
+                // two run side by side (fork after RES, which fixes a_k; join before DIR, which needs the projected residual and overwrites p_{k-1}).  Sampled
+                // iterations keep everything on one stream so that the per-kernel durations of shm_stats stay what they say.
+                const bool fork_x = xoverlap && (it & 1) && !sample && !pre;
                 if (fork_x) {
+                    // the PROJECTION goes to the set-up stream (highest priority: its short kernels get their CUs at once), the update stays on the main stream
                     e_xfork.record(stream);
                     HIPCHK(hipStreamWaitEvent(stream_x, e_xfork.e, 0));
-                    launch_x_update2(slabs[0], 1, 1, stream_x);
+                    launch_projection(nparts, false, 1, stream_x);
                     e_xjoin.record(stream_x);
+                    launch_x_update2(slabs[0], 1, 1);
+                    HIPCHK(hipStreamWaitEvent(stream, e_xjoin.e, 0));
+                } else {
+                    launch_projection(nparts, false, 1);
                 }
-                launch_projection(nparts, false, 1);
                 mark(2);
                 if (pre) launch_precond(true);
                 mark(3);
                 if (pre) launch_projection(zparts, true, 0);
                 mark(4);
-                if (fork_x) HIPCHK(hipStreamWaitEvent(stream, e_xjoin.e, 0));
-                else if (it & 1)
+                if (!fork_x && (it & 1))
                     for (Slab<T>& sl : slabs) launch_x_update2(sl, 1, 1);
                 mark(5);
                 run_dir(it, slot_old, slot_new, 0);
