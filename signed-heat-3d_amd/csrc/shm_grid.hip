@@ -512,8 +512,11 @@ struct Solver final : SolverBase {
     struct TwoLevel {
         bool on = false;
         int box = 16, P = 0, nI = 0, nS = 0, nSp = 0, ysz = 0;
-        DevArray<int> ptrI, ptrS, rowsI, colsS, sepRow, adj_ptr, adj_idx, colour_list, rowBox, chunkBox, chunkCol;
-        int nChunks = 0;
+        DevArray<int> ptrI, ptrS, rowsI, colsS, sepRow, adj_ptr, adj_idx, colour_list, rowBox, chunkBox, chunkCol, tBox, tRow, sBox, sRow;
+        DevArray<size_t> offW;
+        DevArray<double> gjP, gjR, gjC;   // pivot blocks and panels of the batched Gauss-Jordan over the boxes
+        int nChunks = 0, nTChunks = 0, nbMax = 0;
+        int schur_ptr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         DevArray<size_t> offD, offE;
         DevArray<double> D, E, Tm, tbuf, ybuf, vS, uS;
         DevArray<float> D32, E32, T32;
@@ -1446,7 +1449,7 @@ struct Solver final : SolverBase {
         }
         std::vector<int> boxid, slot, ptrI, ptrS, rowsI, colsS, sepRow, colour_of;
         std::vector<size_t> offD, offE;
-        int P = 0, nS = 0;
+        int P = 0, nS = 0, tl_maxs = 0, tl_maxc = 0;
         for (int b : {box_env > 1 ? box_env : 16, 8, 4}) {
             tl.box = b;
             // box key -> compact id in order of first appearance (deterministic)
@@ -1508,6 +1511,8 @@ struct Solver final : SolverBase {
                 maxs = std::max(maxs, cnt[(size_t)a]);
                 maxc = std::max(maxc, ptrS[(size_t)a + 1] - ptrS[(size_t)a]);
             }
+            tl_maxs = maxs;
+            tl_maxc = maxc;
             if (maxs <= kTlMaxBox && maxc <= kTlMaxBox) break;
             if (b == 4) return false;
         }
@@ -1524,7 +1529,7 @@ struct Solver final : SolverBase {
             const size_t sa = (size_t)(ptrI[(size_t)a + 1] - ptrI[(size_t)a]), ca = (size_t)(ptrS[(size_t)a + 1] - ptrS[(size_t)a]);
             offD[(size_t)a] = szD;
             offE[(size_t)a] = szE;
-            szD += sa * sa;
+            szD += (size_t)tl_ld((int)sa) * (size_t)tl_ld((int)sa);   // D_a padded to whole 64-row blocks (the batched blocked Gauss-Jordan)
             szE += sa * ca;
         }
         tl.szD = szD;
@@ -1536,11 +1541,12 @@ struct Solver final : SolverBase {
         for (int a = 0; a < P; a++) {
             const int s0 = ptrI[(size_t)a], sa = ptrI[(size_t)a + 1] - s0, c0 = ptrS[(size_t)a], ca = ptrS[(size_t)a + 1] - c0;
             for (int l = 0; l < ca; l++) lcol[(size_t)colsS[(size_t)(c0 + l)]] = l;
+            for (int t = sa; t < tl_ld(sa); t++) hD[offD[(size_t)a] + (size_t)t * (size_t)tl_ld(sa) + (size_t)t] = 1.0;   // identity on the padded diagonal
             for (int t = 0; t < sa; t++) {
                 const int r = rowsI[(size_t)(s0 + t)];
                 for (int e = gptr[(size_t)r]; e < gptr[(size_t)r + 1]; e++) {
                     const int c = gcol[(size_t)e];
-                    if (boxid[(size_t)c] >= 0) hD[offD[(size_t)a] + (size_t)t * sa + (size_t)slot[(size_t)c]] = gval[(size_t)e];  // same box (interiors of different boxes never couple)
+                    if (boxid[(size_t)c] >= 0) hD[offD[(size_t)a] + (size_t)t * (size_t)tl_ld(sa) + (size_t)slot[(size_t)c]] = gval[(size_t)e];  // same box (interiors of different boxes never couple)
                     else hE[offE[(size_t)a] + (size_t)t * ca + (size_t)lcol[(size_t)slot[(size_t)c]]] = gval[(size_t)e];
                 }
             }
@@ -1591,6 +1597,41 @@ struct Solver final : SolverBase {
             tl.rowBox.upload(rowBox, stream);
             tl.chunkBox.upload(chunkBox, stream);
             tl.chunkCol.upload(chunkCol, stream);
+            // set-up lists: (box, 16 rows of T) for all boxes; (box, 16 rows of the Schur update) per colour; offsets of the boxes' Gauss-Jordan panels
+            std::vector<int> tBox, tRow, sBox, sRow;
+            std::vector<size_t> offW((size_t)P, 0);
+            size_t szW = 0;
+            tl.nbMax = 0;
+            for (int a = 0; a < P; a++) {
+                const int sa = ptrI[(size_t)a + 1] - ptrI[(size_t)a];
+                for (int r0 = 0; r0 < sa; r0 += kTlRowsPerWg) {
+                    tBox.push_back(a);
+                    tRow.push_back(r0);
+                }
+                offW[(size_t)a] = szW;
+                szW += (size_t)kGJ * (size_t)tl_ld(sa);
+                tl.nbMax = std::max(tl.nbMax, tl_ld(sa) / kGJ);
+            }
+            tl.nTChunks = (int)tBox.size();
+            for (int col = 0; col < 8; col++) {
+                tl.schur_ptr[col] = (int)sBox.size();
+                for (int a = 0; a < P; a++) {
+                    if (colour_of[(size_t)a] != col) continue;
+                    for (int p0 = 0; p0 < ptrS[(size_t)a + 1] - ptrS[(size_t)a]; p0 += kTlRowsPerWg) {
+                        sBox.push_back(a);
+                        sRow.push_back(p0);
+                    }
+                }
+            }
+            tl.schur_ptr[8] = (int)sBox.size();
+            tl.tBox.upload(tBox, stream);
+            tl.tRow.upload(tRow, stream);
+            tl.sBox.upload(sBox, stream);
+            tl.sRow.upload(sRow, stream);
+            tl.offW.upload(offW, stream);
+            tl.gjP.alloc((size_t)P * kGJ * kGJ);
+            tl.gjR.alloc(std::max<size_t>(szW, 1));
+            tl.gjC.alloc(std::max<size_t>(szW, 1));
         }
         tl.colsS.upload(colsS, stream);
         tl.sepRow.upload(sepRow, stream);
@@ -1616,12 +1657,25 @@ struct Solver final : SolverBase {
         hipLaunchKernelGGL(scatter_triplets_kernel, dim3(grid_for(tidx.size(), 4096)), dim3(kBlock), 0, stream, (size_t)tidx.size(), d_tidx.p, d_tval.p, Ginv.p);
         gjFlag.alloc(2);   // [0]: blocked Gauss-Jordan (enqueue_gj_invert), [1]: the boxes' inverses; both read by finish_invert_G()
         HIPCHK(hipMemsetAsync(gjFlag.p + 1, 0, sizeof(int), stream));
-        hipLaunchKernelGGL(tl_block_inverse_kernel, dim3((unsigned)P), dim3(kBlock), 0, stream, tl.view(), (const int*)nullptr, tl.D.p, gjFlag.p + 1);
+        {   // all boxes' D_a^-1 at once: the blocked Gauss-Jordan of enqueue_gj_invert(), batched over the boxes (blockIdx.y)
+            const GjBatch Bt{tl.ptrI.p, tl.offD.p, tl.offW.p, tl.D.p, tl.gjP.p, tl.gjR.p, tl.gjC.p};
+            const unsigned nb = (unsigned)tl.nbMax, uP = (unsigned)P;
+            for (unsigned kb = 0; kb < nb; kb++) {
+                hipLaunchKernelGGL(gj_pivot_kernel<4>, dim3(1, uP), dim3(256), 0, stream, (double*)nullptr, 0, (int)kb, (double*)nullptr, gjFlag.p + 1, setup_prio, Bt);
+                hipLaunchKernelGGL(gj_panels_kernel, dim3(nb, uP), dim3(kBlock), 0, stream, (const double*)nullptr, 0, (int)kb, (const double*)nullptr, (double*)nullptr, 0,
+                                   (double*)nullptr, kGJ, 0, setup_prio, Bt);
+                hipLaunchKernelGGL((gj_update_kernel<GJ_ALL>), dim3(nb * (nb + 1) / 2, uP), dim3(kBlock), 0, stream, (double*)nullptr, 0, 0, (int)kb, 0, 1,
+                                   (const double*)nullptr, 0, (const double*)nullptr, kGJ, 0, kGJ, setup_prio, Bt);
+            }
+            if (nb > 1) hipLaunchKernelGGL(gj_mirror_kernel, dim3(nb * (nb - 1) / 2, uP), dim3(kBlock), 0, stream, (double*)nullptr, 0, Bt);
+        }
+        if (tl.nTChunks > 0)
+            hipLaunchKernelGGL(tl_T_kernel, dim3((unsigned)tl.nTChunks), dim3(kBlock), 0, stream, tl.view(), tl.tBox.p, tl.tRow.p, tl.D.p, tl.E.p, tl.Tm.p, setup_prio);
         for (int col = 0; col < 8; col++) {
-            const int cntc = tl.colour_ptr[col + 1] - tl.colour_ptr[col];
+            const int cntc = tl.schur_ptr[col + 1] - tl.schur_ptr[col];
             if (cntc > 0)
-                hipLaunchKernelGGL(tl_schur_kernel, dim3((unsigned)cntc), dim3(kBlock), 0, stream, tl.view(), tl.colour_list.p + tl.colour_ptr[col], tl.D.p, tl.E.p,
-                                   tl.Tm.p, Ginv.p, tl.nSp);
+                hipLaunchKernelGGL(tl_schur_kernel, dim3((unsigned)cntc), dim3(kBlock), 0, stream, tl.view(), tl.sBox.p + tl.schur_ptr[col], tl.sRow.p + tl.schur_ptr[col],
+                                   tl.E.p, tl.Tm.p, Ginv.p, tl.nSp, setup_prio);
         }
         // fp32 copies for the dual preconditioner
         tl.D32.alloc(std::max<size_t>(szD, 1));
@@ -1633,7 +1687,7 @@ struct Solver final : SolverBase {
         HIPCHK(hipGetLastError());
         // (no synchronisation here: the uploads above were staged, and a non-positive pivot of a box is reported by finish_invert_G() with the others --
         // waiting for the set-up stream at this point stalls the rest of the host set-up behind a Step-1 kernel that leaves it no SIMD)
-        log("[shm] two-level inverse of A A^T: box %d, %d boxes (%d interior rows), separator %d rows", tl.box, P, tl.nI, nS);
+        log("[shm] two-level inverse of A A^T: box %d, %d boxes (%d interior rows, largest box %d rows x %d separator columns), separator %d rows", tl.box, P, tl.nI, tl_maxs, tl_maxc, nS);
         return true;
     }
 

@@ -1222,6 +1222,21 @@ __global__ __launch_bounds__(kBlock) void convert_kernel(size_t count, const TS*
 // =================================================================================================
 constexpr int kGJ = 64;
 
+// Batched form of the blocked Gauss-Jordan kernels below (round 4: the boxes of the two-level inverse, shm_twolevel.hip.h -- one workgroup per box walking its
+// matrix in global memory took 45 ms for a 280-row box; the blocked kernels do all boxes at once in 3 launches per 64 rows of the LARGEST box).  blockIdx.y = box a:
+// its matrix is D + offD[a], ld = rows padded to 64 (identity on the padded diagonal), its 64 x 64 pivot scratch P + a 4096, its R / C panels at offW[a]
+// (64 x ld and ld x 64).  D == nullptr: the unbatched call (one matrix, the kernel's own arguments).
+struct GjBatch {
+    const int* ptrI;
+    const size_t* offD;
+    const size_t* offW;
+    double* D;
+    double* P;
+    double* R;
+    double* C;
+};
+__device__ __forceinline__ int gj_batch_ld(const GjBatch& B, int a) { return (B.ptrI[a + 1] - B.ptrI[a] + kGJ - 1) / kGJ * kGJ; }
+
 // step 1: invert the 64x64 pivot block (Gauss-Jordan, SPD -> no pivoting).  256 threads, each owning a 4x4 sub-block
 // in registers; per elimination step only the pivot row and column travel through LDS (double-buffered: one barrier
 // per step).
@@ -1229,10 +1244,20 @@ constexpr int kGJ = 64;
 // dependent chain; with one wave per SIMD every one of a step's ~95 fp64 instructions waits out its predecessor's latency, with four a quarter of the
 // instructions per thread and three other waves to issue from meanwhile (round 3: 39 -> see DESIGN.md section 4 per 64 x 64 block).
 template <int E>
-__global__ __launch_bounds__((kGJ / E) * (kGJ / E)) void gj_pivot_kernel(double* __restrict__ G, int ld, int kb, double* __restrict__ Pout, int* __restrict__ flag, int prio) {
+__global__ __launch_bounds__((kGJ / E) * (kGJ / E)) void gj_pivot_kernel(double* __restrict__ G_, int ld, int kb, double* __restrict__ Pout_, int* __restrict__ flag, int prio,
+                                                                         GjBatch Bt = GjBatch{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}) {
     constexpr int kT = kGJ / E;   // threads per dimension
     __shared__ double rowk[2][kGJ], colk[2][kGJ];
     if (prio) __builtin_amdgcn_s_setprio(3);   // (see gj_panels_kernel)
+    double* G = G_;
+    double* Pout = Pout_;
+    if (Bt.D) {
+        const int a = blockIdx.y;
+        ld = gj_batch_ld(Bt, a);
+        if (kb >= ld / kGJ) return;
+        G = Bt.D + Bt.offD[a];
+        Pout = Bt.P + (size_t)a * kGJ * kGJ;
+    }
     const int ty = threadIdx.x / kT, tx = threadIdx.x % kT;
     const size_t o = (size_t)kb * kGJ;
     double r[E][E];
@@ -1426,9 +1451,24 @@ __global__ __launch_bounds__(256) void gj_pivot_block4_kernel(double* __restrict
 // step 2: R[:, b] = P * G[kb, b] and C[b, :] = G[b, kb] for every block index b, from the block-lower triangle:
 //   X = stored block (b >= kb ? G[b,kb] : G[kb,b]);   b > kb: G[kb,b] = X^T, G[b,kb] = X;   b < kb: G[kb,b] = X, G[b,kb] = -X^T.
 typedef double gj_f64x4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(kBlock) void gj_panels_kernel(const double* __restrict__ G, int ld, int kb, const double* __restrict__ P,
-                                                           double* __restrict__ R /* [..][ld]: rows r_row0 .. r_row0+63 */, int r_row0,
-                                                           double* __restrict__ C /* [ld][c_ld]: columns c_col0 .. c_col0+63 */, int c_ld, int c_col0, int prio) {
+__global__ __launch_bounds__(kBlock) void gj_panels_kernel(const double* __restrict__ G_, int ld, int kb, const double* __restrict__ P_,
+                                                           double* __restrict__ R_ /* [..][ld]: rows r_row0 .. r_row0+63 */, int r_row0,
+                                                           double* __restrict__ C_ /* [ld][c_ld]: columns c_col0 .. c_col0+63 */, int c_ld, int c_col0, int prio,
+                                                           GjBatch Bt = GjBatch{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}) {
+    const double* G = G_;
+    const double* P = P_;
+    double* R = R_;
+    double* C = C_;
+    if (Bt.D) {
+        const int a = blockIdx.y;
+        ld = gj_batch_ld(Bt, a);
+        if (kb >= ld / kGJ || (int)blockIdx.x >= ld / kGJ) return;
+        G = Bt.D + Bt.offD[a];
+        P = Bt.P + (size_t)a * kGJ * kGJ;
+        R = Bt.R + Bt.offW[a];
+        C = Bt.C + Bt.offW[a];
+        c_ld = kGJ;
+    }
     // X alone in LDS (33 KB; with P staged as well the kernel needed 65 KB and could not be placed on a CU beside two workgroups of the tiered Step-1
     // kernel).  The 64 x 64 x 64 product P X (or P X^T) runs on the matrix cores (round 3; the scalar LDS version took 23-32 us per launch, three quarters of
     // it waiting on LDS): one 32 x 32 quadrant per wave as 2 x 2 v_mfma_f64_16x16x4_f64 tiles; the A operand (P: the same 32 KB for every workgroup of
@@ -1508,12 +1548,26 @@ __device__ __forceinline__ void gj_tri_decode(unsigned t, int& bi, int& bj) {   
     bj = (int)(t - (unsigned)bi * (unsigned)(bi + 1) / 2);
 }
 template <int TILES>
-__global__ __launch_bounds__(kBlock) void gj_update_kernel(double* __restrict__ G, int ld, int nb, int kb /* inner pivot block; unused for GJ_REST */,
-                                                           int k0, int nO, const double* __restrict__ R /* [..][ld] */, int r_row0,
-                                                           const double* __restrict__ C /* [ld][c_ld] */, int c_ld, int c_col0, int K, int prio) {
+__global__ __launch_bounds__(kBlock) void gj_update_kernel(double* __restrict__ G_, int ld, int nb, int kb /* inner pivot block; unused for GJ_REST */,
+                                                           int k0, int nO, const double* __restrict__ R_ /* [..][ld] */, int r_row0,
+                                                           const double* __restrict__ C_ /* [ld][c_ld] */, int c_ld, int c_col0, int K, int prio,
+                                                           GjBatch Bt = GjBatch{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}) {
     __shared__ double cs[kGJ][kGJK + 1];  // C chunk  [i][k]
     __shared__ double rs[kGJK][kGJ + 1];  // R chunk  [k][j]
     if (prio) __builtin_amdgcn_s_setprio(3);   // (see gj_panels_kernel)
+    double* G = G_;
+    const double* R = R_;
+    const double* C = C_;
+    if (Bt.D) {   // (GJ_ALL only)
+        const int a = blockIdx.y;
+        ld = gj_batch_ld(Bt, a);
+        nb = ld / kGJ;
+        if (kb >= nb || blockIdx.x >= (unsigned)(nb * (nb + 1) / 2)) return;
+        G = Bt.D + Bt.offD[a];
+        R = Bt.R + Bt.offW[a];
+        C = Bt.C + Bt.offW[a];
+        c_ld = kGJ;
+    }
     int bi, bj;
     if (TILES == GJ_ALL) {
         gj_tri_decode(blockIdx.x, bi, bj);
@@ -1583,8 +1637,16 @@ __global__ __launch_bounds__(kBlock) void gj_update_kernel(double* __restrict__ 
 }
 
 // after the last pivot block: G[bj, bi] = G[bi, bj]^T for bi > bj (the inverse is symmetric; only its block-lower triangle was kept)
-__global__ __launch_bounds__(kBlock) void gj_mirror_kernel(double* __restrict__ G, int ld) {
+__global__ __launch_bounds__(kBlock) void gj_mirror_kernel(double* __restrict__ G_, int ld, GjBatch Bt = GjBatch{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}) {
     __shared__ double x[kGJ][kGJ + 1];
+    double* G = G_;
+    if (Bt.D) {
+        const int a = blockIdx.y;
+        ld = gj_batch_ld(Bt, a);
+        const int nb = ld / kGJ;
+        if (blockIdx.x >= (unsigned)(nb * (nb - 1) / 2)) return;
+        G = Bt.D + Bt.offD[a];
+    }
     const unsigned t = blockIdx.x;   // strictly lower tile: bi >= 1, bj < bi
     int bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
     while ((unsigned)bi * (unsigned)(bi + 1) / 2 > t) bi--;

@@ -10,7 +10,7 @@
 //            [ E^T F ]
 //        u_I = t - T u_S ,  u_S = S^-1 (w_S - E^T t) ,  t = D^-1 w_I ,  T_a = D_a^-1 E_a .
 //
-// Set-up: batched in-place Gauss-Jordan of the D_a (one workgroup each), T_a and the Schur update per box (boxes of one colour -- box
+// Set-up: batched blocked Gauss-Jordan of the D_a (all boxes at once), T_a for all boxes in one launch, the Schur update per colour (boxes of one colour -- box
 // coordinates of equal parity -- touch disjoint separator rows, so eight passes need no atomics and the sums have a fixed order),
 // then the existing blocked Gauss-Jordan on the |Sigma| x |Sigma| Schur complement: (3/b)^3 of the flops of the full inversion.
 // Application (5 launches): row-parallel mat-vecs with D_a^-1, column-parallel ones with E_a^T, the gather of w_S - E^T t, the dense S^-1 mat-vec,
@@ -30,67 +30,77 @@ struct TlBoxes {               // device views shared by the kernels below (all 
     const int* colsS;          // [sum c_a] separator index (0..nS) of a box-local column
 };
 
-// In-place inverse of every SPD block D_a by Gauss-Jordan without pivoting (the Schur complements of an SPD matrix stay SPD).
-// One workgroup per box; the pivot row and column of a step are staged in LDS.  flag != 0: a non-positive pivot was met.
-constexpr int kTlMaxBox = 2048;  // rows of a box the LDS staging can hold
-__global__ __launch_bounds__(kBlock) void tl_block_inverse_kernel(TlBoxes B, const int* __restrict__ box_list, double* __restrict__ D, int* __restrict__ flag) {
-    __shared__ double prow[kTlMaxBox], pcol[kTlMaxBox];
-    const int a = box_list ? box_list[blockIdx.x] : blockIdx.x;
-    const int s = B.ptrI[a + 1] - B.ptrI[a];
-    double* M = D + B.offD[a];
-    for (int k = 0; k < s; k++) {
-        const double piv = M[(size_t)k * s + k];
-        if (!(piv > 0.)) {
-            if (threadIdx.x == 0) *flag = 1;
-            return;
-        }
-        const double ip = 1. / piv;
-        for (int j = threadIdx.x; j < s; j += kBlock) {
-            prow[j] = M[(size_t)k * s + j] * ip;
-            pcol[j] = M[(size_t)j * s + k];
-        }
-        __syncthreads();
-        {
-            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-            for (int i = wave; i < s; i += kBlock / kWave) {   // a wave per row, lanes stride the columns (no integer division, coalesced)
-                const double ci = pcol[i];
-                double* Mi = M + (size_t)i * s;
-                for (int j = lane; j < s; j += kWave) {
-                    double v;
-                    if (i == k) v = (j == k) ? ip : prow[j];
-                    else if (j == k) v = -ci * ip;
-                    else v = Mi[j] - ci * prow[j];
-                    Mi[j] = v;
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
+// Set-up kernels (round 4).  The D_a are stored padded to whole 64-row blocks (leading dimension ld_a = tl_ld(s_a), identity on the padded diagonal) and inverted
+// ALL AT ONCE by the blocked Gauss-Jordan kernels of shm_kernels.hip.h in their batched form (GjBatch: 3 launches per 64 rows of the largest box).  Rounds 2-3
+// inverted each box with one workgroup walking its matrix in global memory (s dependent steps of s^2 / 256 read-modify-writes per thread: 2 ms for the 126-row
+// boxes of rocker at 512^3, 45 ms for the 280-row boxes of the same mesh at 256^3) and formed T_a and the Schur update with one workgroup per box as well
+// (3.8 / 41 ms) -- together the 6 ms of set-up an fp32 solve of configs[2] waits for after its Step 1, 41 ms for configs[4], and 88 ms behind an 84 ms Step 1
+// for rocker at 256^3 in fp64.
+constexpr int kTlMaxBox = 2048;  // rows / separator columns of a box (the application kernels stage them in LDS)
+__host__ __device__ __forceinline__ int tl_ld(int s) { return (s + 63) / 64 * 64; }
 
-// T_a = D_a^-1 E_a, then S[Sigma_a, Sigma_a] -= E_a^T T_a for the boxes of one colour (disjoint separator rows: plain read-modify-write).
-__global__ __launch_bounds__(kBlock) void tl_schur_kernel(TlBoxes B, const int* __restrict__ box_list, const double* __restrict__ Dinv, const double* __restrict__ E,
-                                                          double* __restrict__ Tm, double* __restrict__ S, int ldS) {
-    const int a = box_list[blockIdx.x];
-    const int s = B.ptrI[a + 1] - B.ptrI[a], c = B.ptrS[a + 1] - B.ptrS[a];
+// T_a = D_a^-1 E_a for all boxes: a workgroup per (box, 16 rows of T), a wave per 4 rows, lanes = consecutive columns (coalesced rows of E)
+constexpr int kTlRowsPerWg = 16;
+__global__ __launch_bounds__(kBlock) void tl_T_kernel(TlBoxes B, const int* __restrict__ chunkBox, const int* __restrict__ chunkRow, const double* __restrict__ Dinv,
+                                                      const double* __restrict__ E, double* __restrict__ Tm, int prio) {
+    if (prio) __builtin_amdgcn_s_setprio(3);   // beside the tiered Step 1 (see gj_panels_kernel)
+    const int a = chunkBox[blockIdx.x], r0 = chunkRow[blockIdx.x];
+    const int s = B.ptrI[a + 1] - B.ptrI[a], c = B.ptrS[a + 1] - B.ptrS[a], ld = tl_ld(s);
     const double* Di = Dinv + B.offD[a];
     const double* Ea = E + B.offE[a];
     double* Ta = Tm + B.offE[a];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int kR = kTlRowsPerWg / (kBlock / kWave);   // rows per wave
+    for (int l = lane; l < c; l += kWave) {
+        double acc[kR];
+#pragma unroll
+        for (int q = 0; q < kR; q++) acc[q] = 0.;
+        for (int j = 0; j < s; j++) {
+            const double e = Ea[(size_t)j * c + l];
+#pragma unroll
+            for (int q = 0; q < kR; q++) {
+                const int i = r0 + wave * kR + q;
+                acc[q] += (i < s ? Di[(size_t)i * ld + j] : 0.) * e;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kR; q++) {
+            const int i = r0 + wave * kR + q;
+            if (i < s) Ta[(size_t)i * c + l] = acc[q];
+        }
+    }
+}
+
+// S[Sigma_a, Sigma_a] -= E_a^T T_a for the boxes of one colour (disjoint separator rows: plain read-modify-write): a workgroup per (box, 16 rows p of the
+// update), a wave per 4 rows, lanes = consecutive columns q
+__global__ __launch_bounds__(kBlock) void tl_schur_kernel(TlBoxes B, const int* __restrict__ chunkBox, const int* __restrict__ chunkRow, const double* __restrict__ E,
+                                                          const double* __restrict__ Tm, double* __restrict__ S, int ldS, int prio) {
+    if (prio) __builtin_amdgcn_s_setprio(3);
+    const int a = chunkBox[blockIdx.x], p0 = chunkRow[blockIdx.x];
+    const int s = B.ptrI[a + 1] - B.ptrI[a], c = B.ptrS[a + 1] - B.ptrS[a];
+    const double* Ea = E + B.offE[a];
+    const double* Ta = Tm + B.offE[a];
     const int* cols = B.colsS + B.ptrS[a];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = wave; i < s; i += kBlock / kWave)        // a wave per row of T, lanes = consecutive columns l (coalesced E reads)
-        for (int l = lane; l < c; l += kWave) {
-            double acc = 0.;
-            for (int j = 0; j < s; j++) acc += Di[(size_t)i * s + j] * Ea[(size_t)j * c + l];
-            Ta[(size_t)i * c + l] = acc;
+    constexpr int kR = kTlRowsPerWg / (kBlock / kWave);
+    for (int q = lane; q < c; q += kWave) {
+        double acc[kR];
+#pragma unroll
+        for (int u = 0; u < kR; u++) acc[u] = 0.;
+        for (int i = 0; i < s; i++) {
+            const double t = Ta[(size_t)i * c + q];
+#pragma unroll
+            for (int u = 0; u < kR; u++) {
+                const int p = p0 + wave * kR + u;
+                acc[u] += (p < c ? Ea[(size_t)i * c + p] : 0.) * t;
+            }
         }
-    __syncthreads();   // (global writes of this workgroup are visible to it after the barrier)
-    for (int p = wave; p < c; p += kBlock / kWave)
-        for (int q = lane; q < c; q += kWave) {
-            double acc = 0.;
-            for (int i = 0; i < s; i++) acc += Ea[(size_t)i * c + p] * Ta[(size_t)i * c + q];
-            S[(size_t)cols[p] * ldS + cols[q]] -= acc;
+#pragma unroll
+        for (int u = 0; u < kR; u++) {
+            const int p = p0 + wave * kR + u;
+            if (p < c) S[(size_t)cols[p] * ldS + cols[q]] -= acc[u];
         }
+    }
 }
 
 // Application, step 1a (round 4):  t = D_a^-1 w_I  ->  tbuf, a WAVE per interior row over all boxes at once (rowBox: box of an interior slot).
@@ -102,7 +112,7 @@ __global__ __launch_bounds__(kBlock) void tl_rows_kernel(TlBoxes B, const int* _
     const int lane = threadIdx.x & 63, i = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
     if (i >= nI) return;
     const int a = rowBox[i], i0 = B.ptrI[a], s = B.ptrI[a + 1] - i0;
-    const TM* Di = Dinv + B.offD[a] + (size_t)(i - i0) * s;
+    const TM* Di = Dinv + B.offD[a] + (size_t)(i - i0) * tl_ld(s);
     const int* rows = B.rowsI + i0;
     double acc = 0.;
     for (int j = lane; j < s; j += kWave) acc += (double)Di[j] * w[rows[j]];
