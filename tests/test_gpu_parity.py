@@ -147,7 +147,7 @@ def test_step1_is_translation_invariant(shm, precision):
 # The classification geometry of the tiered kernel changes with n (a block spans 2.5 e-folds of the kernel at 256^3, 1.3 at 512^3), so the budget is
 # checked where it is used: configs[1] (256^3), configs[3] (bunny.pc 512^3), configs[2] / [4] in the reference's fp64 arithmetic (rocker 512^3, SprayBottle.pc
 # 1024^3) and the file with the largest measured error (knot.obj), tiered and all-fp64; the fp32 kernel of configs[2] / [4] with its own bound.
-STEP1_FULL = [("bunny_small.obj", 4.0, 64), ("bunny.pc", 5.0, 64), ("knot.obj", 4.0, 64), ("rocker.obj", 5.0, 64), ("knot.obj", 5.0, 64),
+STEP1_FULL = [("bunny_small.obj", 4.0, 64), ("bunny.pc", 5.0, 64), ("knot.obj", 4.0, 64), ("rocker.obj", 5.0, 64), ("knot.obj", 5.0, 64), ("chair.obj", 5.0, 64),
               ("SprayBottle.pc", 6.0, 64), ("rocker.obj", 5.0, 32), ("SprayBottle.pc", 6.0, 32)]
 Y_BUDGET_F32 = 2e-3   # fp32 kernel: every pair in fp32 (relative error ~1e-5 per term incl. the exponent); measured worst 3e-4 where sheets cancel
 
