@@ -1733,13 +1733,29 @@ struct Solver final : SolverBase {
         HIPCHK(hipMemsetAsync(gjFlag.p, 0, sizeof(int), stream));
         const int c_ld = outer * kGJ;
         static const int pivot_env = getenv("SHM_GJ_PIVOT_E") ? atoi(getenv("SHM_GJ_PIVOT_E")) : 0;
+        static const bool classic = getenv("SHM_GJ_CLASSIC") != nullptr;   // A/B knob: three dependent launches per pivot block (rounds 1-3)
+        // one launch per pivot block (gj_step_kernel; it inverts the pivot tiles by the scalar elimination) unless a pivot kernel is asked for explicitly
+        const bool stepped = outer == 1 && !classic && pivot_env == 0;
         const int pivot_e = pivot_env ? pivot_env : (refined_later ? 16 : 4);   // 16 = block Gauss-Jordan with 4 x 4 pivot blocks (round 3);   // A/B knob: 4 = 256 threads; 2 = 1024 threads (2 % faster on an idle GPU, but four 40-register waves per SIMD do not fit beside Step 1)
         auto launch_pivot = [&](int kb) {
             if (pivot_e == 16) hipLaunchKernelGGL(gj_pivot_block4_kernel, dim3(1), dim3(256), 0, stream, M, mp, kb, gjP.p, gjFlag.p, setup_prio);
             else if (pivot_e == 4) hipLaunchKernelGGL(gj_pivot_kernel<4>, dim3(1), dim3(256), 0, stream, M, mp, kb, gjP.p, gjFlag.p, setup_prio);
             else hipLaunchKernelGGL(gj_pivot_kernel<2>, dim3(1), dim3(1024), 0, stream, M, mp, kb, gjP.p, gjFlag.p, setup_prio);
         };
-        if (outer == 1) {
+        if (stepped) {
+            // one launch per pivot block: step k-1's update beside step k's pivot and panels (gj_step_kernel)
+            gjR.alloc((size_t)2 * kGJ * mp);
+            gjC.alloc((size_t)2 * mp * kGJ);
+            for (int k = 0; k <= nb; k++) {
+                const size_t nU = k == 0 ? 0 : (k < nb ? (size_t)(nb - 1) * nb / 2 : (size_t)nb * (nb + 1) / 2);
+                const unsigned grid = (unsigned)((k < nb ? nb : 0) + nU);
+                double* Rn = gjR.p + (size_t)(k & 1) * kGJ * mp;
+                double* Cn = gjC.p + (size_t)(k & 1) * mp * kGJ;
+                const double* Rp = gjR.p + (size_t)((k + 1) & 1) * kGJ * mp;
+                const double* Cp = gjC.p + (size_t)((k + 1) & 1) * mp * kGJ;
+                hipLaunchKernelGGL(gj_step_kernel, dim3(grid), dim3(kBlock), 0, stream, M, mp, nb, k, Rp, Cp, Rn, Cn, gjFlag.p, setup_prio);
+            }
+        } else if (outer == 1) {
             for (int kb = 0; kb < nb; kb++) {
                 launch_pivot(kb);
                 hipLaunchKernelGGL(gj_panels_kernel, dim3(nb), dim3(kBlock), 0, stream, M, mp, kb, gjP.p, gjR.p, 0, gjC.p, c_ld, 0, setup_prio);

@@ -1243,11 +1243,70 @@ __device__ __forceinline__ int gj_batch_ld(const GjBatch& B, int a) { return (B.
 // E = elements per thread and dimension: E = 4 -> 256 threads (one wave per SIMD), E = 2 -> 1024 threads (four waves per SIMD).  The 64 elimination steps are a
 // dependent chain; with one wave per SIMD every one of a step's ~95 fp64 instructions waits out its predecessor's latency, with four a quarter of the
 // instructions per thread and three other waves to issue from meanwhile (round 3: 39 -> see DESIGN.md section 4 per 64 x 64 block).
+// the elimination itself: r = this thread's E x E sub-block (row block ty, column block tx) of the 64 x 64 tile on entry, of its inverse on return;
+// lds: 4 x 64 doubles (pivot row / column, double-buffered).  Callers that reuse `lds` afterwards put a barrier in between.
+// One elimination step k = kq E + KR with KR -- the pivot's position inside a thread's E x E block -- a compile-time constant (round 4): only the block's row KR
+// and column KR can be the pivot row / column, so 2 E - 1 of its E^2 elements need selects and the others are one FMA each.  With k a run-time value every element
+// carried three 64-bit selects (the step was bound by its ~120 vector instructions per thread: 0.6 us); the values are the same.
+template <int E, int KR>
+__device__ __forceinline__ void gj_scalar_step(double (&r)[E][E], double (*rowk)[kGJ], double (*colk)[kGJ], int kq, int ty, int tx, int* __restrict__ flag) {
+    const int k = kq * E + KR;
+    constexpr int pb = KR & 1;   // (E is even)
+    if (kq == ty) {
+#pragma unroll
+        for (int b = 0; b < E; b++) rowk[pb][tx * E + b] = r[KR][b];
+    }
+    if (kq == tx) {
+#pragma unroll
+        for (int a = 0; a < E; a++) colk[pb][ty * E + a] = r[a][KR];
+    }
+    __syncthreads();
+    const double piv = rowk[pb][k];
+    if (threadIdx.x == 0 && !(piv > 0.)) *flag = 1;
+    // 1 / piv sits on the critical path of all 64 elimination steps: hardware reciprocal + two Newton steps (full precision for a positive,
+    // normal pivot) instead of the IEEE division sequence
+    double ip = __builtin_amdgcn_rcp(piv);
+    ip = fma(fma(-piv, ip, 1.0), ip, ip);
+    ip = fma(fma(-piv, ip, 1.0), ip, ip);
+    double rv[E], cv[E];
+#pragma unroll
+    for (int b = 0; b < E; b++) rv[b] = rowk[pb][tx * E + b];
+#pragma unroll
+    for (int a = 0; a < E; a++) cv[a] = colk[pb][ty * E + a];
+    const bool rowsel = ty == kq, colsel = tx == kq;
+#pragma unroll
+    for (int a = 0; a < E; a++)
+#pragma unroll
+        for (int b = 0; b < E; b++) {
+            const double rowv = rv[b] * ip, colv = -cv[a] * ip;
+            const double base = fma(-cv[a], rowv, r[a][b]);
+            if (a == KR && b == KR) r[a][b] = rowsel ? (colsel ? ip : rowv) : (colsel ? colv : base);
+            else if (a == KR) r[a][b] = rowsel ? rowv : base;
+            else if (b == KR) r[a][b] = colsel ? colv : base;
+            else r[a][b] = base;
+        }
+}
+template <int E>
+__device__ __forceinline__ void gj_invert64_scalar(double (&r)[E][E], double* __restrict__ lds, int* __restrict__ flag) {
+    static_assert(E == 2 || E == 4, "block size");
+    constexpr int kT = kGJ / E;   // threads per dimension
+    double(*rowk)[kGJ] = reinterpret_cast<double(*)[kGJ]>(lds);
+    double(*colk)[kGJ] = reinterpret_cast<double(*)[kGJ]>(lds + 2 * kGJ);
+    const int ty = threadIdx.x / kT, tx = threadIdx.x % kT;
+    for (int kq = 0; kq < kT; kq++) {
+        gj_scalar_step<E, 0>(r, rowk, colk, kq, ty, tx, flag);
+        gj_scalar_step<E, 1>(r, rowk, colk, kq, ty, tx, flag);
+        if (E == 4) {
+            gj_scalar_step<E, 2 % E>(r, rowk, colk, kq, ty, tx, flag);
+            gj_scalar_step<E, 3 % E>(r, rowk, colk, kq, ty, tx, flag);
+        }
+    }
+}
 template <int E>
 __global__ __launch_bounds__((kGJ / E) * (kGJ / E)) void gj_pivot_kernel(double* __restrict__ G_, int ld, int kb, double* __restrict__ Pout_, int* __restrict__ flag, int prio,
                                                                          GjBatch Bt = GjBatch{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}) {
     constexpr int kT = kGJ / E;   // threads per dimension
-    __shared__ double rowk[2][kGJ], colk[2][kGJ];
+    __shared__ double lds[4 * kGJ];
     if (prio) __builtin_amdgcn_s_setprio(3);   // (see gj_panels_kernel)
     double* G = G_;
     double* Pout = Pout_;
@@ -1265,50 +1324,7 @@ __global__ __launch_bounds__((kGJ / E) * (kGJ / E)) void gj_pivot_kernel(double*
     for (int a = 0; a < E; a++)
 #pragma unroll
         for (int b = 0; b < E; b++) r[a][b] = G[(o + ty * E + a) * ld + o + tx * E + b];
-    for (int k = 0; k < kGJ; k++) {
-        const int pb = k & 1, kq = k / E, kr = k % E;
-        if (kq == ty) {
-#pragma unroll
-            for (int a = 0; a < E; a++)
-                if (a == kr) {
-#pragma unroll
-                    for (int b = 0; b < E; b++) rowk[pb][tx * E + b] = r[a][b];
-                }
-        }
-        if (kq == tx) {
-#pragma unroll
-            for (int b = 0; b < E; b++)
-                if (b == kr) {
-#pragma unroll
-                    for (int a = 0; a < E; a++) colk[pb][ty * E + a] = r[a][b];
-                }
-        }
-        __syncthreads();
-        const double piv = rowk[pb][k];
-        if (threadIdx.x == 0 && !(piv > 0.)) *flag = 1;
-        // 1 / piv sits on the critical path of all 64 elimination steps: hardware reciprocal + two Newton steps (full precision for a positive,
-        // normal pivot) instead of the IEEE division sequence
-        double ip = __builtin_amdgcn_rcp(piv);
-        ip = fma(fma(-piv, ip, 1.0), ip, ip);
-        ip = fma(fma(-piv, ip, 1.0), ip, ip);
-        double rv[E], cv[E];
-#pragma unroll
-        for (int b = 0; b < E; b++) rv[b] = rowk[pb][tx * E + b];
-#pragma unroll
-        for (int a = 0; a < E; a++) cv[a] = colk[pb][ty * E + a];
-#pragma unroll
-        for (int a = 0; a < E; a++)
-#pragma unroll
-            for (int b = 0; b < E; b++) {
-                // branch-free selects (v_cndmask): a divergent if/else chain here cost ~1 us per elimination step
-                const bool ik = (ty * E + a) == k, jk = (tx * E + b) == k;
-                const double rowv = rv[b] * ip, colv = -cv[a] * ip;
-                const double base = fma(-cv[a], rowv, r[a][b]);
-                const double vk = jk ? ip : rowv;
-                const double vn = jk ? colv : base;
-                r[a][b] = ik ? vk : vn;
-            }
-    }
+    gj_invert64_scalar<E>(r, lds, flag);
 #pragma unroll
     for (int a = 0; a < E; a++)
 #pragma unroll
@@ -1325,16 +1341,14 @@ __global__ __launch_bounds__((kGJ / E) * (kGJ / E)) void gj_pivot_kernel(double*
 //   (q, q):     Rb = I                                      -> Binv
 // The scalar version's 64 steps each pay a barrier, an LDS round trip and a reciprocal chain (0.6 us per step: 39 us per pivot block, the longest
 // link of the three-launch chain per pivot block that the constraint set-up waits for at <= 128^3).
-__global__ __launch_bounds__(256) void gj_pivot_block4_kernel(double* __restrict__ G, int ld, int kb, double* __restrict__ Pout, int* __restrict__ flag, int prio) {
-    __shared__ double rowb[2][16][16], colb[2][16][16], binv[2][16];
-    if (prio) __builtin_amdgcn_s_setprio(3);   // (see gj_panels_kernel)
+// the elimination itself (r: this thread's 4 x 4 block (ty, tx) of the tile, replaced by the inverse's; lds: kGjBlock4Lds doubles; a caller that reuses
+// `lds` afterwards puts a barrier in between)
+constexpr int kGjBlock4Lds = 2 * (256 + 256 + 16);
+__device__ __forceinline__ void gj_invert64_block4(double (&r)[4][4], double* __restrict__ lds, int* __restrict__ flag) {
+    double(*rowb)[16][16] = reinterpret_cast<double(*)[16][16]>(lds);
+    double(*colb)[16][16] = reinterpret_cast<double(*)[16][16]>(lds + 512);
+    double(*binv)[16] = reinterpret_cast<double(*)[16]>(lds + 1024);
     const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-    const size_t o = (size_t)kb * kGJ;
-    double r[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = 0; b < 4; b++) r[a][b] = G[(o + ty * 4 + a) * ld + o + tx * 4 + b];
     for (int q = 0; q < 16; q++) {
         const int pb = q & 1;
         const bool in_row = ty == q, in_col = tx == q;
@@ -1442,6 +1456,18 @@ __global__ __launch_bounds__(256) void gj_pivot_block4_kernel(double* __restrict
             }
         }
     }
+}
+__global__ __launch_bounds__(256) void gj_pivot_block4_kernel(double* __restrict__ G, int ld, int kb, double* __restrict__ Pout, int* __restrict__ flag, int prio) {
+    __shared__ double lds[kGjBlock4Lds];
+    if (prio) __builtin_amdgcn_s_setprio(3);   // (see gj_panels_kernel)
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    const size_t o = (size_t)kb * kGJ;
+    double r[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) r[a][b] = G[(o + ty * 4 + a) * ld + o + tx * 4 + b];
+    gj_invert64_block4(r, lds, flag);
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -1547,13 +1573,65 @@ __device__ __forceinline__ void gj_tri_decode(unsigned t, int& bi, int& bj) {   
     while ((unsigned)(bi + 1) * (unsigned)(bi + 2) / 2 <= t) bi++;
     bj = (int)(t - (unsigned)bi * (unsigned)(bi + 1) / 2);
 }
+// one 64 x 64 tile (bi >= bj) of the update; kb < 0: no pivot row / column among the tiles of this launch (GJ_REST).  smem: kGjUpdateLds doubles.
+constexpr int kGjUpdateLds = kGJ * (kGJK + 1) + kGJK * (kGJ + 1);
+__device__ __forceinline__ void gj_update_tile(double* __restrict__ G, int ld, int bi, int bj, int kb, const double* __restrict__ R, int r_row0, const double* __restrict__ C,
+                                               int c_ld, int c_col0, int K, double* __restrict__ smem) {
+    double(*cs)[kGJK + 1] = reinterpret_cast<double(*)[kGJK + 1]>(smem);                     // C chunk  [i][k]
+    double(*rs)[kGJ + 1] = reinterpret_cast<double(*)[kGJ + 1]>(smem + kGJ * (kGJK + 1));   // R chunk  [k][j]
+    const size_t oi = (size_t)bi * kGJ, oj = (size_t)bj * kGJ;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    gj_f64x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = gj_f64x4{0., 0., 0., 0.};
+    for (int kc = 0; kc < K; kc += kGJK) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < kGJ * kGJK; t += kBlock) {
+            const int k = t & (kGJK - 1), i = t >> 5;   // 32 consecutive k per row segment of C
+            cs[i][k] = C[(oi + i) * c_ld + c_col0 + kc + k];
+            const int j = t & (kGJ - 1), k2 = t >> 6;   // 64 consecutive j per row segment of R
+            rs[k2][j] = R[(size_t)(r_row0 + kc + k2) * ld + oj + j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < kGJK; kk += 4) {
+            double af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; a++) af[a] = cs[wr * 32 + a * 16 + l15][kk + l4];
+#pragma unroll
+            for (int b = 0; b < 2; b++) bf[b] = rs[kk + l4][wc * 32 + b * 16 + l15];
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    const bool prow = kb >= 0 && bi == kb, pcol = kb >= 0 && bj == kb;
+    const size_t o = (size_t)kb * kGJ;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const size_t row = oi + wr * 32 + a * 16 + l4 + 4 * r, col = oj + wc * 32 + b * 16 + l15;
+                double* dst = &G[row * ld + col];
+                const double v = acc[a][b][r];
+                if (prow) *dst = R[(size_t)(r_row0 + (int)(row - o)) * ld + col];
+                else if (pcol) *dst = -v;
+                else *dst -= v;
+            }
+}
 template <int TILES>
 __global__ __launch_bounds__(kBlock) void gj_update_kernel(double* __restrict__ G_, int ld, int nb, int kb /* inner pivot block; unused for GJ_REST */,
                                                            int k0, int nO, const double* __restrict__ R_ /* [..][ld] */, int r_row0,
                                                            const double* __restrict__ C_ /* [ld][c_ld] */, int c_ld, int c_col0, int K, int prio,
                                                            GjBatch Bt = GjBatch{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}) {
-    __shared__ double cs[kGJ][kGJK + 1];  // C chunk  [i][k]
-    __shared__ double rs[kGJK][kGJ + 1];  // R chunk  [k][j]
+    __shared__ double smem[kGjUpdateLds];
     if (prio) __builtin_amdgcn_s_setprio(3);   // (see gj_panels_kernel)
     double* G = G_;
     const double* R = R_;
@@ -1588,52 +1666,175 @@ __global__ __launch_bounds__(kBlock) void gj_update_kernel(double* __restrict__ 
         if (bi >= k0) bi += nO;
         if (bj >= k0) bj += nO;
     }
-    const size_t oi = (size_t)bi * kGJ, oj = (size_t)bj * kGJ;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int wr = w >> 1, wc = w & 1;
-    const int l15 = lane & 15, l4 = lane >> 4;
+    gj_update_tile(G, ld, bi, bj, TILES != GJ_REST ? kb : -1, R, r_row0, C, c_ld, c_col0, K, smem);
+}
+
+// Round 4: the whole chain link of pivot block k in ONE launch.  The three launches above are a dependent chain per pivot block (pivot -> panels -> update: 80 us per
+// block at m = 2842 on an idle device, and what the constraint set-up -- hence a 64^3 / 128^3 solve, or a thin slab of a multi-GPU run -- waits for).  But step k's pivot
+// and panels read only the CROSS of tiles with a block index k, and the update of step k-1 rewrites that cross without reading it again at step k.  So launch k
+//   * workgroups [0, nb) ("panel role", block b): form the pivot tile and the stored tile X_b of the cross with step k-1's rank-64 update applied ON THE FLY (two
+//     64 x 64 x 64 products on the matrix cores, operands = the previous launch's panels, read straight from L2), invert the pivot tile -- every workgroup for itself:
+//     nb redundant inversions in parallel cost nothing on the critical path and there is no flag to wait for --, and write R_k[:, b] and C_k[b] as gj_panels_kernel does;
+//   * the remaining workgroups ("update role"): step k-1's update of every tile OUTSIDE the cross of k (the cross of k is rewritten by step k's own update from R_k, C_k
+//     alone: rows of the pivot block = R_k, columns = -C_k P_k), exactly as gj_update_kernel<GJ_ALL>.
+// The update of step k-1 thus runs beside the pivot / panels of step k: per pivot block one launch whose length is max(panel role, update role) instead of the sum of three.
+// R / C alternate between two buffers (launch k reads k-1's, writes k's); launch nb is the last update alone.  Same arithmetic, operand order and results as the chain
+// above.
+// The pivot tile is inverted by the scalar 64-step elimination: inside this kernel's register budget it is the faster one (the 4 x 4 block steps want 140 registers).
+// Resources: <= 128 registers (waves_per_eu; the compiler honours it only while the LDS lets four workgroups onto a CU) -- what two waves of the tiered Step-1
+// kernel leave free on a SIMD is 512 - 2 x 184, and a 144-register build of this kernel measurably does NOT run beside them -- and 35.3 KB of LDS (one workgroup
+// per CU beside two of Step 1's, like the 33.5 KB of the separate kernels): x[64][65] holds the pivot tile on its way from the accumulator layout to the 4 x 4
+// blocks, then X_b (through the inversion), finally P; `scratch` serves the inversion.
+constexpr int kGjStepScratch = 8 * (kGJ + 1);
+constexpr int kGjStepLds = kGJ * (kGJ + 1) + kGjStepScratch;
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void gj_step_kernel(
+    double* __restrict__ G, int ld, int nb, int k, const double* __restrict__ Rp /* [64][ld] of step k-1 */, const double* __restrict__ Cp /* [ld][64] */,
+    double* __restrict__ Rn, double* __restrict__ Cn, int* __restrict__ flag, int prio) {
+    __shared__ double smem[kGjStepLds];
+    static_assert(kGjStepLds >= kGjUpdateLds && kGjStepScratch >= 4 * kGJ, "LDS carve");
+    if (prio) __builtin_amdgcn_s_setprio(3);   // (see gj_panels_kernel)
+    const int nN = k < nb ? nb : 0;
+    if ((int)blockIdx.x >= nN) {
+        // ---- update role: step k-1 on every tile (bi >= bj) without a block index k
+        int bi, bj;
+        gj_tri_decode(blockIdx.x - (unsigned)nN, bi, bj);   // over nb - 1 blocks (k < nb) or all nb (last launch)
+        if (k < nb) {
+            if (bi >= k) bi += 1;
+            if (bj >= k) bj += 1;
+        }
+        gj_update_tile(G, ld, bi, bj, k - 1, Rp, 0, Cp, kGJ, 0, kGJ, smem);
+        return;
+    }
+    // ---- panel role
+    double(*x)[kGJ + 1] = reinterpret_cast<double(*)[kGJ + 1]>(smem);
+    double* scratch = smem + kGJ * (kGJ + 1);
+    double(*prow)[kGJ + 1] = reinterpret_cast<double(*)[kGJ + 1]>(scratch);
+    const int b = blockIdx.x;
+    const bool below = b >= k;
+    const int bi = below ? b : k, bj = below ? k : b;   // the stored tile of the cross
+    const size_t o = (size_t)k * kGJ, ob = (size_t)b * kGJ, oi = (size_t)bi * kGJ, oj = (size_t)bj * kGJ;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w >> 1, wc = w & 1, l15 = lane & 15, l4 = lane >> 4;
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    double r[4][4];      // the pivot tile, thread (ty, tx) owning the 4 x 4 block (ty, tx)
+    double* Cb = Cn + ob * kGJ;   // C_k[b], 64 x 64
+    if (k > 0) {
+        // accumulator layout: row = wr 32 + a 16 + l4 + 4 q, col = wc 32 + c 16 + l15.  The pivot tile's product is C[k] R[:, k]; X_b's shares one operand with it:
+        // C[b] R[:, k] below the pivot block, C[k] R[:, b] above it.
+        gj_f64x4 accp[2][2], accx[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) accp[a][c] = accx[a][c] = gj_f64x4{0., 0., 0., 0.};
+        const size_t oo = below ? oi : oj;   // the operand X_b's product does not share
+#pragma unroll 2
+        for (int s4 = 0; s4 < kGJ / 4; s4++) {
+            const int kk = 4 * s4 + l4;
+            double ap[2], bp[2], ox[2];
+#pragma unroll
+            for (int a = 0; a < 2; a++) ap[a] = Cp[(o + wr * 32 + a * 16 + l15) * kGJ + kk];
+#pragma unroll
+            for (int c = 0; c < 2; c++) bp[c] = Rp[(size_t)kk * ld + o + wc * 32 + c * 16 + l15];
+#pragma unroll
+            for (int e = 0; e < 2; e++) ox[e] = below ? Cp[(oo + wr * 32 + e * 16 + l15) * kGJ + kk] : Rp[(size_t)kk * ld + oo + wc * 32 + e * 16 + l15];
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    accp[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[a], bp[c], accp[a][c], 0, 0, 0);
+                    accx[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(below ? ox[a] : ap[a], below ? bp[c] : ox[c], accx[a][c], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const size_t row = wr * 32 + a * 16 + l4 + 4 * q, col = wc * 32 + c * 16 + l15;
+                    x[row][col] = G[(o + row) * ld + o + col] - accp[a][c][q];
+                }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) r[a][c] = x[ty * 4 + a][tx * 4 + c];
+        __syncthreads();
+        const bool pcol = b == k - 1;   // the tile (k, k-1) lies in the pivot column of step k-1: -C P, no base
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const size_t row = wr * 32 + a * 16 + l4 + 4 * q, col = wc * 32 + c * 16 + l15;
+                    const double base = G[(oi + row) * ld + oj + col];
+                    x[row][col] = pcol ? -accx[a][c][q] : base - accx[a][c][q];
+                }
+    } else {
+        for (int t = threadIdx.x; t < kGJ * kGJ; t += kBlock) {
+            const int i = t / kGJ, j = t % kGJ;
+            x[i][j] = G[(oi + i) * ld + oj + j];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) r[a][c] = G[(o + ty * 4 + a) * ld + o + tx * 4 + c];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < kGJ * kGJ; t += kBlock) {
+        const int i = t / kGJ, j = t % kGJ;
+        Cb[i * kGJ + j] = below ? x[i][j] : -x[j][i];
+    }
+    gj_invert64_scalar<4>(r, scratch, flag);
+    if (b == k) {   // the pivot block's own R column carries P
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) Rn[(size_t)(ty * 4 + a) * ld + ob + tx * 4 + c] = r[a][c];
+        return;
+    }
+    // P: registers -> scratch, 8 rows at a time -> the lanes that feed it to the matrix cores (rows wr 32 + a 16 + l15, k = 4 s + l4)
+    double pa[2][kGJ / 4];
+#pragma unroll
+    for (int pass = 0; pass < 8; pass++) {
+        __syncthreads();
+        if ((ty >> 1) == pass) {
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) prow[(ty & 1) * 4 + a][tx * 4 + c] = r[a][c];
+        }
+        __syncthreads();
+        if (wr == (pass >> 2) && (l15 >> 3) == (pass & 1)) {
+#pragma unroll
+            for (int s4 = 0; s4 < kGJ / 4; s4++) pa[(pass >> 1) & 1][s4] = prow[l15 & 7][4 * s4 + l4];
+        }
+    }
     gj_f64x4 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++) acc[a][b] = gj_f64x4{0., 0., 0., 0.};
-    for (int kc = 0; kc < K; kc += kGJK) {
-        __syncthreads();
-        for (int t = threadIdx.x; t < kGJ * kGJK; t += kBlock) {
-            const int k = t & (kGJK - 1), i = t >> 5;   // 32 consecutive k per row segment of C
-            cs[i][k] = C[(oi + i) * c_ld + c_col0 + kc + k];
-            const int j = t & (kGJ - 1), k2 = t >> 6;   // 64 consecutive j per row segment of R
-            rs[k2][j] = R[(size_t)(r_row0 + kc + k2) * ld + oj + j];
+        for (int c = 0; c < 2; c++) acc[a][c] = gj_f64x4{0., 0., 0., 0.};
+#pragma unroll
+    for (int s4 = 0; s4 < kGJ / 4; s4++) {
+        const int kk = 4 * s4 + l4;
+        double bf[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int j = wc * 32 + c * 16 + l15;
+            bf[c] = (b > k) ? x[j][kk] : x[kk][j];   // R[:, b] = P X^T below the pivot block, P X above it
         }
-        __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < kGJK; kk += 4) {
-            double af[2], bf[2];
+        for (int a = 0; a < 2; a++)
 #pragma unroll
-            for (int a = 0; a < 2; a++) af[a] = cs[wr * 32 + a * 16 + l15][kk + l4];
-#pragma unroll
-            for (int b = 0; b < 2; b++) bf[b] = rs[kk + l4][wc * 32 + b * 16 + l15];
-#pragma unroll
-            for (int a = 0; a < 2; a++)
-#pragma unroll
-                for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
-        }
+            for (int c = 0; c < 2; c++) acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[a][s4], bf[c], acc[a][c], 0, 0, 0);
     }
-    const bool prow = TILES != GJ_REST && bi == kb, pcol = TILES != GJ_REST && bj == kb;
-    const size_t o = (size_t)kb * kGJ;
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++)
+        for (int c = 0; c < 2; c++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const size_t row = oi + wr * 32 + a * 16 + l4 + 4 * r, col = oj + wc * 32 + b * 16 + l15;
-                double* dst = &G[row * ld + col];
-                const double v = acc[a][b][r];
-                if (prow) *dst = R[(size_t)(r_row0 + (int)(row - o)) * ld + col];
-                else if (pcol) *dst = -v;
-                else *dst -= v;
-            }
+            for (int q = 0; q < 4; q++) Rn[(size_t)(wr * 32 + a * 16 + l4 + 4 * q) * ld + ob + wc * 32 + c * 16 + l15] = acc[a][c][q];
 }
 
 // after the last pivot block: G[bj, bi] = G[bi, bj]^T for bi > bj (the inverse is symmetric; only its block-lower triangle was kept)

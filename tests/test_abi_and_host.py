@@ -191,18 +191,25 @@ def test_kernel_register_schedules():
     dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.splitlines()
     by_name = {re.sub(r"\(.*", "", d): res[n] for n, d in zip(names, dem)}
     spilled = {k: v["VGPRs Spill"] for k, v in by_name.items() if v.get("VGPRs Spill", 0)}   # (scalar registers spill into vector lanes: harmless)
+    # gj_step_kernel runs under a 128-register cap (it has to fit beside Step 1's waves): the compiler parks a few address registers and 12 operand registers
+    # of the last product in scratch, each stored and reloaded ONCE per workgroup, outside every loop (checked in the ISA; a capped build with 74 registers
+    # spilled inside the inversion loop measured 1.5x slower and is what this bound keeps out)
+    step_spill = spilled.pop("shm::gj_step_kernel", 0)
+    assert step_spill <= 16, step_spill
     assert not spilled, spilled
     conv = by_name["void shm::conv_normalize_kernel<double, 4>"]
     assert conv["VGPRs"] >= 200 and conv["Occupancy"] == 2, conv
     # the tiered fp64 Step 1 must leave room on every SIMD for a wave of the set-up kernels (two of its waves + one of theirs <= 512 registers, LDS likewise):
     # that is what lets the constraint set-up run WHILE Step 1 runs instead of in the gaps between its launches
     tier = by_name["void shm::conv_tiered_kernel<4>"]
-    assert tier["VGPRs"] <= 184 and tier["LDS Size"] <= 52 * 1024, tier      # (two of its workgroups per CU + a set-up workgroup of <= 40 KB: 144 of 160 KB)
+    assert tier["VGPRs"] <= 184 and tier["LDS Size"] <= 52 * 1024, tier      # (two of its workgroups per CU + a set-up workgroup of <= 42 KB: 146 of 160 KB)
     room = 512 - 2 * ((tier["VGPRs"] + 7) // 8 * 8)
-    for k in ("void shm::dgemm_rm_kernel<1>", "shm::gj_pivot_block4_kernel", "shm::gj_panels_kernel", "void shm::gj_update_kernel<0>", "shm::schur_assemble_kernel", "shm::green_symbol_kernel"):
+    for k in ("void shm::dgemm_rm_kernel<1>", "shm::gj_pivot_block4_kernel", "shm::gj_panels_kernel", "void shm::gj_update_kernel<0>", "shm::schur_assemble_kernel", "shm::green_symbol_kernel",
+              "shm::gj_step_kernel"):
         v = by_name[k]
         waves_per_simd = 4 if "gj_pivot_kernel<2>" in k else 1      # (1024-thread workgroup: four waves on every SIMD)
-        assert waves_per_simd * ((v["VGPRs"] + v.get("AGPRs", 0) + 7) // 8 * 8) <= room and v["LDS Size"] <= 40 * 1024, (k, v, room)
+        # (round 4, measured: a 144-register build of gj_step_kernel does NOT run beside Step 1 although 2 x 184 + 144 = 512; the 137 of gj_pivot_block4_kernel do)
+        assert waves_per_simd * (v["VGPRs"] + v.get("AGPRs", 0)) <= min(room, 140) and v["LDS Size"] <= 42 * 1024, (k, v, room)
     conv32 = by_name["void shm::conv_normalize_kernel<float, 8>"]   # two sources in flight, three waves per SIMD (measured best with the tile queue)
     assert conv32["VGPRs"] <= 168 and conv32["Occupancy"] >= 3, conv32
     for k, v in by_name.items():   # the shipped shape of the fused stencil-CG sweeps: two rows per lane, four waves per SIMD
