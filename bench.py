@@ -478,7 +478,7 @@ def main():
             out["roofline"] = {"kernel": s1["kernel"], "bound": "valu",
                                "bound_detail": "compute: vector-ALU issue (no matrix-core shape in the kernel, no MFMA instruction); peak = the vector peaks of the two "
                                                "arithmetic tiers (78.6 TFLOP/s fp64, 157.3 TFLOP/s fp32) weighted by the pairs each tier evaluated; SQ counters of this "
-                                               "kernel: profiles/r03_sq_counters_conv.txt",
+                                               "kernel: profiles/r04_sq_counters_conv.txt",
                                "achieved": s1["achieved_TFLOPs_18_per_evaluated_pair"], "peak": s1["peak_TFLOPs_weighted"], "unit": "TFLOP/s", "frac": s1["frac"],
                                "traffic": conv_traffic,
                                "note": "%d launch(es) per step, duration = phases_ms.ms_conv (HIP events on the solver's stream around all of them); achieved = 18 nominal "

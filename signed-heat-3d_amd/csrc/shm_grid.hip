@@ -467,7 +467,8 @@ struct Solver final : SolverBase {
     hipStream_t stream = nullptr;   // conv, divergence, CG
     hipStream_t stream2 = nullptr;  // constraint set-up ((A A^T)^-1), overlapped with the Step-1 kernel
     hipStream_t stream3 = nullptr;  // explicit Schur complement of the dual solver: beside the inversion of G (stream2) and Step 1 (created on first use)
-    std::unique_ptr<Event> e_sch_in, e_sch_done;
+    std::unique_ptr<Event> e_sch_in, e_sch_done, e_gs_done;
+    bool gs_early = false;   // this solve's Green's table was queued before the host built the rows (enqueue_green_table)
     hipStream_t stream_h = nullptr;  // halo exchange of the fused primal CG, overlapped with the interior z chunks of its DIR sweep (created on first use)
     int n = 0, alloc_n = -1;
     size_t N = 0;
@@ -1207,6 +1208,12 @@ struct Solver final : SolverBase {
         static const int prio_env = getenv("SHM_SETUP_PRIO") ? atoi(getenv("SHM_SETUP_PRIO")) : -1;   // A/B knob: 0 / 1
         setup_prio = prio_env >= 0 ? prio_env : (conv_tiered && conv_est_total_ms >= 150. && conv_est_total_ms < 1e29 ? 0 : 1);   // (estimate: 256^3 bunny 40, 512^3 320 / 160 ms)
         auto lap = [&](const char* what) { log("[shm]   setup %-28s %.2f ms", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count()); };
+        gs_early = green_table_early_ok();
+        if (gs_early) {
+            enqueue_green_table(stream);
+            if (!e_gs_done) e_gs_done.reset(new Event());
+            e_gs_done->record(stream);
+        }
         build_rows();
         lap("rows");
         const size_t plane = (size_t)n * n;
@@ -1813,18 +1820,22 @@ struct Solver final : SolverBase {
         const double schur_est_ms = 2.2e-7 * (double)m * (double)m;
         return force || dual_direct || conv_est_total_ms >= 3.0 * schur_est_ms;
     }
-    void prepare_schur() {
-        hipStream_t st = stream2;
-        have_S = false;
-        if (!schur_wanted()) return;
+    // The Green's table of the grid (depends on n and h alone) on `st`.  Round 4: when the number of sources already guarantees the direct dual solve (m <= S <=
+    // its limit), build_constraints() queues this BEFORE the host builds the constraint rows, so the table's kernels (0.9 ms at 256^3, 10 ms at 512^3) run while
+    // the host works (1 ms) instead of after it; otherwise prepare_schur() queues it once m is known.
+    bool green_table_early_ok() const {
+        static const bool off = getenv("SHM_GREEN_LATE") != nullptr;   // A/B knob
+        static const int direct_max_m = getenv("SHM_DUAL_DIRECT_MAX_M") ? atoi(getenv("SHM_DUAL_DIRECT_MAX_M")) : 4096;
+        return !off && dual_direct_requested && getenv("SHM_DUAL_NO_DIRECT") == nullptr && getenv("SHM_DUAL_NO_DENSE_S") == nullptr && total_slabs == 1 && precond_available() &&
+               !gemm_dct() && n <= 512 && S > 0 && S <= direct_max_m;
+    }
+    void enqueue_green_table(hipStream_t st) {
         const int P = n + 8;   // leading dimension of the last table index (rows stay 64-byte aligned)
         const size_t n1 = (size_t)n + 1;
-        // T is rebuilt with every solve (0.85 ms at 256^3, 10 ms at 512^3, beside Step 1: +1 % / +2.5 % of a solve), so that a timed solve contains all of
-        // its own work; SHM_SCHUR_KEEP_TABLE=1 keeps it while n and h stay the same (it depends on nothing else)
         static const bool keep_table = getenv("SHM_SCHUR_KEEP_TABLE") != nullptr;
         if (!keep_table) gs_n = 0;
-        if (!(gs_n == n && gs_cell == cell)) {
-            gs_n = 0;   // (table invalid until enqueue_schur has queued its construction)
+        if (gs_n == n && gs_cell == cell) return;
+        {
             const double pi = 3.14159265358979323846;
             h_gs_lam.resize(n);
             h_gs_ctab.resize(2 * (size_t)n);
@@ -1834,6 +1845,45 @@ struct Solver final : SolverBase {
             gs_ctab.upload(h_gs_ctab, st);
             gs_T.alloc(n1 * n1 * P);
         }
+        {
+            // scratch of the three contractions: W0 (the symbol) is dead once the first product has been formed, so the second product's output W2 reuses
+            // its storage (two scratch arrays of ~n^3 doubles beside the table instead of three: 3.3 instead of 4.4 GB at 512^3, kept for the next solve)
+            DevArray<double>&W0 = gs_W0, &W1 = gs_W1, &W2 = gs_W0;
+            gs_Cm.alloc(n1 * n);
+            gs_Ct.alloc((size_t)n * P);
+            W0.alloc(std::max((size_t)n * n * n, (size_t)n * n1 * P));
+            W1.alloc((size_t)n * n * P);
+            HIPCHK(hipMemsetAsync(gs_Ct.p, 0, (size_t)n * P * sizeof(double), st));
+            hipLaunchKernelGGL(cosine_tables_kernel, dim3(grid_for(n1 * n, 1024)), dim3(kBlock), 0, st, n, P, gs_ctab.p, gs_Cm.p, gs_Ct.p);
+            hipLaunchKernelGGL(green_symbol_kernel, dim3(grid_for((size_t)n * n * n, 4096)), dim3(kBlock), 0, st, n, gs_lam.p, W0.p);
+            // beside the tiered fp64 Step 1 (two 184-register waves per SIMD) only the narrow shape fits on a SIMD; otherwise the 128 x 128 tiles
+            static const bool gemm_wide_env = getenv("SHM_GREEN_WIDE") != nullptr;   // A/B knob
+            const bool narrow = (conv_tiered || getenv("SHM_GREEN_NARROW") != nullptr) && !gemm_wide_env;
+            auto tiles = [](size_t v) { return (unsigned)((v + kGemmT - 1) / kGemmT); };
+            auto gemm = [&](unsigned batches, int M, int N, int K, const double* A, int lda, long long sA, const double* B, int ldb, long long sB, double* C, int ldc, long long sC) {
+                if (narrow)
+                    hipLaunchKernelGGL(dgemm_rm_kernel<1>, dim3((unsigned)((N + 31) / 32), tiles((size_t)M), batches), dim3(kBlock), 0, st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, setup_prio);
+                else
+                    hipLaunchKernelGGL(dgemm_rm_kernel<4>, dim3(tiles((size_t)N), tiles((size_t)M), batches), dim3(kBlock), 0, st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, setup_prio);
+            };
+            // W1[(k1,k2)][d3] = sum_k3 W0[(k1,k2)][k3] Ct[k3][d3]
+            gemm(1, n * n, P, n, W0.p, n, 0LL, gs_Ct.p, P, 0LL, W1.p, P, 0LL);
+            // W2[k1][d2][d3] = sum_k2 Cm[d2][k2] W1[k1][k2][d3]   (one product per k1)
+            gemm((unsigned)n, (int)n1, P, n, gs_Cm.p, n, 0LL, W1.p, P, (long long)n * P, W2.p, P, (long long)(n1 * P));
+            // T[d1][(d2,d3)] = sum_k1 Cm[d1][k1] W2[k1][(d2,d3)]
+            gemm(1, (int)n1, (int)(n1 * P), n, gs_Cm.p, n, 0LL, W2.p, (int)(n1 * P), 0LL, gs_T.p, (int)(n1 * P), 0LL);
+            HIPCHK(hipGetLastError());
+            gs_n = n;
+            gs_cell = cell;
+        }
+    }
+    void prepare_schur() {
+        hipStream_t st = stream2;
+        have_S = false;
+        if (!schur_wanted()) return;
+        // T is rebuilt with every solve (0.85 ms at 256^3, 10 ms at 512^3, beside Step 1: +1 % / +2.5 % of a solve), so that a timed solve contains all of
+        // its own work; SHM_SCHUR_KEEP_TABLE=1 keeps it while n and h stay the same (it depends on nothing else)
+        if (!gs_early) enqueue_green_table(st);
         // rows in Morton order of their cells: the 16 x 16 tiles of the assembly then read neighbouring table entries
         std::vector<std::pair<uint64_t, int>> key((size_t)m);
         auto spread = [](uint64_t v) {
@@ -1877,38 +1927,7 @@ struct Solver final : SolverBase {
         hipStream_t st = dual_direct ? stream2 : stream3;
         HIPCHK(hipStreamWaitEvent(st, e_sch_in->e, 0));
         const int P = n + 8;
-        const size_t n1 = (size_t)n + 1;
-        if (!(gs_n == n && gs_cell == cell)) {
-            // scratch of the three contractions: W0 (the symbol) is dead once the first product has been formed, so the second product's output W2 reuses
-            // its storage (two scratch arrays of ~n^3 doubles beside the table instead of three: 3.3 instead of 4.4 GB at 512^3, kept for the next solve)
-            DevArray<double>&W0 = gs_W0, &W1 = gs_W1, &W2 = gs_W0;
-            gs_Cm.alloc(n1 * n);
-            gs_Ct.alloc((size_t)n * P);
-            W0.alloc(std::max((size_t)n * n * n, (size_t)n * n1 * P));
-            W1.alloc((size_t)n * n * P);
-            HIPCHK(hipMemsetAsync(gs_Ct.p, 0, (size_t)n * P * sizeof(double), st));
-            hipLaunchKernelGGL(cosine_tables_kernel, dim3(grid_for(n1 * n, 1024)), dim3(kBlock), 0, st, n, P, gs_ctab.p, gs_Cm.p, gs_Ct.p);
-            hipLaunchKernelGGL(green_symbol_kernel, dim3(grid_for((size_t)n * n * n, 4096)), dim3(kBlock), 0, st, n, gs_lam.p, W0.p);
-            // beside the tiered fp64 Step 1 (two 184-register waves per SIMD) only the narrow shape fits on a SIMD; otherwise the 128 x 128 tiles
-            static const bool gemm_wide_env = getenv("SHM_GREEN_WIDE") != nullptr;   // A/B knob
-            const bool narrow = (conv_tiered || getenv("SHM_GREEN_NARROW") != nullptr) && !gemm_wide_env;
-            auto tiles = [](size_t v) { return (unsigned)((v + kGemmT - 1) / kGemmT); };
-            auto gemm = [&](unsigned batches, int M, int N, int K, const double* A, int lda, long long sA, const double* B, int ldb, long long sB, double* C, int ldc, long long sC) {
-                if (narrow)
-                    hipLaunchKernelGGL(dgemm_rm_kernel<1>, dim3((unsigned)((N + 31) / 32), tiles((size_t)M), batches), dim3(kBlock), 0, st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, setup_prio);
-                else
-                    hipLaunchKernelGGL(dgemm_rm_kernel<4>, dim3(tiles((size_t)N), tiles((size_t)M), batches), dim3(kBlock), 0, st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, setup_prio);
-            };
-            // W1[(k1,k2)][d3] = sum_k3 W0[(k1,k2)][k3] Ct[k3][d3]
-            gemm(1, n * n, P, n, W0.p, n, 0LL, gs_Ct.p, P, 0LL, W1.p, P, 0LL);
-            // W2[k1][d2][d3] = sum_k2 Cm[d2][k2] W1[k1][k2][d3]   (one product per k1)
-            gemm((unsigned)n, (int)n1, P, n, gs_Cm.p, n, 0LL, W1.p, P, (long long)n * P, W2.p, P, (long long)(n1 * P));
-            // T[d1][(d2,d3)] = sum_k1 Cm[d1][k1] W2[k1][(d2,d3)]
-            gemm(1, (int)n1, (int)(n1 * P), n, gs_Cm.p, n, 0LL, W2.p, (int)(n1 * P), 0LL, gs_T.p, (int)(n1 * P), 0LL);
-            HIPCHK(hipGetLastError());
-            gs_n = n;
-            gs_cell = cell;
-        }
+        if (gs_early) HIPCHK(hipStreamWaitEvent(st, e_gs_done->e, 0));
         HIPCHK(hipMemsetAsync(Sdense.p, 0, (size_t)mp * mp * sizeof(double), st));
         const unsigned mt = (unsigned)((m + 15) / 16);
         hipLaunchKernelGGL(schur_assemble_kernel, dim3(mt, mt), dim3(kBlock), 0, st, m, mp, n, P, d_rowX.p, d_rowT.p, gs_T.p, Sdense.p, setup_prio);

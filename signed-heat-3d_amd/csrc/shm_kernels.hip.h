@@ -1718,48 +1718,56 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     double r[4][4];      // the pivot tile, thread (ty, tx) owning the 4 x 4 block (ty, tx)
     double* Cb = Cn + ob * kGJ;   // C_k[b], 64 x 64
     if (k > 0) {
-        // accumulator layout: row = wr 32 + a 16 + l4 + 4 q, col = wc 32 + c 16 + l15.  The pivot tile's product is C[k] R[:, k]; X_b's shares one operand with it:
-        // C[b] R[:, k] below the pivot block, C[k] R[:, b] above it.
-        gj_f64x4 accp[2][2], accx[2][2];
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int c = 0; c < 2; c++) accp[a][c] = accx[a][c] = gj_f64x4{0., 0., 0., 0.};
-        const size_t oo = below ? oi : oj;   // the operand X_b's product does not share
-#pragma unroll 2
-        for (int s4 = 0; s4 < kGJ / 4; s4++) {
-            const int kk = 4 * s4 + l4;
-            double ap[2], bp[2], ox[2];
-#pragma unroll
-            for (int a = 0; a < 2; a++) ap[a] = Cp[(o + wr * 32 + a * 16 + l15) * kGJ + kk];
-#pragma unroll
-            for (int c = 0; c < 2; c++) bp[c] = Rp[(size_t)kk * ld + o + wc * 32 + c * 16 + l15];
-#pragma unroll
-            for (int e = 0; e < 2; e++) ox[e] = below ? Cp[(oo + wr * 32 + e * 16 + l15) * kGJ + kk] : Rp[(size_t)kk * ld + oo + wc * 32 + e * 16 + l15];
+        // accumulator layout: row = wr 32 + a 16 + l4 + 4 q, col = wc 32 + c 16 + l15.  Two products C[rows] R[:, cols], one after the other (together their
+        // accumulators and operands do not fit the register cap), each in two groups of eight k-steps whose 32 operand loads are issued together, ahead of the
+        // group's matrix instructions: left to itself the compiler waits for every k-step's loads before it issues the next ones -- 16 round trips to L2, a
+        // quarter of this role's time.
+        auto product = [&](gj_f64x4(&acc)[2][2], size_t orow, size_t ocol) {
 #pragma unroll
             for (int a = 0; a < 2; a++)
 #pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    accp[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[a], bp[c], accp[a][c], 0, 0, 0);
-                    accx[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(below ? ox[a] : ap[a], below ? bp[c] : ox[c], accx[a][c], 0, 0, 0);
+                for (int c = 0; c < 2; c++) acc[a][c] = gj_f64x4{0., 0., 0., 0.};
+#pragma unroll 1
+            for (int g = 0; g < 2; g++) {
+                double af[8][2], bf[8][2];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int kk = 32 * g + 4 * u + l4;
+#pragma unroll
+                    for (int a = 0; a < 2; a++) af[u][a] = Cp[(orow + wr * 32 + a * 16 + l15) * kGJ + kk];
+#pragma unroll
+                    for (int c = 0; c < 2; c++) bf[u][c] = Rp[(size_t)kk * ld + ocol + wc * 32 + c * 16 + l15];
                 }
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+#pragma unroll
+                    for (int a = 0; a < 2; a++)
+#pragma unroll
+                        for (int c = 0; c < 2; c++) acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u][a], bf[u][c], acc[a][c], 0, 0, 0);
+            }
+        };
+        {
+            gj_f64x4 accp[2][2];
+            product(accp, o, o);   // the pivot tile: G[k, k] - C[k] R[:, k]
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int c = 0; c < 2; c++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const size_t row = wr * 32 + a * 16 + l4 + 4 * q, col = wc * 32 + c * 16 + l15;
+                        x[row][col] = G[(o + row) * ld + o + col] - accp[a][c][q];
+                    }
         }
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int c = 0; c < 2; c++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const size_t row = wr * 32 + a * 16 + l4 + 4 * q, col = wc * 32 + c * 16 + l15;
-                    x[row][col] = G[(o + row) * ld + o + col] - accp[a][c][q];
-                }
+        gj_f64x4 accx[2][2];
+        product(accx, oi, oj);     // X_b: G[bi, bj] - C[bi] R[:, bj]
         __syncthreads();
 #pragma unroll
         for (int a = 0; a < 4; a++)
 #pragma unroll
             for (int c = 0; c < 4; c++) r[a][c] = x[ty * 4 + a][tx * 4 + c];
         __syncthreads();
-        const bool pcol = b == k - 1;   // the tile (k, k-1) lies in the pivot column of step k-1: -C P, no base
+        const double keep = b == k - 1 ? 0. : 1.;   // the tile (k, k-1) lies in the pivot column of step k-1: -C P, no base
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -1767,8 +1775,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const size_t row = wr * 32 + a * 16 + l4 + 4 * q, col = wc * 32 + c * 16 + l15;
-                    const double base = G[(oi + row) * ld + oj + col];
-                    x[row][col] = pcol ? -accx[a][c][q] : base - accx[a][c][q];
+                    // (keep = 0 instead of a select: a select lets the compiler branch around each load, and it then waited for the 16 loads one by one)
+                    x[row][col] = G[(oi + row) * ld + oj + col] * keep - accx[a][c][q];
                 }
     } else {
         for (int t = threadIdx.x; t < kGJ * kGJ; t += kBlock) {
