@@ -1740,7 +1740,7 @@ struct Solver final : SolverBase {
         HIPCHK(hipMemsetAsync(gjFlag.p, 0, sizeof(int), stream));
         const int c_ld = outer * kGJ;
         static const int pivot_env = getenv("SHM_GJ_PIVOT_E") ? atoi(getenv("SHM_GJ_PIVOT_E")) : 0;
-        static const bool classic = getenv("SHM_GJ_CLASSIC") != nullptr;   // A/B knob: three dependent launches per pivot block (rounds 1-3)
+        const bool classic = getenv("SHM_GJ_CLASSIC") != nullptr;   // A/B knob, read per inversion (a test flips it inside one process): three dependent launches per pivot block (rounds 1-3)
         // one launch per pivot block (gj_step_kernel; it inverts the pivot tiles by the scalar elimination) unless a pivot kernel is asked for explicitly
         const bool stepped = outer == 1 && !classic && pivot_env == 0;
         const int pivot_e = pivot_env ? pivot_env : (refined_later ? 16 : 4);   // 16 = block Gauss-Jordan with 4 x 4 pivot blocks (round 3);   // A/B knob: 4 = 256 threads; 2 = 1024 threads (2 % faster on an idle GPU, but four 40-register waves per SIMD do not fit beside Step 1)

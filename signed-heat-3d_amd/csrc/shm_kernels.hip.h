@@ -1286,13 +1286,103 @@ __device__ __forceinline__ void gj_scalar_step(double (&r)[E][E], double (*rowk)
             else r[a][b] = base;
         }
 }
-template <int E>
+// Two elimination steps (k = kq E + KR and k + 1, KR even: both pivots lie in the same E x E blocks) behind ONE barrier (round 4).  The owners publish rows and
+// columns k and k + 1 as they are BEFORE step k; every thread then forms row / column k + 1 as step k leaves them itself -- eight extra FMAs, the very
+// operations their owners perform, so the values (and the inverse) are bit-identical to two single steps -- and applies both steps to its block.  Saves one
+// LDS write -> barrier -> read round trip of the ~1000 cycles a single step takes.  lds: 2 buffers x 4 x 64 doubles.
+template <int E, int KR>
+__device__ __forceinline__ void gj_scalar_step2(double (&r)[E][E], double* __restrict__ lds, int kq, int ty, int tx, int* __restrict__ flag) {
+    static_assert(KR % 2 == 0 && KR + 1 < E, "a pair of pivots inside one block");
+    const int k = kq * E + KR;
+    double* buf = lds + ((KR >> 1) & 1) * 4 * kGJ;
+    double *rowA = buf, *rowB = buf + kGJ, *colA = buf + 2 * kGJ, *colB = buf + 3 * kGJ;
+    if (kq == ty) {
+#pragma unroll
+        for (int b = 0; b < E; b++) {
+            rowA[tx * E + b] = r[KR][b];
+            rowB[tx * E + b] = r[KR + 1][b];
+        }
+    }
+    if (kq == tx) {
+#pragma unroll
+        for (int a = 0; a < E; a++) {
+            colA[ty * E + a] = r[a][KR];
+            colB[ty * E + a] = r[a][KR + 1];
+        }
+    }
+    __syncthreads();
+    const double piv0 = rowA[k], m01 = rowA[k + 1], m10 = colA[k + 1], m11 = rowB[k + 1];
+    if (threadIdx.x == 0 && !(piv0 > 0.)) *flag = 1;
+    double ip0 = __builtin_amdgcn_rcp(piv0);
+    ip0 = fma(fma(-piv0, ip0, 1.0), ip0, ip0);
+    ip0 = fma(fma(-piv0, ip0, 1.0), ip0, ip0);
+    double rv0[E], cv0[E], rv1[E], cv1[E];
+#pragma unroll
+    for (int b = 0; b < E; b++) {
+        rv0[b] = rowA[tx * E + b];
+        rv1[b] = rowB[tx * E + b];
+    }
+#pragma unroll
+    for (int a = 0; a < E; a++) {
+        cv0[a] = colA[ty * E + a];
+        cv1[a] = colB[ty * E + a];
+    }
+    const bool rowsel = ty == kq, colsel = tx == kq;
+    const double rowv0_k1 = m01 * ip0;   // M'[k][k+1]
+    // row / column k + 1 after step k (what their owners hold then)
+#pragma unroll
+    for (int b = 0; b < E; b++) {
+        const double base = fma(-m10, rv0[b] * ip0, rv1[b]);
+        rv1[b] = (b == KR && colsel) ? -m10 * ip0 : base;
+    }
+#pragma unroll
+    for (int a = 0; a < E; a++) {
+        const double base = fma(-cv0[a], rowv0_k1, cv1[a]);
+        cv1[a] = (a == KR && rowsel) ? rowv0_k1 : base;
+    }
+    const double piv1 = fma(-m10, rowv0_k1, m11);
+    if (threadIdx.x == 0 && !(piv1 > 0.)) *flag = 1;
+    double ip1 = __builtin_amdgcn_rcp(piv1);
+    ip1 = fma(fma(-piv1, ip1, 1.0), ip1, ip1);
+    ip1 = fma(fma(-piv1, ip1, 1.0), ip1, ip1);
+    // step k, then step k + 1, on this thread's block (as gj_scalar_step)
+#pragma unroll
+    for (int a = 0; a < E; a++)
+#pragma unroll
+        for (int b = 0; b < E; b++) {
+            const double rowv = rv0[b] * ip0, colv = -cv0[a] * ip0;
+            const double base = fma(-cv0[a], rowv, r[a][b]);
+            if (a == KR && b == KR) r[a][b] = rowsel ? (colsel ? ip0 : rowv) : (colsel ? colv : base);
+            else if (a == KR) r[a][b] = rowsel ? rowv : base;
+            else if (b == KR) r[a][b] = colsel ? colv : base;
+            else r[a][b] = base;
+        }
+#pragma unroll
+    for (int a = 0; a < E; a++)
+#pragma unroll
+        for (int b = 0; b < E; b++) {
+            const double rowv = rv1[b] * ip1, colv = -cv1[a] * ip1;
+            const double base = fma(-cv1[a], rowv, r[a][b]);
+            if (a == KR + 1 && b == KR + 1) r[a][b] = rowsel ? (colsel ? ip1 : rowv) : (colsel ? colv : base);
+            else if (a == KR + 1) r[a][b] = rowsel ? rowv : base;
+            else if (b == KR + 1) r[a][b] = colsel ? colv : base;
+            else r[a][b] = base;
+        }
+}
+template <int E, bool PAIRS = false>
 __device__ __forceinline__ void gj_invert64_scalar(double (&r)[E][E], double* __restrict__ lds, int* __restrict__ flag) {
     static_assert(E == 2 || E == 4, "block size");
     constexpr int kT = kGJ / E;   // threads per dimension
     double(*rowk)[kGJ] = reinterpret_cast<double(*)[kGJ]>(lds);
     double(*colk)[kGJ] = reinterpret_cast<double(*)[kGJ]>(lds + 2 * kGJ);
     const int ty = threadIdx.x / kT, tx = threadIdx.x % kT;
+    if (PAIRS) {
+        for (int kq = 0; kq < kT; kq++) {
+            gj_scalar_step2<E, 0>(r, lds, kq, ty, tx, flag);
+            if (E == 4) gj_scalar_step2<E, 2 % E>(r, lds, kq, ty, tx, flag);
+        }
+        return;
+    }
     for (int kq = 0; kq < kT; kq++) {
         gj_scalar_step<E, 0>(r, rowk, colk, kq, ty, tx, flag);
         gj_scalar_step<E, 1>(r, rowk, colk, kq, ty, tx, flag);
@@ -1685,13 +1775,16 @@ __global__ __launch_bounds__(kBlock) void gj_update_kernel(double* __restrict__ 
 // kernel leave free on a SIMD is 512 - 2 x 184, and a 144-register build of this kernel measurably does NOT run beside them -- and 35.3 KB of LDS (one workgroup
 // per CU beside two of Step 1's, like the 33.5 KB of the separate kernels): x[64][65] holds the pivot tile on its way from the accumulator layout to the 4 x 4
 // blocks, then X_b (through the inversion), finally P; `scratch` serves the inversion.
+#ifndef SHM_GJ_STEP_PAIRS
+#define SHM_GJ_STEP_PAIRS 1   // gj_step_kernel's pivot inversion: two elimination steps per barrier (0: one, as in the separate pivot kernel -- A/B builds)
+#endif
 constexpr int kGjStepScratch = 8 * (kGJ + 1);
 constexpr int kGjStepLds = kGJ * (kGJ + 1) + kGjStepScratch;
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void gj_step_kernel(
     double* __restrict__ G, int ld, int nb, int k, const double* __restrict__ Rp /* [64][ld] of step k-1 */, const double* __restrict__ Cp /* [ld][64] */,
     double* __restrict__ Rn, double* __restrict__ Cn, int* __restrict__ flag, int prio) {
     __shared__ double smem[kGjStepLds];
-    static_assert(kGjStepLds >= kGjUpdateLds && kGjStepScratch >= 4 * kGJ, "LDS carve");
+    static_assert(kGjStepLds >= kGjUpdateLds && kGjStepScratch >= 8 * kGJ, "LDS carve");
     if (prio) __builtin_amdgcn_s_setprio(3);   // (see gj_panels_kernel)
     const int nN = k < nb ? nb : 0;
     if ((int)blockIdx.x >= nN) {
@@ -1793,7 +1886,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         const int i = t / kGJ, j = t % kGJ;
         Cb[i * kGJ + j] = below ? x[i][j] : -x[j][i];
     }
-    gj_invert64_scalar<4>(r, scratch, flag);
+    gj_invert64_scalar<4, SHM_GJ_STEP_PAIRS != 0>(r, scratch, flag);
     if (b == k) {   // the pivot block's own R column carries P
 #pragma unroll
         for (int a = 0; a < 4; a++)

@@ -195,7 +195,7 @@ def test_kernel_register_schedules():
     # of the last product in scratch, each stored and reloaded ONCE per workgroup, outside every loop (checked in the ISA; a capped build with 74 registers
     # spilled inside the inversion loop measured 1.5x slower and is what this bound keeps out)
     step_spill = spilled.pop("shm::gj_step_kernel", 0)
-    assert step_spill <= 16, step_spill
+    assert step_spill <= 24, step_spill
     assert not spilled, spilled
     conv = by_name["void shm::conv_normalize_kernel<double, 4>"]
     assert conv["VGPRs"] >= 200 and conv["Occupancy"] == 2, conv

@@ -266,6 +266,30 @@ def test_projector(shm, case):
     assert np.abs(s.apply_projector(Atw)).max() < 1e-10 * np.abs(Atw).max()
 
 
+@pytest.mark.parametrize("case", ["bunny_small_n32", "bunny_small_n64"])
+def test_one_launch_gauss_jordan_gives_the_bits_of_the_three_launch_chain(shm, case, monkeypatch):
+    """gj_step_kernel (round 4: one launch per pivot block -- the previous block's update beside this block's pivot inversion and panels, the cross of tiles
+    updated on the fly, the pivot tile inverted redundantly by every panel workgroup) claims the arithmetic, operand order and results of the three-launch chain
+    it replaces (gj_pivot / gj_panels / gj_update kernels, SHM_GJ_CLASSIC=1; its pivot kernel also takes one elimination step per barrier where gj_step_kernel takes two): the projector P = I - A^T (A A^T)^-1 A must come out BIT-identical either way
+    (m = 497 / 1129: 8 / 18 pivot blocks)."""
+    d = load_golden(case)
+    n = int(d["n"])
+    v = np.random.default_rng(5).standard_normal(n ** 3)
+    out = []
+    for classic in (False, True):
+        if classic:
+            monkeypatch.setenv("SHM_GJ_CLASSIC", "1")
+        else:
+            monkeypatch.delenv("SHM_GJ_CLASSIC", raising=False)
+        s = make_solver(shm, d)
+        out.append(s.apply_projector(v))
+        s.close()
+    assert np.array_equal(out[0], out[1])
+    if "c_nodes" in d.files:
+        nodes, coeffs = d["c_nodes"], d["c_coeffs"]
+        assert np.abs((coeffs * out[0][nodes]).sum(axis=1)).max() < 1e-11
+
+
 @pytest.mark.parametrize("n", [16, 32, 64, 128, 256, 512, 22, 45, 90, 181, 362])
 def test_preconditioner_is_the_dct_pseudo_inverse(shm, n):
     """M^-1 = C^T D C must equal the pseudo-inverse of K = -L (the 3-D DCT-II diagonalises the Neumann Laplacian):
