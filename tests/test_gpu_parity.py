@@ -1327,6 +1327,16 @@ def test_bench_py_multi_rank_flow_on_one_gpu(tmp_path):
     m = d["also_multi"]
     assert m["primal_pcg"]["value"] > 0 and m["primal_pcg"]["rel_residual"] < 1e-7 and m["primal_pcg"]["preconditioner"].startswith("dct")
     assert m["primal_plain_cg_200"]["cg_iters"] == 200 and "cg_fused_kernel<DIR>" in m["primal_plain_cg_200"]["kernels"]
+    # the legs run after the headline record is complete and under a watchdog: if they do not finish in time (here: at once) the line is printed without them
+    # and every rank exits cleanly -- an extra can never cost the timed result
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29900 + os.getpid() % 90), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--workload", "bunny_small_64_f64", "--dist-backend", "gloo"], env=dict(env, SHM_BENCH_LEGS_TIMEOUT="0.001"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["value"] > 0 and "roofline" in d2 and "failed" in d2["also_multi"]
 
 
 @pytest.mark.gpu
