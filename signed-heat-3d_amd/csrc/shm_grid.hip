@@ -1811,7 +1811,8 @@ struct Solver final : SolverBase {
         // is worth its assembly up to the sizes its memory allows, whatever Step 1 hides
         if (gemm_dct()) return !off && m > 0 && m <= std::max(max_m, 16384);
         if (off || total_slabs != 1 || !precond_available() || m <= 0 || m > max_m || n > 512) return false;
-        // the assembly (216 table reads per entry: ~2.2e-7 ms per m^2 on an idle device, measured 1.8 ms at m = 2842, 29 ms at m = 12 612) has to hide behind
+        // the assembly (216 table entries per matrix entry: ~2.2e-7 ms per m^2 on an idle device until round 4 -- 1.8 ms at m = 2842, 29 ms at m = 12 612; 1.1 ms at m = 2842 since the
+        // windows along the last axis are fetched by two loads instead of three; the estimate below keeps the conservative constant) has to hide behind
         // this rank's Step 1 like the rest of the set-up; where Step 1 is short (<= 128^3, or a thin slab of a multi-GPU run) the sweeps through the grid are
         // cheap anyway (0.11 ms per iteration at 128^3) and the set-up is the critical path already
         // (the direct dual solve replaces the inversion of G, the host's B rows and the whole iteration by the assembly and the inversion of S: a gain at

@@ -133,6 +133,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WN == 4 
 // table entries, served by L1 / L2 -- staging a tile's index windows in LDS first was measured and is no faster: 1.79 against 1.76 ms at m = 2842);
 // tiles below the diagonal are left to their mirror images.
 __device__ __forceinline__ int schur_fold(int e, int n) { return e <= n ? e : 2 * n - e; }
+typedef double schur_f64x2 __attribute__((ext_vector_type(2), aligned(8)));
 __global__ __launch_bounds__(kBlock) void schur_assemble_kernel(int m, int ld, int n, int P, const int* __restrict__ rowX /* [m][4]: cell i, j, k and the row index, in Morton order of the cells */,
                                                                 const double* __restrict__ rowT /* [m][3] */, const double* __restrict__ T, double* __restrict__ S, int prio) {
     if (blockIdx.x < blockIdx.y) return;
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(kBlock) void schur_assemble_kernel(int m, int ld, i
         for (int a = 0; a < 3; a++)
 #pragma unroll
             for (int e = 0; e < 3; e++) pos[a][e] = sg[a] ? schur_fold(E[a] + e, n) : abs(D[a] - 1 + e);
+        const int zb = min(pos[2][0], min(pos[2][1], pos[2][2]));
         double sc = 0.;
 #pragma unroll
         for (int p = 0; p < 3; p++) {
@@ -171,9 +173,17 @@ __global__ __launch_bounds__(kBlock) void schur_assemble_kernel(int m, int ld, i
 #pragma unroll
             for (int q = 0; q < 3; q++) {
                 const double* row = T + ((size_t)pos[0][p] * (n + 1) + pos[1][q]) * P;
+                // the three entries along the last axis lie in [zb, zb + 2] (a window |D - 1|, |D|, |D + 1| or its folded counterpart): two loads (16 + 8
+                // bytes, 8-byte aligned) instead of three -- the kernel is bound by the cache lines its loads touch per instruction (round 4: 1.8 -> 1.1 ms
+                // at m = 2842, profiles/r04_schur_assemble.txt); rows are P = n + 8 long, so zb + 2 stays inside the row
+                const schur_f64x2 lo = *reinterpret_cast<const schur_f64x2*>(row + zb);
+                const double hi = row[zb + 2];
                 double sq = 0.;
 #pragma unroll
-                for (int r = 0; r < 3; r++) sq += wt[2][3 * sg[2] + r] * row[pos[2][r]];
+                for (int r = 0; r < 3; r++) {
+                    const int o = pos[2][r] - zb;
+                    sq += wt[2][3 * sg[2] + r] * (o == 0 ? lo.x : (o == 1 ? lo.y : hi));
+                }
                 sp += wt[1][3 * sg[1] + q] * sq;
             }
             sc += wt[0][3 * sg[0] + p] * sp;
