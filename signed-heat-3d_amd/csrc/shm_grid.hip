@@ -1806,7 +1806,10 @@ struct Solver final : SolverBase {
         static const bool off = getenv("SHM_DUAL_NO_DENSE_S") != nullptr;   // A/B knob: apply S through the grid (five sparse sweeps) as before
         // (beyond ~8000 rows the assembly costs Step 1 more time than the dense mat-vec saves the CG: rocker 512^3 fp32, m = 12 612: 29 ms of assembly for
         // 36 x 0.37 ms -- 493-508 against 491-501 ms per solve with S applied through the grid)
-        static const int max_m = getenv("SHM_DENSE_S_MAX_M") ? atoi(getenv("SHM_DENSE_S_MAX_M")) : 8192;
+        // (beside the tiered fp64 Step 1 -- where the assembly is co-resident and hidden -- up to 16384 rows since round 4: rocker 512^3 fp64, m = 12 612: solve phase
+        // 71.5 -> 35.9 ms, 631 -> 609 ms per solve; after the fp32 Step 1, which leaves the set-up's kernels no room, the same choice costs 401 -> 423 ms)
+        static const int max_m_env = getenv("SHM_DENSE_S_MAX_M") ? atoi(getenv("SHM_DENSE_S_MAX_M")) : 0;
+        const int max_m = max_m_env > 0 ? max_m_env : (conv_tiered ? 16384 : 8192);
         // n not a power of two: applying S through the grid costs six dense products per CG iteration (shm_dct_gemm.hip.h: 5 ms at n = 362), so the explicit S
         // is worth its assembly up to the sizes its memory allows, whatever Step 1 hides
         if (gemm_dct()) return !off && m > 0 && m <= std::max(max_m, 16384);
@@ -2818,6 +2821,8 @@ struct Solver final : SolverBase {
         Event c_s2a, c_s2b, e_gather, f_start, f_setup;
         c_s2a.record(F.stream2);
         F.conv_est_total_ms = conv_est_total_ms;   // what the whole-grid solver's set-up can hide behind is this rank's share of Step 1
+        F.conv_tiered = conv_tiered;               // ... and beside WHICH Step-1 kernel it runs: the tiered one leaves room only for the narrow GEMM shape (round 4: the
+                                                   // whole-grid solver never learnt this and queued the 256-register shape, which waits for Step 1's persistent waves to end)
         F.dual_direct_requested = true;
         F.build_constraints();
         F.dual_direct_requested = false;  // on the whole-grid solver's set-up stream: overlaps this rank's Step-1 kernel
