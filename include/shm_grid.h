@@ -213,7 +213,7 @@ shm_status shm_grid_get_field_planes(shm_solver* s, shm_field f, int32_t k_begin
 shm_status shm_grid_apply_laplacian(shm_solver* s, const double* u, double* out);
 /* Constraint rows (signed_heat_grid_solver.cpp:80-98): nodes/coeffs hold 8*S entries; *m rows written. */
 shm_status shm_grid_get_constraints(shm_solver* s, int64_t* nodes, double* coeffs, int32_t* m);
-/* The explicit Schur complement S = A K^+ A^T the dual solver iterates on when the problem qualifies (one slab; n = 2^k <= 512 and m <= 8192 -- m <= 16384 in the fp64 solve with shm_opts.step1_arith = SHM_STEP1_AUTO, whose Step 1 hides the assembly --, or any other n and m <= 16384): m x m
+/* The explicit Schur complement S = A K^+ A^T the dual solver iterates on when the problem qualifies (one slab; n = 2^k <= 512 and m <= 4096 (direct solve), or m <= 16384 in the fp64 solve with shm_opts.step1_arith = SHM_STEP1_AUTO where the library estimates the dense mat-vec cheaper than its sparse sweeps through the grid; any other n: m <= 16384): m x m
  * doubles, row-major; *m rows.  SHM_ERR_STATE when the solver applies S through the grid instead.  Test entry point (world==1). */
 shm_status shm_grid_get_schur(shm_solver* s, double* out, int32_t* m);
 /* v <- v - A^T (A A^T)^-1 A v on the device (the projector inside the CG); v: n^3 doubles, world==1. */

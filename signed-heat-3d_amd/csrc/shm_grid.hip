@@ -1822,7 +1822,17 @@ struct Solver final : SolverBase {
         // every size it applies to -- 128^3: 12.1 -> 9.6 ms, 64^3: 4.5 -> 2.7 ms per solve -- so it is not subject to this test)
         static const bool force = getenv("SHM_DUAL_DENSE_S_ALWAYS") != nullptr;
         const double schur_est_ms = 2.2e-7 * (double)m * (double)m;
-        return force || dual_direct || conv_est_total_ms >= 3.0 * schur_est_ms;
+        if (force || dual_direct) return true;
+        // CG on the explicit S (no inversion): worth it only where an iteration through the grid costs clearly more than the dense mat-vecs -- which grows with
+        // m^2 while the sparse sweeps grow with the grid.  Measured, fp64 (round 4, tools/r04_dense_s_256.py; ms per iteration through the grid / on the explicit
+        // S): 512^3 rocker (m = 12 612) 1.37 / 0.69 -> 631 / 610 ms per solve; 256^3 rocker (9 110) 0.31 / 0.38, SprayBottle (12 620) 0.27 / 0.65, chair (6 340)
+        // 0.23 / 0.245 -> 97 / 104, 174 / 195, 58.3 / 62.5 ms per solve (the assembly also costs Step 1 4-14 ms of shared SIMD time); 128^3: a tie.  Rounds 2-3
+        // chose the explicit S for every m <= 8192 that Step 1 could hide.
+        const double dense_iter_ms = 3.6e-9 * (double)m * (double)m * (sizeof(T) / 8.0) + 0.08;
+        const double grid_iter_ms = std::max(0.15, 1.4 * std::pow((double)n / 512.0, 3.0) * (sizeof(T) / 8.0));
+        // ... and only beside the tiered fp64 Step 1: after the fp32 (or all-fp64) kernel, which leaves the set-up's kernels no room, the assembly is exposed
+        // (chair 512^3 fp32, m = 7 748: 243 ms through the grid, 253 with the explicit S and 17 ms of wait; 256^3 fp32: 38.1 / 43.5)
+        return conv_tiered && conv_est_total_ms >= 3.0 * schur_est_ms && grid_iter_ms > 1.3 * dense_iter_ms;
     }
     // The Green's table of the grid (depends on n and h alone) on `st`.  Round 4: when the number of sources already guarantees the direct dual solve (m <= S <=
     // its limit), build_constraints() queues this BEFORE the host builds the constraint rows, so the table's kernels (0.9 ms at 256^3, 10 ms at 512^3) run while
