@@ -1223,6 +1223,12 @@ struct Solver final : SolverBase {
         const bool no_direct = getenv("SHM_DUAL_NO_DIRECT") != nullptr;   // A/B knob, read per solve (tests of the iterative path flip it inside one process)
         static const int direct_max_m = getenv("SHM_DUAL_DIRECT_MAX_M") ? atoi(getenv("SHM_DUAL_DIRECT_MAX_M")) : 4096;   // single-level Gauss-Jordan range
         dual_direct = dual_direct_requested && !no_direct && m <= direct_max_m;
+        // After the fp32 Step 1 -- which leaves the set-up's kernels no room: they run in its gaps and after it -- the direct solve's extra set-up (the
+        // Green's table: three n^4 products, 10 ms at 512^3; the assembly of S) is paid in full, and at 512^3 it costs more than the iterations it replaces
+        // (round 4, tools/r04_ab.py: bunny_small 512^3 fp32 112.8 ms direct / 107.6 iterative, bunny.pc 62.7 / 59.4; at 256^3: 15.8 / 18.5, 128^3: 4.7 / 7.3)
+        static const bool direct_always = getenv("SHM_DUAL_DIRECT_ALWAYS") != nullptr;   // A/B knob
+        // (the all-fp64 kernel at 512^3: 321 direct / 329 iterative -- fp64 iterations cost twice as much, so only the fp32 solve changes)
+        if (sizeof(T) == 4 && n >= 512 && !gemm_dct() && !direct_always) dual_direct = false;
         dual_direct = dual_direct && schur_wanted();   // (schur_wanted() reads dual_direct: with it set only the structural conditions remain)
         const bool need_node_tables = !dual_direct;
         // ---- G = A A^T and B = A K A^T from the (node, row, coef) entries sorted by node: rows meet exactly at shared nodes.
@@ -1841,7 +1847,7 @@ struct Solver final : SolverBase {
         static const bool off = getenv("SHM_GREEN_LATE") != nullptr;   // A/B knob
         static const int direct_max_m = getenv("SHM_DUAL_DIRECT_MAX_M") ? atoi(getenv("SHM_DUAL_DIRECT_MAX_M")) : 4096;
         return !off && dual_direct_requested && getenv("SHM_DUAL_NO_DIRECT") == nullptr && getenv("SHM_DUAL_NO_DENSE_S") == nullptr && total_slabs == 1 && precond_available() &&
-               !gemm_dct() && n <= 512 && S > 0 && S <= direct_max_m;
+               !gemm_dct() && n <= 512 && S > 0 && S <= direct_max_m && (sizeof(T) == 8 || n < 512 || getenv("SHM_DUAL_DIRECT_ALWAYS") != nullptr);
     }
     void enqueue_green_table(hipStream_t st) {
         const int P = n + 8;   // leading dimension of the last table index (rows stay 64-byte aligned)
