@@ -1199,6 +1199,45 @@ struct Solver final : SolverBase {
         upload_red_tables(stream);
     }
 
+    // Duration of the tiered fp64 Step 1 on this rank's nodes, from the sources alone (host, ~1 ns per (node sample, source): 2-7 ms): 128 pseudo-random nodes
+    // (fixed sequence) against all S sources, each pair classified as the kernel classifies a node BLOCK against a source (distance beyond the node's nearest
+    // source, less the block's diameter, against the far threshold G and the drop threshold), and the three shares priced with constants fitted to the 28
+    // measured (data file, grid size) pairs of round 4 (tools/r04_ab.py, profiles/r04_all_files.txt): predicted / measured 0.68 ... 1.23, where nominal pairs at
+    // a fixed rate -- conv_est_total_ms -- are off by up to 9x on the culled inputs.
+    double estimate_step1_ms_tiered() const {
+        if (S <= 0) return 0.;
+        const int K = 128;
+        uint64_t st = 0x9E3779B97F4A7C15ULL;
+        auto rnd = [&]() {
+            st = st * 6364136223846793005ULL + 1442695040888963407ULL;
+            return (double)(st >> 11) * (1.0 / 9007199254740992.0);
+        };
+        const double ext = (double)(n - 1) * cell, rt2 = 2.0 * 5.17 * cell;
+        const double r_near_gap = rt2 + conv_tier_log / lambda, r_keep_gap = rt2 + std::log((double)S / 2e-9) / lambda;
+        std::vector<float> d2((size_t)S);
+        size_t c_near = 0, c_keep = 0;
+        for (int k = 0; k < K; k++) {
+            const float x = (float)(bbox_min[0] + rnd() * ext), y = (float)(bbox_min[1] + rnd() * ext), z = (float)(bbox_min[2] + rnd() * ext);
+            float dmin = 3.0e38f;
+            for (int64_t s = 0; s < S; s++) {
+                const float dx = x - (float)h_pos[3 * s], dy = y - (float)h_pos[3 * s + 1], dz = z - (float)h_pos[3 * s + 2];
+                const float v = dx * dx + dy * dy + dz * dz;
+                d2[(size_t)s] = v;
+                dmin = std::min(dmin, v);
+            }
+            const double rn = std::sqrt((double)dmin);
+            const float tn = (float)((rn + r_near_gap) * (rn + r_near_gap)), tk = (float)((rn + r_keep_gap) * (rn + r_keep_gap));
+            for (int64_t s = 0; s < S; s++) {
+                c_near += d2[(size_t)s] < tn;
+                c_keep += d2[(size_t)s] < tk;
+            }
+        }
+        const double f_near = (double)c_near / ((double)K * (double)S), f_keep = (double)c_keep / ((double)K * (double)S);
+        double nodes = 0.;
+        for (const Slab<T>& sl : slabs) nodes += (double)sl.nown;
+        return nodes * (double)S * (1.229e-9 * f_near + 1.84e-10 * (f_keep - f_near) + 3.3e-12);
+    }
+
     // Per-slab CSR pieces, shift items, G = A A^T (sparse triplets -> dense on device -> inverted) and B = A K A^T.
     // Order: everything the inversion needs first (rows, G), then the Gauss-Jordan kernels are enqueued, and the rest of the host
     // work (per-slab lists, B, active-tile lists) runs while the GPU inverts; uploads come last (a pageable copy waits for the stream).
@@ -1223,6 +1262,25 @@ struct Solver final : SolverBase {
         const bool no_direct = getenv("SHM_DUAL_NO_DIRECT") != nullptr;   // A/B knob, read per solve (tests of the iterative path flip it inside one process)
         static const int direct_max_m = getenv("SHM_DUAL_DIRECT_MAX_M") ? atoi(getenv("SHM_DUAL_DIRECT_MAX_M")) : 4096;   // single-level Gauss-Jordan range
         dual_direct = dual_direct_requested && !no_direct && m <= direct_max_m;
+        // Round 4: between 4096 and 16384 rows the direct solve pays exactly where this rank's Step 1 outlasts the inversion of S that runs beside it (measured,
+        // tools/r04_ab.py, ms per solve iterative / direct: rocker 128^3 (m = 4 169) 23.9 / 19.8, SprayBottle 128^3 (4 141) 70.2 / 65.3, chair 256^3 (6 340) 58.7 / 57.8,
+        // chair 512^3 (7 748) 373.6 / 367.5 -- and rocker 256^3 (9 110) 97.4 / 106.9, SprayBottle 256^3 (12 620) 174 / 221, knot 128^3 (12 155) 55.6 / 96.5).  The
+        // line is drawn per problem from an estimate of Step 1 that knows what the tiers drop (estimate_step1_ms_tiered: +-25 % over the data files) and of the
+        // set-up on an idle device (assembly 1.4e-7 m^2, inversion 5.5e-11 m^3, the Green's table); beside Step 1 the set-up runs at ~0.4 of that speed.
+        static const bool direct_est_off = getenv("SHM_DUAL_DIRECT_EST_OFF") != nullptr;   // A/B knob: the fixed limit alone
+        if (!dual_direct && dual_direct_requested && !no_direct && !direct_est_off && conv_tiered && total_slabs == 1 && precond_available() && !gemm_dct() && n <= 512 &&
+            m > direct_max_m && m <= 16384 && conv_est_total_ms < 1e29) {
+            const double md = (double)m;
+            const double table_ms = 10.0 * std::pow((double)n / 512.0, 4.0);
+            const double setup_alone_ms = 5.5e-11 * md * md * md + 1.4e-7 * md * md + table_ms;
+            // (the whole-grid solver of a multi-rank run hides its set-up behind the RANK's share of Step 1: conv_est_total_ms carries that share in nominal pairs)
+            double nodes_here = 0.;
+            for (const Slab<T>& sl : slabs) nodes_here += (double)sl.nown;
+            const double share = std::min(1.0, conv_est_total_ms / std::max(1e-30, nodes_here * (double)S / 1.2e9));
+            const double step1_ms = estimate_step1_ms_tiered() * share;
+            dual_direct = setup_alone_ms <= 0.38 * step1_ms;
+            log("[shm]   direct solve for m = %d: set-up alone ~%.1f ms, Step 1 ~%.1f ms -> %s", m, setup_alone_ms, step1_ms, dual_direct ? "direct" : "iterative");
+        }
         // After the fp32 Step 1 -- which leaves the set-up's kernels no room: they run in its gaps and after it -- the direct solve's extra set-up (the
         // Green's table: three n^4 products, 10 ms at 512^3; the assembly of S) is paid in full, and at 512^3 it costs more than the iterations it replaces
         // (round 4, tools/r04_ab.py: bunny_small 512^3 fp32 112.8 ms direct / 107.6 iterative, bunny.pc 62.7 / 59.4; at 256^3: 15.8 / 18.5, 128^3: 4.7 / 7.3)
