@@ -1199,14 +1199,14 @@ struct Solver final : SolverBase {
         upload_red_tables(stream);
     }
 
-    // Duration of the tiered fp64 Step 1 on this rank's nodes, from the sources alone (host, ~1 ns per (node sample, source): 2-7 ms): 128 pseudo-random nodes
+    // Duration of the tiered fp64 Step 1 on this rank's nodes, from the sources alone (host, ~1 ns per (node sample, source), at most 2e6 of them): 32-128 pseudo-random nodes
     // (fixed sequence) against all S sources, each pair classified as the kernel classifies a node BLOCK against a source (distance beyond the node's nearest
     // source, less the block's diameter, against the far threshold G and the drop threshold), and the three shares priced with constants fitted to the 28
     // measured (data file, grid size) pairs of round 4 (tools/r04_ab.py, profiles/r04_all_files.txt): predicted / measured 0.68 ... 1.23, where nominal pairs at
     // a fixed rate -- conv_est_total_ms -- are off by up to 9x on the culled inputs.
     double estimate_step1_ms_tiered() const {
         if (S <= 0) return 0.;
-        const int K = 128;
+        const int K = (int)std::max<int64_t>(32, std::min<int64_t>(128, 2000000 / S));   // <= 2e6 (sample, source) pairs: ~2 ms of host time, paid before the set-up is queued
         uint64_t st = 0x9E3779B97F4A7C15ULL;
         auto rnd = [&]() {
             st = st * 6364136223846793005ULL + 1442695040888963407ULL;
