@@ -983,6 +983,26 @@ def test_direct_dual_solve_accepts_the_rounding_floor(shm, case):
     assert np.abs(phi - d["phi"]).max() < 1e-7
 
 
+@pytest.mark.parametrize("fname,hc,precision,form", [("rocker.obj", 3.0, 64, 2), ("chair.pc", 4.0, 64, 2), ("rocker.obj", 4.0, 64, 0), ("chair.obj", 4.0, 32, 0)])
+def test_dual_form_choice_and_agreement_of_the_forms(shm, fname, hc, precision, form, monkeypatch):
+    """The dual solver picks its form per problem (round 4 re-measured the choices): the direct solve (explicit S^-1) for mid-size
+    constraint sets where a sampled estimate of Step 1 says the inversion hides behind it (rocker 128^3: m = 4 169, chair.pc 256^3: 4 535), the CG with S applied
+    through the grid where it does not (rocker 256^3: 9 110) and in the fp32 solve (chair 256^3).  Whatever is picked, forcing the iterative form on the same
+    solver (SHM_DUAL_NO_DIRECT, read per solve) must give the same field to the solvers' tolerance: they solve the same KKT system."""
+    pre = _preprocess(fname, hc)
+    scrub = not fname.endswith(".pc")
+    s, st, phi = _gpu_phi(shm, pre, precision, scrub)
+    assert st.cg_form == form, (st.m, st.cg_form)
+    assert np.isfinite(phi).all()
+    monkeypatch.setenv("SHM_DUAL_NO_DIRECT", "1")
+    st2 = s.solve(scrub=scrub, allow_noconv=True)
+    phi2, _ = s.get_phi()
+    assert st2.cg_form in (0, 3) and st2.iters > 4
+    tol = (2e-7 if precision == 64 else 2e-4) * max(1.0, float(np.abs(phi).max()))
+    assert np.abs(phi2 - phi).max() < tol, (np.abs(phi2 - phi).max(), st.iters, st2.iters)
+    s.close()
+
+
 def test_config3_bunny_pc_512_fp64_full_size(shm):
     """BASELINE.json configs[3] on one GPU at its full size: data/bunny.pc (point overload: no divYt scrub, signed_heat_grid_solver.cpp:116-222, :179-180),
     hCoef 5 = 512^3, fp64; areas / h from the build's estimator (inputs of the ABI).  Size-independent properties: KKT stationarity off the
