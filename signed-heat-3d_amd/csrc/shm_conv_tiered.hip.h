@@ -36,29 +36,40 @@ namespace shm {
 
 // e^{-lambda r}/r from x = r^2 for the near tier: hardware v_rsq_f64 seed (2^-24) + one second-order step (relative error 3/8 e^2 ~ 1e-15 in r
 // and 1/r), exponent remainder with a single rounding against the 2048-entry table of 2^(j/2048), degree-2 polynomial of 2^(f/2048)
-// (truncation (ln2/4096)^3/6 = 8e-13).  13 fp64 VALU + v_rsq_f64 + v_ldexp_f64 + 3 integer instructions.
-__device__ __forceinline__ double yukawa_near(double x, double c, const double* __restrict__ tab) {
+// (truncation (ln2/4096)^3/6 = 8e-13).
+// Round 5: the power of two is no longer applied by v_ashrrev + v_ldexp_f64 but ADDED INTO THE EXPONENT FIELD of the table entry by one v_lshl_add_u32:
+// with ki = 2048 k + j the low word of the rounding trick holds ki, and (ki << 9) = (k << 20) + (j << 9) -- the table is stored with (j << 9) subtracted
+// from the high word of entry j, so hi(entry) + (ki << 9) is the high word of 2^(j/2048) 2^k.  That is only valid while 2^k stays a normal number, so the
+// block works relative to ITS OWN exponent: m1 = 1.5 2^52 - 2048 k0 with 2^k0 ~ e^{-lambda d0} (d0: no source is closer to any node of the block), which
+// makes the low word ki - 2048 k0 -- every near term of the block comes out scaled by 2^-k0 exactly, the scale is put back once per node at the end of
+// the block (where the reference's underflow to 0 -> NaN far from the sources is reproduced by that one v_ldexp_f64).  The host keeps blocks whose near
+// terms could span more than 2^-990 off this kernel (Solver::tier_exponent_span_ok).
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double yukawa_near(double x, double c, double m1, const uint2v* __restrict__ tab) {
     const double y0 = __builtin_amdgcn_rsq(x);
     const double t = x * y0;
     const double h = 0.5 * y0;
     const double e = fma(-t, h, 0.5);            // (1 - x y0^2) / 2
     const double r = fma(t, e, t);
     const double rinv = fma(y0, e, y0);
-    const double tm = fma(r, c, 6755399441055744.0);   // 1.5 * 2^52: round(r c) lands in the low mantissa bits
-    const double kf = tm - 6755399441055744.0;
-    const int ki = (int)(unsigned)__double_as_longlong(tm);
+    const double tm = fma(r, c, m1);             // round(r c) - 2048 k0 lands in the low mantissa bits
+    const double kf = tm - m1;
+    const unsigned ki = (unsigned)__double_as_longlong(tm);
     const double f = fma(r, c, -kf);
     double p = 5.727446245172041e-08;                   // (ln2/2048)^2 / 2
     p = fma(p, f, 3.384507717577858e-04);               // ln2/2048
     p = fma(p, f, 1.0);
-    return __builtin_amdgcn_ldexp(tab[ki & 2047] * p * rinv, ki >> 11);   // r = 0 -> NaN (0 * inf), like exp(0)/0 -> inf -> NaN after normalise
+    uint2v tv = tab[ki & 2047u];
+    tv.y += ki << 9;
+    return __builtin_bit_cast(double, tv) * (p * rinv);   // r = 0 -> NaN (0 * inf), like exp(0)/0 -> inf -> NaN after normalise
 }
 
 // the same for B values at once, stage by stage (breadth-first): the source order the scheduler starts from interleaves the B dependent chains
 template <int B>
-__device__ __forceinline__ void yukawa_near_batch(const double* __restrict__ x, double c, const double* __restrict__ tab, double* __restrict__ g) {
-    double y0[B], t[B], e[B], r[B], rinv[B], tm[B], f[B], p[B], tv[B];
-    int ki[B];
+__device__ __forceinline__ void yukawa_near_batch(const double* __restrict__ x, double c, double m1, const uint2v* __restrict__ tab, double* __restrict__ g) {
+    double y0[B], t[B], e[B], r[B], rinv[B], tm[B], f[B], p[B];
+    unsigned ki[B];
+    uint2v tv[B];
 #pragma unroll
     for (int b = 0; b < B; b++) y0[b] = __builtin_amdgcn_rsq(x[b]);
 #pragma unroll
@@ -68,20 +79,58 @@ __device__ __forceinline__ void yukawa_near_batch(const double* __restrict__ x, 
 #pragma unroll
     for (int b = 0; b < B; b++) r[b] = fma(t[b], e[b], t[b]);
 #pragma unroll
-    for (int b = 0; b < B; b++) tm[b] = fma(r[b], c, 6755399441055744.0);
+    for (int b = 0; b < B; b++) tm[b] = fma(r[b], c, m1);
 #pragma unroll
     for (int b = 0; b < B; b++) {
-        ki[b] = (int)(unsigned)__double_as_longlong(tm[b]);
-        tv[b] = tab[ki[b] & 2047];
+        ki[b] = (unsigned)__double_as_longlong(tm[b]);
+        tv[b] = tab[ki[b] & 2047u];
+        tv[b].y += ki[b] << 9;
     }
 #pragma unroll
-    for (int b = 0; b < B; b++) f[b] = fma(r[b], c, -(tm[b] - 6755399441055744.0));
+    for (int b = 0; b < B; b++) f[b] = fma(r[b], c, -(tm[b] - m1));
 #pragma unroll
     for (int b = 0; b < B; b++) rinv[b] = fma(y0[b], e[b], y0[b]);
 #pragma unroll
     for (int b = 0; b < B; b++) p[b] = fma(fma(5.727446245172041e-08, f[b], 3.384507717577858e-04), f[b], 1.0);
 #pragma unroll
-    for (int b = 0; b < B; b++) g[b] = __builtin_amdgcn_ldexp(tv[b] * p[b] * rinv[b], ki[b] >> 11);
+    for (int b = 0; b < B; b++) {
+        g[b] = __builtin_bit_cast(double, tv[b]) * (p[b] * rinv[b]);
+    }
+}
+
+// acc += w.lo * g  /  acc += w.hi * g  on two nodes at once: the weight is one half of a register pair, broadcast to both halves of the instruction by op_sel.  The
+// compiler finds the low-half form by itself but copies a high half into a fresh pair first (v_mov_b32: 8 of the far loop's 112 vector instructions); spelled out here.
+#ifndef SHM_TIER_ASM_BCAST
+#define SHM_TIER_ASM_BCAST 1
+#endif
+__device__ __forceinline__ void pk_fma_lo(float2v& acc, float2v w, float2v g) {
+#if SHM_TIER_ASM_BCAST
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(w), "v"(g));
+#else
+    acc = __builtin_elementwise_fma(float2v{w.x, w.x}, g, acc);
+#endif
+}
+__device__ __forceinline__ void pk_fma_hi(float2v& acc, float2v w, float2v g) {
+#if SHM_TIER_ASM_BCAST
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "v"(g));
+#else
+    acc = __builtin_elementwise_fma(float2v{w.y, w.y}, g, acc);
+#endif
+}
+
+// set bits of a wave mask below this lane (v_mbcnt_lo / _hi: no (1 << lane) - 1 held in a register pair)
+__device__ __forceinline__ int mask_rank(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+// 2^(u / 2048) for 0 <= u < 4096 from the near tier's table (same remainder polynomial): the block's far-tier scale, once per block
+__device__ __forceinline__ double exp2_tab(double u, const uint2v* __restrict__ tab) {
+    const double tm = u + 6755399441055744.0;
+    const unsigned ki = (unsigned)__double_as_longlong(tm);
+    const double f = u - (tm - 6755399441055744.0);
+    uint2v tv = tab[ki & 2047u];
+    tv.y += ki << 9;
+    return __builtin_bit_cast(double, tv) * fma(fma(5.727446245172041e-08, f, 3.384507717577858e-04), f, 1.0);
 }
 
 // a wave-uniform float as a scalar register (the builtin is integer-typed: pass the bits, not the value)
@@ -114,9 +163,6 @@ constexpr int kTierFill = kTierCluster * kTierChunk;
 // source l: the staging needs no workgroup barrier, a wave's LDS accesses execute in order) and walks its own masks.  The workgroup shares only the
 // read-only exponential table.  Units cost between ~0.3 and 1 of the all-fp64 cost depending on how much of the object is near, so static
 // assignment (and a barrier per LDS fill across four differently loaded waves) would leave the SIMDs idle for a fifth of the kernel.
-#ifndef SHM_TIER_NEAR_UNROLL
-#define SHM_TIER_NEAR_UNROLL 1
-#endif
 #ifndef SHM_TIER_FAR_UNROLL
 #define SHM_TIER_FAR_UNROLL 4
 #endif
@@ -129,41 +175,54 @@ constexpr int kTierFill = kTierCluster * kTierChunk;
 #ifndef SHM_TIER_LDS_FETCH
 #define SHM_TIER_LDS_FETCH 1    // the next cluster's sources travel global -> LDS directly; 0: through 12 registers per lane (rounds 2-3)
 #endif
-#ifndef SHM_TIER_FAR_STRIDE
-#define SHM_TIER_FAR_STRIDE 8   // floats per staged far source: 8 = x', y', z', |w|_1 | wx, wy, wz, pad (two 16-byte reads); 6 = x', y', z', wx, wy, wz (|w|_1 per lane)
-#endif
-#ifndef SHM_TIER_NEAR_BFS
-#define SHM_TIER_NEAR_BFS 1
+#ifndef SHM_TIER_PRIO
+#define SHM_TIER_PRIO 0
 #endif
 #ifndef SHM_TIER_NEAR_BATCH
-#define SHM_TIER_NEAR_BATCH 2   // pairs whose e^{-lambda r}/r chains are interleaved stage by stage
+#define SHM_TIER_NEAR_BATCH 4   // pairs whose e^{-lambda r}/r chains are interleaved stage by stage (round 5: all four of a lane's z-column; 2: +2.5 % Step 1)
 #endif
 #ifndef SHM_TIER_WAVES_PER_EU
 #define SHM_TIER_WAVES_PER_EU 2
 #endif
 template <int NPT>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER_WAVES_PER_EU, SHM_TIER_WAVES_PER_EU))) void conv_tiered_kernel(
+#ifndef SHM_TIER_VGPR_CAP
+#define SHM_TIER_VGPR_CAP 184   // two of its waves + one of a set-up kernel per SIMD
+#endif
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER_WAVES_PER_EU, SHM_TIER_WAVES_PER_EU), amdgpu_num_vgpr(SHM_TIER_VGPR_CAP))) void conv_tiered_kernel(
     ConvParams P, const double* __restrict__ src /* [S][6]: pos xyz, wn xyz */, const float* __restrict__ clusters,
     const double* __restrict__ exp_tab_g /* [2048]: 2^(j/2048) */, double* __restrict__ Y0, double* __restrict__ Y1, double* __restrict__ Y2,
     unsigned long long* __restrict__ counters, unsigned* __restrict__ next_unit /* [8] queue heads, zeroed before the launch */) {
     static_assert(NPT % 2 == 0, "the far tier handles a lane's nodes in packed pairs");
     constexpr int kWaves = kBlock / kWave;
-    constexpr int kNearUnroll = SHM_TIER_NEAR_UNROLL, kFarUnroll = SHM_TIER_FAR_UNROLL;
-    constexpr int kPad = kNearUnroll > kFarUnroll ? kNearUnroll : kFarUnroll;   // staged entries behind the last real one: zero weight, far away -- they pad the
+    constexpr int kFarUnroll = SHM_TIER_FAR_UNROLL;
+    constexpr int kPad = kFarUnroll;   // staged entries behind the last real one: zero weight, far away -- they pad the
     __shared__ double stage64[kWaves][(kTierCluster + kPad) * 6];              // compacted lists to whole groups of sources in flight
-    constexpr int kFS = SHM_TIER_FAR_STRIDE;
-    __shared__ __attribute__((aligned(16))) float stage32[kWaves][(kTierCluster + kPad) * kFS];
+    // far list (round 5: three arrays instead of one 32-byte record): A = x', y', wx, wy | B = (z_e - z')^2 for the block's NPT planes -- the planes are the same for
+    // every lane, so the classifying lane squares them once per source and the far loop gets d^2 of two nodes by ONE packed add (it used to take a packed add and a
+    // packed fma per two nodes, and a subtraction per source) | C = wz, |w|_1.  Weights sit in aligned pairs: either half is broadcast by op_sel (pk_fma_lo / _hi)
+    __shared__ __attribute__((aligned(16))) float farA[kWaves][(kTierCluster + kPad) * 4];
+    __shared__ __attribute__((aligned(16))) float farB[kWaves][(kTierCluster + kPad) * NPT];
+    __shared__ __attribute__((aligned(16))) float farC[kWaves][(kTierCluster + kPad) * 2];
     // the next cluster's sources travel global -> LDS directly (global_load_lds_dwordx4: three 16-byte pieces of every lane's 48-byte record, each piece
     // landing at wave base + lane * 16), not through 12 registers per lane held across the two loops: those registers are what the per-node L1 sums of the
     // a-posteriori test now live in (the kernel must stay within 184 VGPRs for the set-up kernels to run beside it)
 #if SHM_TIER_LDS_FETCH
     __shared__ double2 raw[kWaves][3][kTierCluster];
 #endif
-    __shared__ double exp_tab[2048];
+    __shared__ uint2v exp_tab[2048];   // bits of 2^(j/2048) with (j << 9) taken off the high word (see yukawa_near)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
     double* const tile = stage64[wave];
-    float* const tile32 = stage32[wave];
-    for (int a = threadIdx.x; a < 2048; a += kBlock) exp_tab[a] = exp_tab_g[a];
+    float* const tA = farA[wave];
+    float* const tB = farB[wave];
+    float* const tC = farC[wave];
+#if SHM_TIER_PRIO
+    __builtin_amdgcn_s_setprio(SHM_TIER_PRIO);
+#endif
+    for (int a = threadIdx.x; a < 2048; a += kBlock) {
+        uint2v tv = __builtin_bit_cast(uint2v, exp_tab_g[a]);
+        tv.y -= (unsigned)a << 9;
+        exp_tab[a] = tv;
+    }
     __syncthreads();   // the only workgroup barrier: the table
     const int n = P.n;
     const size_t plane = (size_t)n * n;
@@ -204,7 +263,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
         const int i0 = tx * kTierTX, j0 = ty * kTierTY, kk0 = P.kk_begin + tz * NPT;
 
         double pz0 = 0., ax[NPT], ay[NPT], az[NPT];
-        float qz0 = 0.f, fx[NPT], fy[NPT], fz[NPT];
+        float qz0 = 0.f;
+        float2v fx[NPT / 2], fy[NPT / 2], fz[NPT / 2];   // far sums: nodes (2p, 2p + 1) of the lane's z-column in one register pair
         const int li = i0 + (lane % kTierTX), lj = j0 + (lane / kTierTX);
         const int ci = min(li, n - 1), cj = min(lj, n - 1);
         // indicesToNodePosition: (i,j,k)*cellSize + bboxMin, evaluated in double like the reference (:510-514)
@@ -213,7 +273,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
 #pragma unroll
         for (int e = 0; e < NPT; e++) {
             ax[e] = ay[e] = az[e] = 0.;
-            fx[e] = fy[e] = fz[e] = 0.f;
+            fx[e / 2] = fy[e / 2] = fz[e / 2] = float2v{0.f, 0.f};
         }
         // the wave's nodes form a compact kTierTX x kTierTY x NPT block: a lane keeps the z of its first node, the others follow by the cell size (planes past the
         // end of the launch are evaluated like the others and not stored)
@@ -221,8 +281,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
         qz0 = (float)(pz0 * (P.lambda * 1.4426950408889634));
         const bool live_xy = li < n && lj < n;
         // nearest source of the block's centre (and its weight): one source per lane and step, butterfly minimum
-        const float cx = (float)((i0 + kHalfX) * P.cell + P.bbox_min[0]), cy = (float)((j0 + kHalfY) * P.cell + P.bbox_min[1]);
-        const float cz = (float)((P.k0 + kk0 - 1 + kHalfZ) * P.cell + P.bbox_min[2]);
+        // (wave-uniform values computed by vector instructions are moved to scalar registers by hand: the compiler would keep a copy per lane)
+        const float cx = uniform_f32((float)((i0 + kHalfX) * P.cell + P.bbox_min[0])), cy = uniform_f32((float)((j0 + kHalfY) * P.cell + P.bbox_min[1]));
+        const float cz = uniform_f32((float)((P.k0 + kk0 - 1 + kHalfZ) * P.cell + P.bbox_min[2]));
         float dmin = 3.0e38f, wnear = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;   // nearest source: squared distance, squared weight, offset from the centre
         for (int s = lane; s < P.S; s += kWave) {
             const double* q = src + (size_t)s * 6;
@@ -237,17 +298,28 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                 nz = dz;
             }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float od = __shfl_xor(dmin, off, kWave), ow = __shfl_xor(wnear, off, kWave);
-            const float ox = __shfl_xor(nx, off, kWave), oy = __shfl_xor(ny, off, kWave), oz = __shfl_xor(nz, off, kWave);
-            if (od < dmin || (od == dmin && ow > wnear)) {
-                dmin = od;
-                wnear = ow;
-                nx = ox;
-                ny = oy;
-                nz = oz;
-            }
+        {   // the lane that holds the nearest source (ties: the larger weight, then the lower lane), then its five values by v_readlane.  Minimum / maximum over the wave
+            // by ds_swizzle butterflies within the halves + two v_readlane: no per-step lane index held in a register (the __shfl_xor form kept six of them live
+            // through the whole kernel), a sixth of the instructions of a five-value butterfly
+            auto wave_min_u = [&](unsigned v) {
+                v = min(v, (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1f | (1 << 10)));    // bit-mask mode: lane ^ 1, 2, 4, 8, 16 within each half
+                v = min(v, (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1f | (2 << 10)));
+                v = min(v, (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1f | (4 << 10)));
+                v = min(v, (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1f | (8 << 10)));
+                v = min(v, (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1f | (16 << 10)));
+                return min((unsigned)__builtin_amdgcn_readlane((int)v, 0), (unsigned)__builtin_amdgcn_readlane((int)v, 32));
+            };
+            // (squared distances and squared weights are >= 0: their bit patterns order like the values)
+            const unsigned dbits = wave_min_u(__float_as_uint(dmin));
+            const unsigned wkey = __float_as_uint(dmin) == dbits ? ~__float_as_uint(wnear) : 0xffffffffu;
+            const unsigned wbits = wave_min_u(wkey);
+            const unsigned long long hit = __ballot(wkey == wbits);
+            const int win = (int)__builtin_ctzll(hit);
+            dmin = __uint_as_float(dbits);
+            wnear = __uint_as_float(~wbits);
+            nx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nx), win));
+            ny = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ny), win));
+            nz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nz), win));
         }
         dmin = sqrtf(dmin);
         // every node of the block has a source at most r_hi_w away: the block's farthest corner from the source nearest to its centre (the block is the box
@@ -256,12 +328,22 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
         const float r_hi_w = uniform_f32(sqrtf(fxn * fxn + fyn * fyn + fzn * fzn) * 1.000001f);
         const float lnear_w = uniform_f32(0.5f * __log2f(fmaxf(wnear, 1e-37f)) - 1e-5f);         // log2 of that source's weight, rounded down
         const float d0_w = uniform_f32(fmaxf(0.f, dmin * 0.999999f - rt_w));                      // no source is closer than this to any node of the block
-        const float coff = lam_l2 * d0_w;   // far tier: e^{-lambda (r - d0)} = 2^(coff - lambda log2 e r), folded back in by e^{-lambda d0} at the end
+        const float coff = uniform_f32(lam_l2 * d0_w);   // far tier: e^{-lambda (r - d0)} = 2^(coff - lambda log2 e r), folded back in by e^{-lambda d0} at the end
 
-        const double e0 = YukawaMath<double>::exp_neg(-P.lambda * (double)d0_w) * (P.lambda * 1.4426950408889634) / P.wscale;   // (the far sums hold w_scaled / (lambda log2 e r))
-        float fl[NPT];   // per node: sum over the far sources of |w|_1 e^{-lambda (r - d0)} / (lambda' r) -- the L1 norm of what the packed-fp32 tier contributed
+        // the block's own exponent (see yukawa_near): 2^k0 ~ e^{-lambda d0}; r >= d0 for every pair of the block, so the scaled near terms are at most 2^1
+        const int k0 = __builtin_amdgcn_readfirstlane((int)floor((double)d0_w * P.cexp * (1.0 / 2048.0)));
+        const double m1 = 6755399441055744.0 - 2048.0 * (double)k0;   // 1.5 * 2^52 - 2048 k0: exact
+        // the far sums hold w_scaled 2^{-lambda' (r - d0)} / (lambda' r): times e^{-lambda d0} lambda' / wscale they are terms of X; here in the block's scale 2^-k0
+        // e^{-lambda d0} / 2^k0 = 2^((d0 c - 2048 k0) / 2048), exponent in [0, 2048): from the near tier's table.  (Evaluated where it is used, after the loops -- the
+        // empty asm keeps the compiler from hoisting it above them, where it would hold two registers throughout.)
+        auto far_scale = [&]() {
+            float d = d0_w;
+            asm volatile("" : "+v"(d));
+            return exp2_tab(fma((double)d, P.cexp, -2048.0 * (double)k0), exp_tab) * (P.lambda * 1.4426950408889634) / P.wscale;
+        };
+        float2v fl[NPT / 2];   // per node: sum over the far sources of |w|_1 e^{-lambda (r - d0)} / (lambda' r) -- the L1 norm of what the packed-fp32 tier contributed
 #pragma unroll
-        for (int e = 0; e < NPT; e++) fl[e] = 0.f;
+        for (int e = 0; e < NPT / 2; e++) fl[e] = float2v{0.f, 0.f};
         // constant of the exponent-range test of a far source: lambda' (dist + 2 rt_w) - coff - log2(w_s / w_max) <= 113  (see the header)
         const float range_c = uniform_f32(2.f * rt_w * lam_l2 - 113.f - coff);
         // pass 0: near sources in fp64, far ones in packed fp32.  pass 1 (only when the a-posteriori test failed): the far sources again, in fp64.
@@ -271,10 +353,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
         // while that cluster's two loops run; a skipped cluster's fetch is simply overwritten by the next: loads return in order)
 #if SHM_TIER_LDS_FETCH
         auto fetch_cluster = [&](int c) {
-            const char* g = reinterpret_cast<const char*>(src + ((size_t)c * kTierCluster + lane) * 6);
-            __builtin_amdgcn_global_load_lds(g, &raw[wave][0][0], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(g + 16, &raw[wave][1][0], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(g + 32, &raw[wave][2][0], 16, 0, 0);
+            // (scalar base + one 32-bit lane offset: the three pieces share the lane's offset register instead of holding three 64-bit addresses)
+            const char* g = reinterpret_cast<const char*>(src) + (size_t)c * (kTierCluster * 48);
+            const unsigned lo = (unsigned)lane * 48u;
+            __builtin_amdgcn_global_load_lds(g + lo, &raw[wave][0][0], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(g + 16 + lo, &raw[wave][1][0], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(g + 32 + lo, &raw[wave][2][0], 16, 0, 0);
         };
 #else
         double nq[6];
@@ -328,122 +412,106 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                 const bool in_range = fmaf(dist, lam_l2, range_c) <= lw;                   // every term of the source stays a normal fp32 number over the block
                 const bool far = lhs > g_l2 + rel && in_range;
                 const bool drop = lhs > skip_l2 + rel;
-                const bool to64 = valid && (pass == 0 ? !far : (far && !drop));
+                const bool to64 = valid && !drop && (pass == 0 ? !far : far);   // (drop first: a source outside the fp32 exponent range is not "far", but it may well be dropped)
                 const bool to32 = valid && pass == 0 && far && !drop;
                 nearmask = __ballot(to64);
                 farmask = __ballot(to32);
                 // stage the cluster for the broadcast reads below (wave-private region: no barrier), COMPACTED: the near sources in fp64 and the far ones in fp32
                 // each as a dense list in mask order, so that the two loops below walk consecutive entries with a plain counter (a bit scan per source cost
                 // ~10 scalar instructions on the wave's in-order instruction stream)
-                const unsigned long long below = (1ull << lane) - 1ull;
                 if (to64) {
-                    const int rnk = __builtin_popcountll(nearmask & below);
+                    const int rnk = mask_rank(nearmask);
 #pragma unroll
                     for (int a = 0; a < 6; a++) tile[rnk * 6 + a] = q[a];
                 } else if (to32) {
-                    const int rnk = __builtin_popcountll(farmask & below);
+                    const int rnk = mask_rank(farmask);
                     // positions in units of 1 / (lambda log2 e): the far loop then gets lambda r log2 e = d2' rsq(d2') without a multiplication of its own
-#if SHM_TIER_FAR_STRIDE == 8
-                    *reinterpret_cast<float4*>(&tile32[rnk * 8]) = float4{q32[0] * lam_l2, q32[1] * lam_l2, q32[2] * lam_l2, fabsf(q32[3]) + fabsf(q32[4]) + fabsf(q32[5])};
-                    *reinterpret_cast<float4*>(&tile32[rnk * 8 + 4]) = float4{q32[3], q32[4], q32[5], 0.f};
-#else
+                    *reinterpret_cast<float4*>(&tA[rnk * 4]) = float4{q32[0] * lam_l2, q32[1] * lam_l2, q32[3], q32[4]};
+                    const float dz0 = qz0 - q32[2] * lam_l2;
+                    float dz2[NPT];
 #pragma unroll
-                    for (int a = 0; a < 6; a++) tile32[rnk * 6 + a] = a < 3 ? q32[a] * lam_l2 : q32[a];
-#endif
+                    for (int e = 0; e < NPT; e++) {
+                        const float dz = e * cellq + dz0;   // (consecutive planes: the block's first scaled z, the others by the scaled cell size)
+                        dz2[e] = dz * dz;
+                    }
+                    if constexpr (NPT == 4) *reinterpret_cast<float4*>(&tB[rnk * 4]) = float4{dz2[0], dz2[1], dz2[2], dz2[3]};
+                    else *reinterpret_cast<float2*>(&tB[rnk * 2]) = float2{dz2[0], dz2[1]};
+                    *reinterpret_cast<float2*>(&tC[rnk * 2]) = float2{q32[5], fabsf(q32[3]) + fabsf(q32[4]) + fabsf(q32[5])};
                 }
             }
             const int nnear = __builtin_popcountll(nearmask), nfar = __builtin_popcountll(farmask);
             if (lane < kPad) {
 #pragma unroll
-                for (int a = 0; a < 6; a++) {
-                    const double pv = a < 3 ? P.bbox_min[a] - (double)P.n * P.cell : 0.0;   // the padding entry: >= one grid side from every node, zero weight
-                    tile[(nnear + lane) * 6 + a] = pv;
-                    // (the far list holds SCALED positions; an unscaled padding point would land inside the grid, where coff - r' > 0 can overflow exp2f
-                    // and 0 * inf = NaN reaches the sums.  1e18 in every scaled coordinate: d2 = 3e36 is finite, r' = 1.7e18 > coff always, 2^(coff - r') = 0)
-                    tile32[(nfar + lane) * kFS + a] = a < 3 ? 1.0e18f : 0.f;
-                    if (kFS == 8 && a < 2) tile32[(nfar + lane) * kFS + 6 + a] = 0.f;
-                }
+                for (int a = 0; a < 6; a++) tile[(nnear + lane) * 6 + a] = a < 3 ? P.pad_pos[a] : 0.0;   // the padding entry: >= one grid side from every node, zero weight
+                // (the far list holds SCALED positions; an unscaled padding point would land inside the grid, where coff - r' > 0 can overflow exp2f
+                // and 0 * inf = NaN reaches the sums.  1e18 in the scaled x and y, 1e36 as the squared z offsets: d2 ~ 3e36 is finite, r' = 1.7e18 > coff always, 2^(coff - r') = 0)
+                *reinterpret_cast<float4*>(&tA[(nfar + lane) * 4]) = float4{1.0e18f, 1.0e18f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < NPT; e++) tB[(nfar + lane) * NPT + e] = 1.0e36f;
+                *reinterpret_cast<float2*>(&tC[(nfar + lane) * 2]) = float2{0.f, 0.f};
             }
             cnt_near += (unsigned)nnear;
             cnt_far += (unsigned)nfar;
             if (pass) cnt_redo += (unsigned)nnear;
-            // ---- near tier: fp64, kNearUnroll sources in flight ----
-            for (int i0 = 0; i0 < nnear; i0 += kNearUnroll) {
-                // breadth-first over the pairs in flight: every stage of e^{-lambda r}/r for all of them before the next stage, so that
-                // the dependent chain of one pair (rsq -> Newton -> exponent -> table -> ldexp) is covered by the others' independent work
-                double wx[kNearUnroll], wy[kNearUnroll], wz[kNearUnroll], x[kNearUnroll][NPT];
+            // one near source against the lane's z-column; breadth-first over the pairs in flight: every stage of e^{-lambda r}/r for all of them before the next stage, so
+            // that the dependent chain of one pair (rsq -> Newton -> exponent -> table -> exponent insertion) is covered by the others' independent work
+            auto near_source = [&](const double (&rec)[6]) {
+                const double dx = px - rec[0], dy = py - rec[1];
+                const double dxy2 = dx * dx + dy * dy;
+                const double dz0 = pz0 - rec[2];
+                double x[NPT], g[NPT];
 #pragma unroll
-                for (int u = 0; u < kNearUnroll; u++) {
-                    const int s = i0 + u;
-                    const double sz = tile[6 * s + 2];
-                    wx[u] = tile[6 * s + 3];
-                    wy[u] = tile[6 * s + 4];
-                    wz[u] = tile[6 * s + 5];
-                    const double dx = px - tile[6 * s], dy = py - tile[6 * s + 1];
-                    const double dxy2 = dx * dx + dy * dy;
-                    const double dz0 = pz0 - sz;
-#pragma unroll
-                    for (int e = 0; e < NPT; e++) {
-                        const double dz = e ? dz0 + e * P.cell : dz0;   // (the block's nodes are consecutive planes: one z per lane, the others by the cell size)
-                        x[u][e] = fma(dz, dz, dxy2);
-                    }
+                for (int e = 0; e < NPT; e++) {
+                    const double dz = e ? dz0 + e * P.cell : dz0;   // (the block's nodes are consecutive planes: one z per lane, the others by the cell size)
+                    x[e] = fma(dz, dz, dxy2);
                 }
-                double g[kNearUnroll][NPT];
-#if SHM_TIER_NEAR_BFS
-                constexpr int kB = SHM_TIER_NEAR_BATCH < kNearUnroll * NPT ? SHM_TIER_NEAR_BATCH : kNearUnroll * NPT;
+                constexpr int kB = SHM_TIER_NEAR_BATCH < NPT ? SHM_TIER_NEAR_BATCH : NPT;
 #pragma unroll
-                for (int b0 = 0; b0 < kNearUnroll * NPT; b0 += kB) yukawa_near_batch<kB>(&x[0][0] + b0, P.cexp, exp_tab, &g[0][0] + b0);
-#else
+                for (int b0 = 0; b0 < NPT; b0 += kB) yukawa_near_batch<kB>(x + b0, P.cexp, m1, exp_tab, g + b0);
 #pragma unroll
-                for (int u = 0; u < kNearUnroll; u++)
+                for (int e = 0; e < NPT; e++) {
+                    ax[e] = fma(rec[3], g[e], ax[e]);
+                    ay[e] = fma(rec[4], g[e], ay[e]);
+                    az[e] = fma(rec[5], g[e], az[e]);
+                }
+            };
+            // ---- near tier: fp64 ----
+            for (int i0 = 0; i0 < nnear; i0++) {
+                double rec[6];
 #pragma unroll
-                    for (int e = 0; e < NPT; e++) g[u][e] = yukawa_near(x[u][e], P.cexp, exp_tab);
-#endif
-#pragma unroll
-                for (int u = 0; u < kNearUnroll; u++)
-#pragma unroll
-                    for (int e = 0; e < NPT; e++) {
-                        ax[e] = fma(wx[u], g[u][e], ax[e]);
-                        ay[e] = fma(wy[u], g[u][e], ay[e]);
-                        az[e] = fma(wz[u], g[u][e], az[e]);
-                    }
+                for (int a = 0; a < 6; a++) rec[a] = tile[6 * i0 + a];
+                near_source(rec);
             }
             // ---- far tier: packed fp32 (two nodes per instruction), kFarUnroll sources in flight (the transcendentals' results arrive late) ----
             for (int i0 = 0; i0 < nfar; i0 += kFarUnroll) {
 #pragma unroll
                 for (int u = 0; u < kFarUnroll; u++) {
                     const int s = i0 + u;
-#if SHM_TIER_FAR_STRIDE == 8
-                    const float4 pa = *reinterpret_cast<const float4*>(&tile32[8 * s]), pb = *reinterpret_cast<const float4*>(&tile32[8 * s + 4]);
-                    const float wx = pb.x, wy = pb.y, wz = pb.z;
-#if SHM_TIER_CHECK
-                    const float wl1 = pa.w;
-#endif
-                    const float dz0 = qz0 - pa.z;
-                    const float dx = qx - pa.x, dy = qy - pa.y;   // (scaled coordinates: qx, qy, qz and the staged positions are x lambda log2 e)
-#else
-                    const float wx = tile32[6 * s + 3], wy = tile32[6 * s + 4], wz = tile32[6 * s + 5];
-#if SHM_TIER_CHECK
-                    const float wl1 = fabsf(wx) + fabsf(wy) + fabsf(wz);
-#endif
-                    const float dz0 = qz0 - tile32[6 * s + 2];
-                    const float dx = qx - tile32[6 * s], dy = qy - tile32[6 * s + 1];
-#endif
+                    const float4 pa = *reinterpret_cast<const float4*>(&tA[4 * s]);
+                    const float2v pc = *reinterpret_cast<const float2v*>(&tC[2 * s]);
+                    const float2v wxy = {pa.z, pa.w};
+                    float2v zz[NPT / 2];
+                    if constexpr (NPT == 4) {
+                        const float4 pb = *reinterpret_cast<const float4*>(&tB[4 * s]);
+                        zz[0] = float2v{pb.x, pb.y};
+                        zz[1] = float2v{pb.z, pb.w};
+                    } else {
+                        zz[0] = *reinterpret_cast<const float2v*>(&tB[2 * s]);
+                    }
+                    const float dx = qx - pa.x, dy = qy - pa.y;   // (scaled coordinates: qx, qy and the staged positions are x lambda log2 e)
                     const float dxy2 = dx * dx + dy * dy;
 #pragma unroll
-                    for (int e = 0; e < NPT; e += 2) {
-                        const float2v dz = float2v{e * cellq, (e + 1) * cellq} + dz0;   // (consecutive planes: one scaled z per lane, the others by the scaled cell size)
-                        const float2v d2 = __builtin_elementwise_fma(dz, dz, float2v{dxy2, dxy2});
+                    for (int h = 0; h < NPT / 2; h++) {
+                        const float2v d2 = zz[h] + float2v{dxy2, dxy2};
                         const float2v rinv = {__builtin_amdgcn_rsqf(d2.x), __builtin_amdgcn_rsqf(d2.y)};   // 1 / (lambda log2 e r)
                         const float2v arg = __builtin_elementwise_fma(-d2, rinv, float2v{coff, coff});     // -lambda log2 e (r - d0)
                         const float2v ex = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
                         const float2v g = ex * rinv;
-                        float2v a;
-                        a = __builtin_elementwise_fma(float2v{wx, wx}, g, float2v{fx[e], fx[e + 1]}); fx[e] = a.x; fx[e + 1] = a.y;
-                        a = __builtin_elementwise_fma(float2v{wy, wy}, g, float2v{fy[e], fy[e + 1]}); fy[e] = a.x; fy[e + 1] = a.y;
-                        a = __builtin_elementwise_fma(float2v{wz, wz}, g, float2v{fz[e], fz[e + 1]}); fz[e] = a.x; fz[e + 1] = a.y;
+                        pk_fma_lo(fx[h], wxy, g);
+                        pk_fma_hi(fy[h], wxy, g);
+                        pk_fma_lo(fz[h], pc, g);
 #if SHM_TIER_CHECK
-                        if (SHM_TIER_CHECK_ALL || (u & 1) == 0) { a = __builtin_elementwise_fma(float2v{wl1, wl1}, g, float2v{fl[e], fl[e + 1]}); fl[e] = a.x; fl[e + 1] = a.y; }
+                        if (SHM_TIER_CHECK_ALL || (u & 1) == 0) pk_fma_hi(fl[h], pc, g);
 #endif
                     }
                 }
@@ -454,20 +522,24 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
             // a-posteriori test of the far tier's contribution (see the header): eps_far L1_far <= budget |X| at every node of the block, or the far sources
             // are evaluated again in fp64 (pass 1) and the packed-fp32 sums discarded
             bool fail = false;
+            const double e0 = far_scale();
 #pragma unroll
             for (int e = 0; e < NPT; e++) {
-                const double x0 = ax[e] + (double)fx[e] * e0, x1 = ay[e] + (double)fy[e] * e0, x2 = az[e] + (double)fz[e] * e0;
-                fail = fail || (live_xy && kk0 + e < P.kk_end && (double)fl[e] * (SHM_TIER_CHECK_ALL ? 1.0 : 2.0) * e0 > (double)P.far_redo_ratio * sqrt(x0 * x0 + x1 * x1 + x2 * x2));
+                const double x0 = ax[e] + (double)fx[e / 2][e & 1] * e0, x1 = ay[e] + (double)fy[e / 2][e & 1] * e0, x2 = az[e] + (double)fz[e / 2][e & 1] * e0;
+                fail = fail || (live_xy && kk0 + e < P.kk_end && (double)fl[e / 2][e & 1] * (SHM_TIER_CHECK_ALL ? 1.0 : 2.0) * e0 > (double)P.far_redo_ratio * sqrt(x0 * x0 + x1 * x1 + x2 * x2));
             }
             if (__ballot(fail) == 0ull) break;
 #pragma unroll
-            for (int e = 0; e < NPT; e++) fx[e] = fy[e] = fz[e] = 0.f;
+            for (int e = 0; e < NPT / 2; e++) fx[e] = fy[e] = fz[e] = float2v{0.f, 0.f};
         }
         }  // pass loop
+        const double e0 = far_scale();
 #pragma unroll
         for (int e = 0; e < NPT; e++) {
             if (!(live_xy && kk0 + e < P.kk_end)) continue;
-            const double x0 = ax[e] + (double)fx[e] * e0, x1 = ay[e] + (double)fy[e] * e0, x2 = az[e] + (double)fz[e] * e0;
+            // the block's scale back on (exact unless the reference's own sum underflows: 2^k0 ~ e^{-lambda d0} < 1e-308 only > 700 / lambda from every source)
+            const double x0 = __builtin_amdgcn_ldexp(ax[e] + (double)fx[e / 2][e & 1] * e0, k0), x1 = __builtin_amdgcn_ldexp(ay[e] + (double)fy[e / 2][e & 1] * e0, k0),
+                         x2 = __builtin_amdgcn_ldexp(az[e] + (double)fz[e / 2][e & 1] * e0, k0);
             const double nrm = sqrt(x0 * x0 + x1 * x1 + x2 * x2);
             const size_t vi = (size_t)(kk0 + e) * plane + (size_t)cj * n + ci;   // (live: kk0 + e is a plane of the launch)
             // 0/0 -> NaN exactly like X /= X.norm() (:61).  A wave writes 64-byte row segments (8 nodes: half lines); the x-adjacent block is a neighbouring

@@ -480,6 +480,7 @@ struct Solver final : SolverBase {
     std::vector<double> h_pos, h_wn, h_area;
     double area_sum = 0., conv_far_gap = 0., conv_skip_base = 3.0e38, last_host_setup_ms = 0., last_setup_wall_ms = 0.;
     double conv_tier_log = 0., conv_tier_skip_base = 3.0e38;   // tiered fp64 Step 1: far threshold G (nats) and its drop threshold
+    double conv_w_span = 0.;                                   // ln(largest / smallest non-zero source weight)
     bool conv_tiered = false;                                  // fp64 only; SHM_CONV_EXACT=1 selects the all-fp64 kernel
     DevArray<unsigned long long> d_pair_counters;              // [0] fp64 pairs, [1] fp32 pairs evaluated by the last Step 1, [2] pairs evaluated again in fp64 (a-posteriori test)
     DevArray<unsigned> d_unit_counters;                        // tiered Step 1: eight work-queue heads (one per XCD) per launch (zeroed at the start of every Step 1)
@@ -707,6 +708,7 @@ struct Solver final : SolverBase {
             // and the fp32 solve's sums rely on.  The fp64 copies keep the reference's own weights (its arithmetic incl. its gradual underflow far from the
             // sources); the tiered kernel applies the factor when it converts a far source to fp32.
             conv_wscale = amax > 0. && std::isfinite(amax) ? std::ldexp(1.0, -std::ilogb(amax) - 1) : 1.0;
+            conv_w_span = amax > 0. && amin < 1e300 ? std::log(amax / amin) : 0.;
             const double wscale = sizeof(T) == 4 ? conv_wscale : 1.0;
             for (int64_t t = 0; t < Spad; t++) {
                 const int64_t s = order[(size_t)std::min<int64_t>(t, S - 1)].second;  // padding repeats the last source with zero weight
@@ -893,7 +895,17 @@ struct Solver final : SolverBase {
     // shm_opts.step1_arith: the tiered kernel unless the caller (or SHM_CONV_EXACT=1, read per call: tests flip it inside one process) asks for the reference's arithmetic
     void select_step1_arith(int arith) {
         if (arith != SHM_STEP1_AUTO && arith != SHM_STEP1_EXACT_F64) throw Error(SHM_ERR_INVALID, "unknown step1_arith");
-        conv_tiered = sizeof(T) == 8 && arith == SHM_STEP1_AUTO && getenv("SHM_CONV_EXACT") == nullptr;
+        conv_tiered = sizeof(T) == 8 && arith == SHM_STEP1_AUTO && getenv("SHM_CONV_EXACT") == nullptr && tier_exponent_span_ok();
+    }
+    // The tiered kernel's near tier works relative to one power of two per block and inserts a term's own power of two into the exponent field by an integer
+    // add (yukawa_near): valid while no evaluated term of a block is more than 2^-990 below the block's scale.  A source that is not dropped lies at most
+    // (skip + ln(w_s / w_near)) / lambda further from the block than the block's nearest source, and a block spans 2 rt: the evaluated exponents of a block span
+    // at most lambda' (4 rt) + skip' + log2(w_max / w_min) bits (62 bits stand in for a nearest source of weight zero: the kernel's floor of 1e-37 on w_near^2).
+    // Beyond that -- a cell of some 25 mean edge lengths, tCoef ~ 1e-3 -- Step 1 runs in the all-fp64 kernel, whose v_ldexp_f64 underflows gradually.
+    bool tier_exponent_span_ok() const {
+        const double rt = std::sqrt(2 * 3.5 * 3.5 + 1.5 * 1.5) * cell;
+        const double bits = (4.0 * rt * lambda + std::min(conv_tier_skip_base, 1.0e6) + std::max(conv_w_span, 43.0)) * 1.4426950408889634 + 16.0;
+        return bits < 990.0;
     }
     void need_problem() const {
         if (!have_problem) throw Error(SHM_ERR_STATE, "shm_grid_set_problem has not been called");
@@ -917,6 +929,7 @@ struct Solver final : SolverBase {
             P.k0 = sl.k0;
             for (int a = 0; a < 3; a++) P.bbox_min[a] = bbox_min[a] - conv_ctr[a];   // Step 1 works in grid-centred coordinates (see set_problem)
             P.cell = cell;
+            for (int a = 0; a < 3; a++) P.pad_pos[a] = P.bbox_min[a] - (double)n * cell;
             P.lambda = lambda;
             P.cexp = -lambda * 2954.639443740597;  // 2048 / ln 2
             P.S = n_clusters * conv_cluster<T>();

@@ -147,6 +147,7 @@ struct ConvParams {
     int exact_offset;   // fp32 path only: 1 = per-node nearest-source distance (coarse grids: lambda * tile diameter too large)
     int n_tiles;        // total tiles; workgroups stride over them (fewer workgroups than slots leave room for the set-up stream)
     double wscale;         // tiered fp64 path: power of two that brings the largest source weight into (0.5, 1] -- applied to the fp32 copies of the weights only
+    double pad_pos[3];     // tiered fp64 path: where the zero-weight padding entries of a compacted source list sit (bbox_min - n cell: a grid side from every node)
     float far_redo_ratio;  // tiered fp64 path: a block whose packed-fp32 sums exceed this fraction of |X| at any node evaluates its far sources again in fp64
                            // (= budget on Y / calibrated relative error of a packed-fp32 term; 3e38: never)
 };
