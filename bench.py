@@ -266,7 +266,7 @@ def also_legs(shm, HostSolver, device, tol, pre256, scrub256):
     return out
 
 
-def multi_gpu_legs(shm, dist, torch, args, pre, precision, scrub, rank, world, local_rank, barrier):
+def multi_gpu_legs(shm, HostSolver, dist, torch, args, pre, precision, scrub, rank, world, local_rank, barrier):
     """N > 1 only.  The timed default above is the gathered dual solve (Steps 1-2 on z-slabs, D^T Y gathered, whole-grid solve replicated).  The split the
     north star names -- z-slab stencil PCG with a one-plane halo exchange per sweep and an all-reduce per dot product -- is SHM_SOLVER_PRIMAL; it is
     run here as further legs on the SAME ranks so that whichever multi-GPU run the driver gets covers both: the DCT-preconditioned stencil PCG to the
@@ -305,6 +305,46 @@ def multi_gpu_legs(shm, dist, torch, args, pre, precision, scrub, rank, world, l
         except Exception as e:   # never lose the headline over an extra leg (every rank fails alike: the library's checks are rank-independent)
             out[name] = {"failed": repr(e)}
     s.close()
+    # BASELINE.json's own multi-GPU configurations, end to end with the library defaults on the SAME ranks: configs[3] (bunny.pc 512^3 fp64) and configs[4]
+    # (SprayBottle.pc 1024^3 fp32, z-slabs weighted by the Step-1 work the source culling leaves in them) -- so that whichever multi-GPU record the driver
+    # gets carries them whatever --workload it timed.  SHM_BENCH_MULTI_HCOEF: stand-in grid size for the flow test on a one-GPU box.
+    for wl in ("bunny_pc_512_f64", "spraybottle_pc_1024_f32"):
+        if wl == args.workload:
+            continue
+        try:
+            path2, hc2, prec2 = WORKLOADS[wl]
+            hc2 = float(os.environ.get("SHM_BENCH_MULTI_HCOEF", hc2))
+            pre2 = HostSolver(os.path.join(ROOT, path2)).preprocess(hCoef=hc2)
+            box = [shm.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            plan = 1 if prec2 == 32 else 0
+            s2 = shm.GridSolver(device=local_rank, precision=prec2, rank=rank, world=world, rccl_unique_id=box[0], slab_plan=plan)
+            n2 = pre2["n"]
+            s2.set_problem(pre2["pos"], pre2["wnormal"], pre2["area"], pre2["lam"], n2, pre2["bbox_min"], pre2["cell"])
+            scrub2 = not path2.endswith(".pc")
+            s2.solve(scrub=scrub2)
+            barrier()
+            reps = 2 if n2 <= 512 else 1
+            t0 = time.perf_counter()
+            sts = [s2.solve(scrub=scrub2).as_dict() for _ in range(reps)]
+            barrier()
+            dt = time.perf_counter() - t0
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item()) / reps
+            a = {k: float(np.mean([x[k] for x in sts])) for k in sts[0]}
+            mine = {"rank": rank, "ms_conv": a["ms_conv"], "pairs_fp64": a.get("pairs_fp64", 0.0), "pairs_fp32": a.get("pairs_fp32", 0.0), "ms_total": a["ms_total"]}
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
+            out[wl + "_end_to_end"] = {"value": n2 ** 3 / dt, "unit": "grid-nodes/s", "ms_per_step": 1e3 * dt, "steps": reps, "grid": "%d^3" % n2, "sources": int(pre2["S"]),
+                                       "constraint_rows": int(a["m"]), "dtype": "f64 (Step 1: f64 / packed-f32 tiers)" if prec2 == 64 else "f32",
+                                       "partition": "z-slabs x%d%s" % (world, " (planes weighted by Step-1 work)" if plan else ""),
+                                       "solver": int(a["solver"]), "cg_iters": int(a["iters"]), "rel_residual": a["rel_residual"],
+                                       "phases_ms": {k: a[k] for k in ("ms_conv", "ms_div", "ms_wait_setup", "ms_pcg", "ms_shift", "ms_total")},
+                                       "per_rank": per_rank}
+            s2.close()
+        except Exception as e:
+            out[wl + "_end_to_end"] = {"failed": repr(e)}
     return out
 
 
@@ -507,21 +547,33 @@ def main():
         # line without them, and the processes exit -- the timed result above is never lost to an extra.
         import threading
         legs_done = threading.Event()
+        line_lock = threading.Lock()   # the record is printed exactly once: by the watchdog (legs hung) or by the main thread (legs done), whoever takes the lock first
+        line_printed = [False]
 
         def watchdog():
             if not legs_done.wait(float(os.environ.get("SHM_BENCH_LEGS_TIMEOUT", "300"))):
-                if rank == 0:
-                    out["also_multi"] = {"failed": "timed out; the record above is complete without these legs"}
-                    print(json.dumps(out), flush=True)
-                os._exit(0)
+                with line_lock:
+                    if line_printed[0]:
+                        return
+                    line_printed[0] = True
+                    if rank == 0:
+                        headline = dict(out)   # (the main thread only ever ADDS "also_multi" to `out`, after the legs: this copy cannot see a half-written record)
+                        headline["also_multi"] = {"failed": "timed out after SHM_BENCH_LEGS_TIMEOUT; the record above is complete without these legs; exit status 3"}
+                        print(json.dumps(headline), flush=True)
+                    os._exit(3)        # a hang in an extra leg is not a green run: the headline line is on stdout, the launcher sees a failing status
 
         threading.Thread(target=watchdog, daemon=True).start()
         solver.close()   # (its communicator and whole-grid arrays go first: the legs build their own solver on a fresh communicator)
-        multi = multi_gpu_legs(shm, dist, torch, args, pre, precision, scrub, rank, world, local_rank, barrier)
-        legs_done.set()
-        if rank == 0:
-            out["also_multi"] = multi
-    if rank == 0:
+        multi = multi_gpu_legs(shm, HostSolver, dist, torch, args, pre, precision, scrub, rank, world, local_rank, barrier)
+        with line_lock:
+            if line_printed[0]:       # the watchdog got there first and is taking the process down
+                return
+            line_printed[0] = True
+            legs_done.set()
+            if rank == 0:
+                out["also_multi"] = multi
+                print(json.dumps(out), flush=True)
+    elif rank == 0:
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

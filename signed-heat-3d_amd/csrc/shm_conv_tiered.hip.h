@@ -136,9 +136,6 @@ __device__ __forceinline__ double exp2_tab(double u, const uint2v* __restrict__ 
 // a wave-uniform float as a scalar register (the builtin is integer-typed: pass the bits, not the value)
 __device__ __forceinline__ float uniform_f32(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
-#ifndef SHM_TIER_NT
-#define SHM_TIER_NT 0
-#endif
 #ifndef SHM_TIER_TX
 #define SHM_TIER_TX 8
 #endif
@@ -166,12 +163,6 @@ constexpr int kTierFill = kTierCluster * kTierChunk;
 #ifndef SHM_TIER_FAR_UNROLL
 #define SHM_TIER_FAR_UNROLL 4
 #endif
-#ifndef SHM_TIER_CHECK
-#define SHM_TIER_CHECK 1        // the a-posteriori test of the packed-fp32 sums (per-node L1 sums + second pass); 0: A/B builds only
-#endif
-#ifndef SHM_TIER_CHECK_ALL
-#define SHM_TIER_CHECK_ALL 1    // 1: the L1 sums of the a-posteriori test run over every far source; 0 (A/B: -0.2 ms of 27.9 at 256^3): over every other one, doubled
-#endif
 #ifndef SHM_TIER_LDS_FETCH
 #define SHM_TIER_LDS_FETCH 1    // the next cluster's sources travel global -> LDS directly; 0: through 12 registers per lane (rounds 2-3)
 #endif
@@ -184,13 +175,18 @@ constexpr int kTierFill = kTierCluster * kTierChunk;
 #ifndef SHM_TIER_WAVES_PER_EU
 #define SHM_TIER_WAVES_PER_EU 2
 #endif
-template <int NPT>
+// TY = double, CHECK = true: Step 1 of the fp64 solve (near tier fp64, far tier packed fp32 under the enforced budget).
+// TY = float, CHECK = false (round 5): Step 1 of the fp32 solve -- the host sets the far threshold to -infinity, so every source that is neither dropped nor
+// outside the far tier's exponent range goes through the packed-fp32 body (no L1 sums, no second pass; the few out-of-range sources keep the fp64 body), Y is
+// stored in fp32.  What the fp32 solve gains over conv_normalize_kernel<float> is the culling per (8 x 8 x NPT block, SOURCE) instead of per (8 x 8 x 32 tile,
+// cluster of 32) -- SprayBottle.pc at 256^3: 2 x -- and this kernel's cheaper far body.
+template <int NPT, typename TY, bool CHECK>
 #ifndef SHM_TIER_VGPR_CAP
 #define SHM_TIER_VGPR_CAP 184   // two of its waves + one of a set-up kernel per SIMD
 #endif
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER_WAVES_PER_EU, SHM_TIER_WAVES_PER_EU), amdgpu_num_vgpr(SHM_TIER_VGPR_CAP))) void conv_tiered_kernel(
     ConvParams P, const double* __restrict__ src /* [S][6]: pos xyz, wn xyz */, const float* __restrict__ clusters,
-    const double* __restrict__ exp_tab_g /* [2048]: 2^(j/2048) */, double* __restrict__ Y0, double* __restrict__ Y1, double* __restrict__ Y2,
+    const double* __restrict__ exp_tab_g /* [2048]: 2^(j/2048) */, TY* __restrict__ Y0, TY* __restrict__ Y1, TY* __restrict__ Y2,
     unsigned long long* __restrict__ counters, unsigned* __restrict__ next_unit /* [8] queue heads, zeroed before the launch */) {
     static_assert(NPT % 2 == 0, "the far tier handles a lane's nodes in packed pairs");
     constexpr int kWaves = kBlock / kWave;
@@ -510,14 +506,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                         pk_fma_lo(fx[h], wxy, g);
                         pk_fma_hi(fy[h], wxy, g);
                         pk_fma_lo(fz[h], pc, g);
-#if SHM_TIER_CHECK
-                        if (SHM_TIER_CHECK_ALL || (u & 1) == 0) pk_fma_hi(fl[h], pc, g);
-#endif
+                        if constexpr (CHECK) pk_fma_hi(fl[h], pc, g);
                     }
                 }
             }
         }
-        if (!SHM_TIER_CHECK) break;
+        if (!CHECK) break;
         if (pass == 0) {
             // a-posteriori test of the far tier's contribution (see the header): eps_far L1_far <= budget |X| at every node of the block, or the far sources
             // are evaluated again in fp64 (pass 1) and the packed-fp32 sums discarded
@@ -526,7 +520,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
 #pragma unroll
             for (int e = 0; e < NPT; e++) {
                 const double x0 = ax[e] + (double)fx[e / 2][e & 1] * e0, x1 = ay[e] + (double)fy[e / 2][e & 1] * e0, x2 = az[e] + (double)fz[e / 2][e & 1] * e0;
-                fail = fail || (live_xy && kk0 + e < P.kk_end && (double)fl[e / 2][e & 1] * (SHM_TIER_CHECK_ALL ? 1.0 : 2.0) * e0 > (double)P.far_redo_ratio * sqrt(x0 * x0 + x1 * x1 + x2 * x2));
+                fail = fail || (live_xy && kk0 + e < P.kk_end && (double)fl[e / 2][e & 1] * e0 > (double)P.far_redo_ratio * sqrt(x0 * x0 + x1 * x1 + x2 * x2));
             }
             if (__ballot(fail) == 0ull) break;
 #pragma unroll
@@ -538,22 +532,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
         for (int e = 0; e < NPT; e++) {
             if (!(live_xy && kk0 + e < P.kk_end)) continue;
             // the block's scale back on (exact unless the reference's own sum underflows: 2^k0 ~ e^{-lambda d0} < 1e-308 only > 700 / lambda from every source)
-            const double x0 = __builtin_amdgcn_ldexp(ax[e] + (double)fx[e / 2][e & 1] * e0, k0), x1 = __builtin_amdgcn_ldexp(ay[e] + (double)fy[e / 2][e & 1] * e0, k0),
-                         x2 = __builtin_amdgcn_ldexp(az[e] + (double)fz[e / 2][e & 1] * e0, k0);
+            // (fp32 solve: the direction is formed in the block's own scale -- finite however far the block is from the sources, like the per-tile offset of the fp32 kernel)
+            const int kback = sizeof(TY) == 8 ? k0 : 0;
+            const double x0 = __builtin_amdgcn_ldexp(ax[e] + (double)fx[e / 2][e & 1] * e0, kback), x1 = __builtin_amdgcn_ldexp(ay[e] + (double)fy[e / 2][e & 1] * e0, kback),
+                         x2 = __builtin_amdgcn_ldexp(az[e] + (double)fz[e / 2][e & 1] * e0, kback);
             const double nrm = sqrt(x0 * x0 + x1 * x1 + x2 * x2);
             const size_t vi = (size_t)(kk0 + e) * plane + (size_t)cj * n + ci;   // (live: kk0 + e is a plane of the launch)
             // 0/0 -> NaN exactly like X /= X.norm() (:61).  A wave writes 64-byte row segments (8 nodes: half lines); the x-adjacent block is a neighbouring
             // unit of the same XCD's queue, so the two halves meet in that XCD's L2: PMC, kernel alone (tools/conv_pmc.sh): 412 MB written for 384 MB of
             // output (non-temporal stores: 497 MB; 16 x 4 x NPT blocks: 387 MB but 7 % slower -- the wider block classifies fewer sources as far)
-#if SHM_TIER_NT
-            __builtin_nontemporal_store(x0 / nrm, &Y0[vi]);
-            __builtin_nontemporal_store(x1 / nrm, &Y1[vi]);
-            __builtin_nontemporal_store(x2 / nrm, &Y2[vi]);
-#else
-            Y0[vi] = x0 / nrm;
-            Y1[vi] = x1 / nrm;
-            Y2[vi] = x2 / nrm;
-#endif
+            Y0[vi] = (TY)(x0 / nrm);
+            Y1[vi] = (TY)(x1 / nrm);
+            Y2[vi] = (TY)(x2 / nrm);
         }
     }  // unit loop
     if (counters && lane == 0) {

@@ -267,16 +267,19 @@ struct Row {
 // the object evaluate more pairs in fp64).  weights[k] is proportional to the cost of plane k; shm_plan_slab_weighted() cuts the planes by it.
 //   fp64 (tiered kernel): block = 8 x 8 x 4 nodes, classified per source; near pairs cost 1, far (packed fp32) pairs 0.43 (measured ratio of the two tiers,
 //   DESIGN.md section 4), dropped 0
-//   fp32 (conv_normalize_kernel<float>): block = 8 x 8 x 16 nodes (its culled unit), classified per CLUSTER of 32 Morton-sorted sources with the cluster's
+//   fp32 through the tiered kernel (round 5; `tiered32`): the fp64 rule with the fp32 drop threshold and tier_log = -infinity -- every kept in-range pair costs 0.43
+//   fp32 (conv_normalize_kernel<float>, SHM_CONV32_CLASSIC=1): block = 8 x 8 x 16 nodes (its culled unit), classified per CLUSTER of 32 Morton-sorted sources with the cluster's
 //   bounding sphere and largest weight, like the kernel: kept clusters cost 32 pairs per node, skipped ones 0.  (A per-source rule predicts a 20 % imbalance
 //   of equal slabs on rocker 512^3 where 3 % is measured: the spheres' radii, not the sources' distances, decide what that kernel skips.)
 static void step1_plane_weights_host(int64_t S, const double* pos, const double* wn, double lambda, int n, const double* bbox_min, double cell, int precision,
-                                     double tier_log, double* weights) {
-    const bool f64 = precision == SHM_F64;
+                                     double tier_log, double* weights, bool tiered32 = false) {
+    const bool per_source = precision == SHM_F64 || tiered32;   // the tiered kernel's classification: per (8 x 8 x 4 block, source)
+    const bool f64 = per_source;                                // (below, "f64" selects that model)
+    if (tiered32 && precision != SHM_F64) tier_log = -1.0e30;
     const int bz = f64 ? 4 : 16;
     const double half_z = 0.5 * (bz - 1);
     const double rt = std::sqrt(3.5 * 3.5 * 2 + half_z * half_z) * cell * 1.000001;
-    const double skip_base = std::log((double)S / (f64 ? 2e-9 : 6.0e-8));   // (the kernels' drop thresholds: Solver::set_sources)
+    const double skip_base = std::log((double)S / (precision == SHM_F64 ? 2e-9 : 6.0e-8));   // (the kernels' drop thresholds: Solver::set_sources)
     const double far_cost = 0.43;
     std::vector<double> wmag((size_t)S);
     double wlo = 1e300, whi = 0.;
@@ -481,7 +484,12 @@ struct Solver final : SolverBase {
     double area_sum = 0., conv_far_gap = 0., conv_skip_base = 3.0e38, last_host_setup_ms = 0., last_setup_wall_ms = 0.;
     double conv_tier_log = 0., conv_tier_skip_base = 3.0e38;   // tiered fp64 Step 1: far threshold G (nats) and its drop threshold
     double conv_w_span = 0.;                                   // ln(largest / smallest non-zero source weight)
+    // fp32 handles: the tiered kernel's view of the sources (fp64 records in clusters of 64, the reference's own weights) beside the fp32 kernel's
+    DevArray<double> d_src_t;
+    DevArray<float> d_clusters_t;
+    int n_clusters_t = 0;
     bool conv_tiered = false;                                  // fp64 only; SHM_CONV_EXACT=1 selects the all-fp64 kernel
+    bool conv_tiered32 = false;                                // fp32 handles: Step 1 through the tiered kernel's packed-fp32 body
     DevArray<unsigned long long> d_pair_counters;              // [0] fp64 pairs, [1] fp32 pairs evaluated by the last Step 1, [2] pairs evaluated again in fp64 (a-posteriori test)
     DevArray<unsigned> d_unit_counters;                        // tiered Step 1: eight work-queue heads (one per XCD) per launch (zeroed at the start of every Step 1)
     static constexpr int kMaxConvLaunches = 256;
@@ -805,6 +813,40 @@ struct Solver final : SolverBase {
                 }
             }
             d_clusters.upload(cl, stream);
+            if constexpr (sizeof(T) == 4) {
+                // fp32 solve through the tiered kernel (conv_tiered_kernel<NPT, float, false>): it stages fp64 source records in clusters of 64 and scales the weights itself
+                n_clusters_t = (int)((S + kTierCluster - 1) / kTierCluster);
+                const int64_t Sp = (int64_t)n_clusters_t * kTierCluster;
+                std::vector<double> pk((size_t)Sp * 6, 0.);
+                for (int64_t t = 0; t < Sp; t++) {
+                    const int64_t sidx = order[(size_t)std::min<int64_t>(t, S - 1)].second;  // padding repeats the last source with zero weight
+                    for (int a = 0; a < 3; a++) {
+                        pk[6 * t + a] = h_pos[3 * sidx + a] - conv_ctr[a];
+                        if (t < S) pk[6 * t + 3 + a] = h_wn[3 * sidx + a];
+                    }
+                }
+                std::vector<float> clt((size_t)n_clusters_t * kConvClusterRec, 0.f);
+                for (int c = 0; c < n_clusters_t; c++) {
+                    const double* q = pk.data() + 6 * (size_t)c * kTierCluster;
+                    double cc[3] = {0, 0, 0}, rad = 0., wmax2 = 0.;
+                    for (int e = 0; e < kTierCluster; e++)
+                        for (int a = 0; a < 3; a++) cc[a] += q[6 * e + a] / kTierCluster;
+                    for (int e = 0; e < kTierCluster; e++) {
+                        double d2 = 0., w2 = 0.;
+                        for (int a = 0; a < 3; a++) {
+                            d2 += (q[6 * e + a] - cc[a]) * (q[6 * e + a] - cc[a]);
+                            w2 += q[6 * e + 3 + a] * q[6 * e + 3 + a];
+                        }
+                        rad = std::max(rad, std::sqrt(d2));
+                        wmax2 = std::max(wmax2, w2);
+                    }
+                    for (int a = 0; a < 3; a++) clt[kConvClusterRec * (size_t)c + a] = (float)cc[a];
+                    clt[kConvClusterRec * (size_t)c + 3] = (float)(rad * 1.00001 + 1e-30);
+                    clt[kConvClusterRec * (size_t)c + 4] = wmax2 > 0. ? (float)(0.5 * std::log(wmax2) + 1e-5) : -1.0e30f;
+                }
+                d_src_t.upload(pk, stream);
+                d_clusters_t.upload(clt, stream);
+            }
             if (!d_exptab.p) {
                 std::vector<double> tab(2048);
                 for (int j = 0; j < 2048; j++) tab[(size_t)j] = std::exp2((double)j / 2048.0);
@@ -820,7 +862,8 @@ struct Solver final : SolverBase {
             slab_bounds.assign((size_t)total_slabs + 1, 0);
             if (weighted) {
                 std::vector<double> w((size_t)n);
-                step1_plane_weights_host(S, h_pos.data(), h_wn.data(), lambda, n, bbox_min, cell, sizeof(T) == 8 ? SHM_F64 : SHM_F32, conv_tier_log, w.data());
+                step1_plane_weights_host(S, h_pos.data(), h_wn.data(), lambda, n, bbox_min, cell, sizeof(T) == 8 ? SHM_F64 : SHM_F32, conv_tier_log, w.data(),
+                                         sizeof(T) == 4 && getenv("SHM_CONV32_CLASSIC") == nullptr);
                 plan_slabs_weighted(n, total_slabs, w.data(), sizeof(T) == 8 ? 4 : 8, slab_bounds);
             } else {
                 for (int sidx = 0; sidx < total_slabs; sidx++) {
@@ -896,6 +939,8 @@ struct Solver final : SolverBase {
     void select_step1_arith(int arith) {
         if (arith != SHM_STEP1_AUTO && arith != SHM_STEP1_EXACT_F64) throw Error(SHM_ERR_INVALID, "unknown step1_arith");
         conv_tiered = sizeof(T) == 8 && arith == SHM_STEP1_AUTO && getenv("SHM_CONV_EXACT") == nullptr && tier_exponent_span_ok();
+        // fp32 handles (round 5): the same kernel with every kept pair in its packed-fp32 body and fp32 output; SHM_CONV32_CLASSIC=1: conv_normalize_kernel<float> (A/B)
+        conv_tiered32 = sizeof(T) == 4 && getenv("SHM_CONV32_CLASSIC") == nullptr && tier_exponent_span_ok();
     }
     // The tiered kernel's near tier works relative to one power of two per block and inserts a term's own power of two into the exponent field by an integer
     // add (yukawa_near): valid while no evaluated term of a block is more than 2^-990 below the block's scale.  A source that is not dropped lies at most
@@ -904,7 +949,7 @@ struct Solver final : SolverBase {
     // Beyond that -- a cell of some 25 mean edge lengths, tCoef ~ 1e-3 -- Step 1 runs in the all-fp64 kernel, whose v_ldexp_f64 underflows gradually.
     bool tier_exponent_span_ok() const {
         const double rt = std::sqrt(2 * 3.5 * 3.5 + 1.5 * 1.5) * cell;
-        const double bits = (4.0 * rt * lambda + std::min(conv_tier_skip_base, 1.0e6) + std::max(conv_w_span, 43.0)) * 1.4426950408889634 + 16.0;
+        const double bits = (4.0 * rt * lambda + std::min(sizeof(T) == 8 ? conv_tier_skip_base : conv_skip_base, 1.0e6) + std::max(conv_w_span, 43.0)) * 1.4426950408889634 + 16.0;
         return bits < 990.0;
     }
     void need_problem() const {
@@ -935,7 +980,7 @@ struct Solver final : SolverBase {
             P.S = n_clusters * conv_cluster<T>();
             P.n_clusters = n_clusters;
             P.far_gap = (float)conv_far_gap;
-            P.tier_log = (float)conv_tier_log;
+            P.tier_log = conv_tiered32 ? -1.0e30f : (float)conv_tier_log;   // (fp32 solve: every kept source that stays in the fp32 exponent range is "far")
             P.wscale = conv_wscale;
             {   // a-posteriori test of the packed-fp32 tier (shm_conv_tiered.hip.h): budget on Y / calibrated relative error of a far term as it shows up in X
                 static const double redo_env = getenv("SHM_CONV_REDO_RATIO") ? atof(getenv("SHM_CONV_REDO_RATIO")) : -1.;   // A/B knob (0: never)
@@ -970,7 +1015,8 @@ struct Solver final : SolverBase {
                 const void* kfn = npt4 ? reinterpret_cast<const void*>(conv_normalize_kernel<T, 4>) : reinterpret_cast<const void*>(conv_normalize_kernel<T, 2>);
                 if constexpr (sizeof(T) == 4)
                     if (npt8) kfn = reinterpret_cast<const void*>(conv_normalize_kernel<float, 8>);
-                if (conv_tiered) kfn = npt4 ? reinterpret_cast<const void*>(conv_tiered_kernel<4>) : reinterpret_cast<const void*>(conv_tiered_kernel<2>);
+                if (conv_tiered) kfn = npt4 ? reinterpret_cast<const void*>(conv_tiered_kernel<4, double, true>) : reinterpret_cast<const void*>(conv_tiered_kernel<2, double, true>);
+                if (conv_tiered32) kfn = npt4 ? reinterpret_cast<const void*>(conv_tiered_kernel<4, float, false>) : reinterpret_cast<const void*>(conv_tiered_kernel<2, float, false>);
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, kBlock, 0) != hipSuccess || occ < 1) occ = 2;
                 const unsigned resident = (unsigned)(occ * num_cus);
                 const double pairs = (double)sl.nown * (double)S;
@@ -978,7 +1024,7 @@ struct Solver final : SolverBase {
                 conv_est_total_ms = (&sl == &slabs[0] ? 0. : conv_est_total_ms) + conv_est_ms;
                 const double setup_est_ms = 2.2e-3 * (double)std::min<int64_t>(S, (int64_t)8 * n * n);
                 static const bool no_reserve = getenv("SHM_CONV_NO_RESERVE") != nullptr;  // A/B knob
-                if (conv_tiered) grid = std::min(grid, resident);   // its waves pull work from a queue: exactly the resident workgroups, nothing left to hand out
+                if (conv_tiered || conv_tiered32) grid = std::min(grid, resident);   // its waves pull work from a queue: exactly the resident workgroups, nothing left to hand out
                 if (!no_reserve && !o_fast_hint && conv_est_ms < 4.0 * setup_est_ms && grid > resident - resident / 8) grid = resident - resident / 8;
             }
             // Several launches over z chunks instead of one: the set-up stream's kernels are dispatched only where a Step-1 launch has no workgroups left to
@@ -991,7 +1037,7 @@ struct Solver final : SolverBase {
             const bool uniform_tiles = lambda * cell * n < 100.;
             // (The tiered fp64 kernel needs none of this: its grid is exactly the resident workgroups -- nothing left to hand out -- and its 176 registers leave room on
             // every SIMD for a wave of the set-up kernels, which therefore run WHILE Step 1 runs; one launch, balanced by its work queue.)
-            const int want_chunks = split_env > 0 ? split_env : conv_tiered ? 1 : (uniform_tiles && conv_est_total_ms >= 10. ? std::min(16, (int)std::lround(conv_est_total_ms / 2.5)) : 1);
+            const int want_chunks = split_env > 0 ? split_env : (conv_tiered || conv_tiered32) ? 1 : (uniform_tiles && conv_est_total_ms >= 10. ? std::min(16, (int)std::lround(conv_est_total_ms / 2.5)) : 1);
             const int nchunks = std::max(1, std::min(tiles_z, want_chunks));
             const int chunk_planes = ((tiles_z + nchunks - 1) / nchunks) * tile_z;
             if (!d_pair_counters.p) d_pair_counters.alloc(3);
@@ -1013,22 +1059,29 @@ struct Solver final : SolverBase {
                 Pc.kk_end = std::min(sl.nzl + 1, 1 + b1);
                 Pc.n_tiles = P.tiles_x * P.tiles_y * ((Pc.kk_end - Pc.kk_begin + tz_sel - 1) / tz_sel);
                 const dim3 g((unsigned)std::min<long long>(Pc.n_tiles, grid));
-                if constexpr (sizeof(T) == 8) {
-                    if (conv_tiered) {
-                        // the unit of work is a wave's sub-tile (8 x 8 x NPT nodes), pulled from a per-launch queue head by the waves of a grid no larger than what is resident
-                        if (conv_launch_index >= kMaxConvLaunches) throw Error(SHM_ERR_INVALID, "too many Step-1 launches");
-                        unsigned* const head = d_unit_counters.p + 8 * conv_launch_index++;   // eight queue heads (one per XCD) per launch
-                        const int npt = npt4 ? 4 : 2;
-                        Pc.tiles_x = (n + kTierTX - 1) / kTierTX;
-                        Pc.tiles_y = (n + kTierTY - 1) / kTierTY;
-                        Pc.n_tiles = Pc.tiles_x * Pc.tiles_y * ((Pc.kk_end - Pc.kk_begin + npt - 1) / npt);
-                        const dim3 gt((unsigned)std::min<long long>((Pc.n_tiles + 3) / 4, grid));
+                if (conv_tiered || conv_tiered32) {
+                    // the unit of work is a wave's sub-tile (8 x 8 x NPT nodes), pulled from a per-launch queue head by the waves of a grid no larger than what is resident
+                    if (conv_launch_index >= kMaxConvLaunches) throw Error(SHM_ERR_INVALID, "too many Step-1 launches");
+                    unsigned* const head = d_unit_counters.p + 8 * conv_launch_index++;   // eight queue heads (one per XCD) per launch
+                    const int npt = npt4 ? 4 : 2;
+                    Pc.tiles_x = (n + kTierTX - 1) / kTierTX;
+                    Pc.tiles_y = (n + kTierTY - 1) / kTierTY;
+                    Pc.n_tiles = Pc.tiles_x * Pc.tiles_y * ((Pc.kk_end - Pc.kk_begin + npt - 1) / npt);
+                    const dim3 gt((unsigned)std::min<long long>((Pc.n_tiles + 3) / 4, grid));
+                    if constexpr (sizeof(T) == 8) {
                         if (npt4)
-                            hipLaunchKernelGGL((conv_tiered_kernel<4>), gt, dim3(kBlock), 0, stream, Pc, d_src.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p, sl.Y2.p, cnt, head);
+                            hipLaunchKernelGGL((conv_tiered_kernel<4, double, true>), gt, dim3(kBlock), 0, stream, Pc, d_src.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p, sl.Y2.p, cnt, head);
                         else
-                            hipLaunchKernelGGL((conv_tiered_kernel<2>), gt, dim3(kBlock), 0, stream, Pc, d_src.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p, sl.Y2.p, cnt, head);
-                        return;
+                            hipLaunchKernelGGL((conv_tiered_kernel<2, double, true>), gt, dim3(kBlock), 0, stream, Pc, d_src.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p, sl.Y2.p, cnt, head);
+                    } else {
+                        Pc.S = n_clusters_t * kTierCluster;
+                        Pc.n_clusters = n_clusters_t;
+                        if (npt4)
+                            hipLaunchKernelGGL((conv_tiered_kernel<4, float, false>), gt, dim3(kBlock), 0, stream, Pc, d_src_t.p, d_clusters_t.p, d_exptab.p, sl.Y0.p, sl.Y1.p, sl.Y2.p, cnt, head);
+                        else
+                            hipLaunchKernelGGL((conv_tiered_kernel<2, float, false>), gt, dim3(kBlock), 0, stream, Pc, d_src_t.p, d_clusters_t.p, d_exptab.p, sl.Y0.p, sl.Y1.p, sl.Y2.p, cnt, head);
                     }
+                    return;
                 }
                 // the tiles of a launch are handed out by a queue head (culled workloads: their costs differ severalfold); SHM_CONV_STATIC: static stride (A/B knob)
                 static const bool static_tiles = getenv("SHM_CONV_STATIC") != nullptr;
@@ -1047,7 +1100,7 @@ struct Solver final : SolverBase {
                     hipLaunchKernelGGL((conv_normalize_kernel<T, 2>), g, dim3(kBlock), 0, stream, Pc, d_src.p, d_src32.p, d_clusters.p, d_exptab.p, sl.Y0.p, sl.Y1.p, sl.Y2.p, cnt, head);
             };
             const int sel0 = npt8 ? 8 : npt4 ? 4 : 2;
-            if (sizeof(T) == 4 && nchunks == 1 && sel0 > 2 && planes % tile_z != 0) {
+            if (sizeof(T) == 4 && !conv_tiered32 && nchunks == 1 && sel0 > 2 && planes % tile_z != 0) {
                 // planes that do not fill the last layer of 32- (16-) plane tiles (a weighted slab plan cuts at multiples of 8 planes): that layer would run with most
                 // of its lanes dead, so the remainder goes to the kernel shapes with fewer nodes per lane (same arithmetic; the 8-plane shape culls in smaller units)
                 int b = (planes / tile_z) * tile_z;
@@ -1219,7 +1272,9 @@ struct Solver final : SolverBase {
     // a fixed rate -- conv_est_total_ms -- are off by up to 9x on the culled inputs.
     double estimate_step1_ms_tiered() const {
         if (S <= 0) return 0.;
-        const int K = (int)std::max<int64_t>(32, std::min<int64_t>(128, 2000000 / S));   // <= 2e6 (sample, source) pairs: ~2 ms of host time, paid before the set-up is queued
+        const int K = (int)std::max<int64_t>(32, std::min<int64_t>(128, 2000000 / S));
+        const int64_t stride = std::max<int64_t>(1, (S * K + 1999999) / 2000000);   // <= 2e6 (sample, source) pairs whatever S (the floor of 32 samples alone let point
+                                                                                     // clouds of 1e5-1e6 sources run tens of ms here): ~2 ms of host time, paid before the set-up is queued
         uint64_t st = 0x9E3779B97F4A7C15ULL;
         auto rnd = [&]() {
             st = st * 6364136223846793005ULL + 1442695040888963407ULL;
@@ -1232,7 +1287,7 @@ struct Solver final : SolverBase {
         for (int k = 0; k < K; k++) {
             const float x = (float)(bbox_min[0] + rnd() * ext), y = (float)(bbox_min[1] + rnd() * ext), z = (float)(bbox_min[2] + rnd() * ext);
             float dmin = 3.0e38f;
-            for (int64_t s = 0; s < S; s++) {
+            for (int64_t s = 0; s < S; s += stride) {
                 const float dx = x - (float)h_pos[3 * s], dy = y - (float)h_pos[3 * s + 1], dz = z - (float)h_pos[3 * s + 2];
                 const float v = dx * dx + dy * dy + dz * dz;
                 d2[(size_t)s] = v;
@@ -1240,15 +1295,16 @@ struct Solver final : SolverBase {
             }
             const double rn = std::sqrt((double)dmin);
             const float tn = (float)((rn + r_near_gap) * (rn + r_near_gap)), tk = (float)((rn + r_keep_gap) * (rn + r_keep_gap));
-            for (int64_t s = 0; s < S; s++) {
+            for (int64_t s = 0; s < S; s += stride) {
                 c_near += d2[(size_t)s] < tn;
                 c_keep += d2[(size_t)s] < tk;
             }
         }
-        const double f_near = (double)c_near / ((double)K * (double)S), f_keep = (double)c_keep / ((double)K * (double)S);
+        const double sampled = (double)K * (double)((S + stride - 1) / stride);
+        const double f_near = (double)c_near / sampled, f_keep = (double)c_keep / sampled;
         double nodes = 0.;
         for (const Slab<T>& sl : slabs) nodes += (double)sl.nown;
-        return nodes * (double)S * (1.229e-9 * f_near + 1.84e-10 * (f_keep - f_near) + 3.3e-12);
+        return nodes * (double)S * (1.14e-9 * f_near + 1.56e-10 * (f_keep - f_near) + 3.3e-12);   // (per-pair costs of the round-5 kernel: 256^3 bunny 24 ms alone)
     }
 
     // Per-slab CSR pieces, shift items, G = A A^T (sparse triplets -> dense on device -> inverted) and B = A K A^T.
@@ -1946,13 +2002,16 @@ struct Solver final : SolverBase {
             W1.alloc((size_t)n * n * P);
             HIPCHK(hipMemsetAsync(gs_Ct.p, 0, (size_t)n * P * sizeof(double), st));
             hipLaunchKernelGGL(cosine_tables_kernel, dim3(grid_for(n1 * n, 1024)), dim3(kBlock), 0, st, n, P, gs_ctab.p, gs_Cm.p, gs_Ct.p);
-            hipLaunchKernelGGL(green_symbol_kernel, dim3(grid_for((size_t)n * n * n, 4096)), dim3(kBlock), 0, st, n, gs_lam.p, W0.p);
+            hipLaunchKernelGGL(green_symbol_kernel, dim3((unsigned)std::min(n * n, 8 * num_cus)), dim3(kBlock), 0, st, n, gs_lam.p, W0.p);
             // beside the tiered fp64 Step 1 (two 184-register waves per SIMD) only the narrow shape fits on a SIMD; otherwise the 128 x 128 tiles
             static const bool gemm_wide_env = getenv("SHM_GREEN_WIDE") != nullptr;   // A/B knob
-            const bool narrow = (conv_tiered || getenv("SHM_GREEN_NARROW") != nullptr) && !gemm_wide_env;
+            const bool narrow = (conv_tiered || conv_tiered32 || getenv("SHM_GREEN_NARROW") != nullptr) && !gemm_wide_env;
             auto tiles = [](size_t v) { return (unsigned)((v + kGemmT - 1) / kGemmT); };
             auto gemm = [&](unsigned batches, int M, int N, int K, const double* A, int lda, long long sA, const double* B, int ldb, long long sB, double* C, int ldc, long long sC) {
-                if (narrow)
+                static const int wn_env = getenv("SHM_GREEN_WN") ? atoi(getenv("SHM_GREEN_WN")) : 0;   // A/B knob (round 5)
+                if (narrow && wn_env == 2)
+                    hipLaunchKernelGGL(dgemm_rm_kernel<2>, dim3((unsigned)((N + 63) / 64), tiles((size_t)M), batches), dim3(kBlock), 0, st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, setup_prio);
+                else if (narrow)
                     hipLaunchKernelGGL(dgemm_rm_kernel<1>, dim3((unsigned)((N + 31) / 32), tiles((size_t)M), batches), dim3(kBlock), 0, st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, setup_prio);
                 else
                     hipLaunchKernelGGL(dgemm_rm_kernel<4>, dim3(tiles((size_t)N), tiles((size_t)M), batches), dim3(kBlock), 0, st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, setup_prio);
@@ -2908,7 +2967,7 @@ struct Solver final : SolverBase {
         Event c_s2a, c_s2b, e_gather, f_start, f_setup;
         c_s2a.record(F.stream2);
         F.conv_est_total_ms = conv_est_total_ms;   // what the whole-grid solver's set-up can hide behind is this rank's share of Step 1
-        F.conv_tiered = conv_tiered;               // ... and beside WHICH Step-1 kernel it runs: the tiered one leaves room only for the narrow GEMM shape (round 4: the
+        F.conv_tiered = conv_tiered || conv_tiered32;               // ... and beside WHICH Step-1 kernel it runs: the tiered one leaves room only for the narrow GEMM shape (round 4: the
                                                    // whole-grid solver never learnt this and queued the 256-register shape, which waits for Step 1's persistent waves to end)
         F.dual_direct_requested = true;
         F.build_constraints();
@@ -3637,7 +3696,8 @@ shm_status shm_step1_plane_weights(const shm_sources* src, const shm_grid* grid,
         return SHM_ERR_INVALID;
     const char* tl = getenv("SHM_CONV_TIER_LOG");
     try {
-        shm::step1_plane_weights_host(src->S, src->pos, src->wnormal, src->lambda, grid->n, grid->bbox_min, grid->cell, precision, tl ? atof(tl) : 8.0, weights);
+        shm::step1_plane_weights_host(src->S, src->pos, src->wnormal, src->lambda, grid->n, grid->bbox_min, grid->cell, precision, tl ? atof(tl) : 8.0, weights,
+                                      precision == SHM_F32 && getenv("SHM_CONV32_CLASSIC") == nullptr);
     } catch (const std::bad_alloc&) {
         return SHM_ERR_NOMEM;
     } catch (...) {

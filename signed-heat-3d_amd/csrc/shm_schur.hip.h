@@ -21,15 +21,21 @@
 
 namespace shm {
 
-// W0[k1][k2][k3] = gamma gamma gamma / lambda_k  (0 for k = 0);  lam1[k] = (2 - 2 cos(pi k / n)) / h^2 is the table the transforms use
+// W0[k1][k2][k3] = gamma gamma gamma / lambda_k  (0 for k = 0);  lam1[k] = (2 - 2 cos(pi k / n)) / h^2 is the table the transforms use.
+// One (k1, k2) row of n entries per workgroup step, k3 across the threads: no 64-bit division by n per element (rounds 2-4 took 0.43 ms at 256^3 for 134 MB of
+// output -- and that much of the vector pipes away from the Step-1 waves it runs beside).  The quotient itself is an IEEE division, as before.
 __global__ __launch_bounds__(kBlock) void green_symbol_kernel(int n, const double* __restrict__ lam1, double* __restrict__ W0) {
-    const size_t N = (size_t)n * n * n;
     const double g0 = 0.5 / n, g1 = 1.0 / n;
-    for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < N; v += (size_t)gridDim.x * kBlock) {
-        const int k3 = (int)(v % n), k2 = (int)((v / n) % n), k1 = (int)(v / ((size_t)n * n));
-        const double lam = lam1[k1] + lam1[k2] + lam1[k3];
-        const double g = (k1 ? g1 : g0) * (k2 ? g1 : g0) * (k3 ? g1 : g0);
-        W0[v] = (k1 | k2 | k3) ? g / lam : 0.;
+    for (int row = blockIdx.x; row < n * n; row += gridDim.x) {
+        const int k1 = row / n, k2 = row - k1 * n;
+        const double l12 = lam1[k1] + lam1[k2];
+        const double g12 = (k1 ? g1 : g0) * (k2 ? g1 : g0);
+        double* const out = W0 + (size_t)row * n;
+        for (int k3 = threadIdx.x; k3 < n; k3 += kBlock) {
+            const double lam = l12 + lam1[k3];
+            const double g = g12 * (k3 ? g1 : g0);
+            out[k3] = (row | k3) ? g / lam : 0.;
+        }
     }
 }
 

@@ -201,8 +201,10 @@ def test_kernel_register_schedules():
     assert conv["VGPRs"] >= 200 and conv["Occupancy"] == 2, conv
     # the tiered fp64 Step 1 must leave room on every SIMD for a wave of the set-up kernels (two of its waves + one of theirs <= 512 registers, LDS likewise):
     # that is what lets the constraint set-up run WHILE Step 1 runs instead of in the gaps between its launches
-    tier = by_name["void shm::conv_tiered_kernel<4>"]
+    tier = by_name["void shm::conv_tiered_kernel<4, double, true>"]
     assert tier["VGPRs"] <= 184 and tier["LDS Size"] <= 52 * 1024, tier      # (two of its workgroups per CU + a set-up workgroup of <= 42 KB: 146 of 160 KB)
+    tier32 = by_name["void shm::conv_tiered_kernel<4, float, false>"]        # round 5: Step 1 of the fp32 solve -- the same budget, so that its set-up runs beside it too
+    assert tier32["VGPRs"] <= 184 and tier32["LDS Size"] <= 52 * 1024, tier32
     room = 512 - 2 * ((tier["VGPRs"] + 7) // 8 * 8)
     for k in ("void shm::dgemm_rm_kernel<1>", "shm::gj_pivot_block4_kernel", "shm::gj_panels_kernel", "void shm::gj_update_kernel<0>", "shm::schur_assemble_kernel", "shm::green_symbol_kernel",
               "shm::gj_step_kernel"):
