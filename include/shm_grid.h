@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SHM_GRID_ABI_VERSION 4 /* 2: shm_stats grew by cg_form (round 2); 3: by pairs_fp64 / pairs_fp32 / conv_launches (round 3); 4: shm_opts grew by step1_arith, shm_stats by pairs_redone,
+#define SHM_GRID_ABI_VERSION 5 /* 5: shm_opts grew by dual_form and step1_budget (round 5); 2: shm_stats grew by cg_form (round 2); 3: by pairs_fp64 / pairs_fp32 / conv_launches (round 3); 4: shm_opts grew by step1_arith, shm_stats by pairs_redone,
                                 * shm_grid_run_conv_arith and shm_grid_get_field_planes added (round 4); callers allocate shm_opts / shm_stats by this header */
 
 typedef struct shm_solver shm_solver; /* opaque */
@@ -100,7 +100,18 @@ typedef struct {
     int32_t preconditioner;   /* SHM_PRECOND_AUTO | _NONE | _DCT  (primal solver only) */
     int32_t solver;           /* SHM_SOLVER_AUTO | _PRIMAL | _DUAL | _DUAL_SLABS */
     int32_t step1_arith;      /* SHM_STEP1_AUTO | SHM_STEP1_EXACT_F64: arithmetic of the Step-1 summation in an SHM_F64 handle (ignored by SHM_F32 handles) */
+    int32_t dual_form;        /* SHM_DUAL_AUTO | _DIRECT | _EXPLICIT_S_CG | _THROUGH_GRID: which form of the dual solver runs (ABI 5; see below) */
+    double step1_budget;      /* error budget of STEP1_AUTO's precision tiers on the normalised field Y; 0 -> 1e-8; accepted range [1e-12, 1e-3] (ABI 5) */
 } shm_opts;
+
+/* Form of the dual solver (SHM_SOLVER_DUAL / AUTO on one process; the same operator in every form, so the same phi up to the tolerance).
+ * AUTO:          chosen per problem (DESIGN.md section 4b'): the direct solve where the inverse of S hides behind Step 1, else CG on the explicit S or through the grid.
+ * DIRECT:        S = A K^+ A^T assembled from the image-sum Green's table and INVERTED beside Step 1; the solve is two dense mat-vecs + refinement passes.
+ *                Applies for m <= 16384 rows, n <= 512, one z-slab; elsewhere the request falls back to AUTO's choice.
+ * EXPLICIT_S_CG: S assembled, CG on it (one dense mat-vec per iteration), preconditioned by (A A^T)^-1 (A K A^T) (A A^T)^-1.
+ * THROUGH_GRID:  CG with S applied through the grid (scatter, five transform sweeps, gather per iteration); no m x m matrix is formed.
+ * stats.cg_form reports what ran (2 / 3 / 0). */
+enum { SHM_DUAL_AUTO = 0, SHM_DUAL_DIRECT = 1, SHM_DUAL_EXPLICIT_S_CG = 2, SHM_DUAL_THROUGH_GRID = 3 };
 
 /* Arithmetic of Step 1 (the N*S direct summation, signed_heat_grid_solver.cpp:48-65 / :157-174; yukawaPotential, signed_heat_3d.cpp:45-49) in an SHM_F64 handle.
  * AUTO:      error-budgeted precision tiers (csrc/shm_conv_tiered.hip.h): per block of 8 x 8 x 4 nodes, sources whose terms are below e^-8 of the block's
@@ -109,7 +120,8 @@ typedef struct {
  *            the budget (cancellation regions; shm_stats.pairs_redone).  max|Y - Y_exact| < 1e-8 (asserted against the C oracle at the full sizes of
  *            BASELINE.json), phi inherits < 1e-9.
  * EXACT_F64: every (node, source) pair in fp64 like the reference (~1.6x the Step-1 time); Y agrees with the serial loops to 1e-11.
- * The environment variable SHM_CONV_EXACT=1 forces EXACT_F64 whatever the caller asks (A/B runs). */
+ * step1_budget (ABI 5) moves AUTO's three thresholds together: a budget b puts the far threshold at e^-(8 - ln(b / 1e-8)), the a-posteriori test at b / 3e-6 and the
+ * drop threshold at b / 5.  (With SHM_DEBUG_KNOBS=1 in the environment, SHM_CONV_EXACT=1 forces EXACT_F64 whatever the caller asks: A/B runs and tests.) */
 enum { SHM_STEP1_AUTO = 0, SHM_STEP1_EXACT_F64 = 1 };
 
 /* How the KKT system of signed_heat_grid_solver.cpp:101-107 is solved.

@@ -46,6 +46,13 @@ struct Error : std::runtime_error {
     Error(shm_status c, const std::string& m) : std::runtime_error(m), code(c) {}
 };
 
+// Experiment knobs (environment variables that select measured-and-rejected variants, A/B shapes and instrumentation) are read only when SHM_DEBUG_KNOBS=1 is set:
+// a product run cannot pick one up by accident (round 5; INTEGRATION.md section 4a lists them).  What a caller may legitimately choose is in shm_opts / shm_config.
+static const char* knob(const char* name) {
+    static const bool on = getenv("SHM_DEBUG_KNOBS") != nullptr && atoi(getenv("SHM_DEBUG_KNOBS")) != 0;
+    return on ? getenv(name) : nullptr;
+}
+
 static std::string fmt(const char* f, ...) {
     char buf[1024];
     va_list ap;
@@ -490,6 +497,8 @@ struct Solver final : SolverBase {
     int n_clusters_t = 0;
     bool conv_tiered = false;                                  // fp64 only; SHM_CONV_EXACT=1 selects the all-fp64 kernel
     bool conv_tiered32 = false;                                // fp32 handles: Step 1 through the tiered kernel's packed-fp32 body
+    int dual_form_req = SHM_DUAL_AUTO;                         // shm_opts.dual_form of the solve in progress
+    double step1_budget = 0.;                                  // shm_opts.step1_budget of the solve in progress (<= 0: kTierBudget)
     DevArray<unsigned long long> d_pair_counters;              // [0] fp64 pairs, [1] fp32 pairs evaluated by the last Step 1, [2] pairs evaluated again in fp64 (a-posteriori test)
     DevArray<unsigned> d_unit_counters;                        // tiered Step 1: eight work-queue heads (one per XCD) per launch (zeroed at the start of every Step 1)
     static constexpr int kMaxConvLaunches = 256;
@@ -530,6 +539,7 @@ struct Solver final : SolverBase {
         DevArray<size_t> offD, offE;
         DevArray<double> D, E, Tm, tbuf, ybuf, vS, uS;
         DevArray<float> D32, E32, T32;
+        DevArray<unsigned> ticket;   // arrival counter of tl_rows_cols_kernel (zero between launches)
         int colour_ptr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         size_t szD = 0, szE = 0;
         TlBoxes view() const { return TlBoxes{ptrI.p, ptrS.p, offD.p, offE.p, rowsI.p, colsS.p}; }
@@ -585,11 +595,11 @@ struct Solver final : SolverBase {
         {
             hipDeviceProp_t prop;
             HIPCHK(hipGetDeviceProperties(&prop, cfg.device));
-            const char* e = getenv("SHM_CONV_SLOTS_PER_CU_X16");  // tuning knob: conv workgroups per CU, in 1/16ths (default 64 = 4, the LDS-limited residency: one persistent wave of workgroups)
+            const char* e = knob("SHM_CONV_SLOTS_PER_CU_X16");  // tuning knob: conv workgroups per CU, in 1/16ths (default 64 = 4, the LDS-limited residency: one persistent wave of workgroups)
             const int x16 = e ? atoi(e) : 64;
             conv_grid_cap = std::max(1, prop.multiProcessorCount * x16 / 16);
             num_cus = prop.multiProcessorCount;
-            const char* d = getenv("SHM_DCT_GRID_X16");  // tuning knob: DCT workgroups per resident slot, in 1/16ths (16 = one persistent wave of workgroups)
+            const char* d = knob("SHM_DCT_GRID_X16");  // tuning knob: DCT workgroups per resident slot, in 1/16ths (16 = one persistent wave of workgroups)
             dct_grid_x16 = d ? std::max(1, atoi(d)) : (1 << 20);
         }
         {   // the set-up stream outranks the main stream so that its short kernels are not starved by the Step-1 kernel
@@ -759,7 +769,7 @@ struct Solver final : SolverBase {
             // far when lambda * (d_lo - r_hi) > 25 + ln(Amax/Amin): the cluster's terms are below e^-25 ~ 1.4e-11 of the
             // tile's dominant term, so their fp32 rounding (~1e-5 incl. the exponent) stays below 2e-16 of it
             {
-                const char* e = getenv("SHM_CONV_FAR_LOG");  // experiment knob: -ln of the relative size below which a cluster goes to fp32
+                const char* e = knob("SHM_CONV_FAR_LOG");  // experiment knob: -ln of the relative size below which a cluster goes to fp32
                 const double far_log = e ? atof(e) : 25.0;
                 conv_far_gap = (far_log + std::log(std::max(1.0, amax / std::max(amin, 1e-300)))) / lambda;
                 // skipped clusters: a source further than r_hi + gap from the tile contributes less than (A_s / A_near) e^{-lambda gap} of
@@ -768,20 +778,20 @@ struct Solver final : SolverBase {
                 // of the dominant term (eps = 2^-24 / 2^-53: the arithmetic's own rounding unit).  Exact to rounding; bites when the kernel
                 // decays over a small part of the grid (SprayBottle.pc at 1024^3: two thirds of the clusters).
                 const double eps = sizeof(T) == 8 ? 1.1e-16 : 6.0e-8;
-                const char* sk = getenv("SHM_CONV_NO_SKIP");
+                const char* sk = knob("SHM_CONV_NO_SKIP");
                 // sources whose terms, all S of them together, stay below one rounding unit of a tile's dominant term are dropped (round 3: the bound is
                 // S e^-skip, loose by orders of magnitude -- rocker 512^3 fp32 reads the same L_inf against fp64, 5.6e-6, with a budget of 1e-6; until round 3
                 // a further safety factor of 64 sat in it: 470 -> 440 ms on that workload).  SHM_CONV_DROP_BUDGET32: A/B knob for the fp32 solve.
-                const char* db32 = getenv("SHM_CONV_DROP_BUDGET32");
+                const char* db32 = knob("SHM_CONV_DROP_BUDGET32");
                 conv_skip_base = sk ? 3.0e38 : std::log((double)S / (db32 && sizeof(T) == 4 ? atof(db32) : eps));
                 // Tiered fp64 Step 1 (shm_conv_tiered.hip.h; default for SHM_F64): per (wave sub-tile, source), terms below e^-G of the sub-tile's dominant
                 // terms go through packed fp32.  G from the error budget on Y (1e-8, the stage test's bound and a decade inside the
                 // 1e-7 gate on phi): the packed-fp32 tier is measured at <= 5.6e-9 over every data file and grid size; sources whose terms all together stay
                 // below 2e-9 of the dominant term are dropped (SHM_CONV_DROP_BUDGET; max|dY| does not move between 1.6e-13 and 2e-9: tools/tier_robustness.py).
                 // SHM_CONV_EXACT=1: every pair in the reference's fp64 arithmetic (conv_normalize_kernel<double>; Y to 1e-11 of the C oracle).
-                const char* tl = getenv("SHM_CONV_TIER_LOG");
+                const char* tl = knob("SHM_CONV_TIER_LOG");
                 conv_tier_log = tl ? atof(tl) : 8.0;
-                const char* db = getenv("SHM_CONV_DROP_BUDGET");
+                const char* db = knob("SHM_CONV_DROP_BUDGET");
                 conv_tier_skip_base = sk ? 3.0e38 : std::log((double)S / (db ? atof(db) : 2e-9));
                 select_step1_arith(SHM_STEP1_AUTO);
             }
@@ -863,7 +873,7 @@ struct Solver final : SolverBase {
             if (weighted) {
                 std::vector<double> w((size_t)n);
                 step1_plane_weights_host(S, h_pos.data(), h_wn.data(), lambda, n, bbox_min, cell, sizeof(T) == 8 ? SHM_F64 : SHM_F32, conv_tier_log, w.data(),
-                                         sizeof(T) == 4 && getenv("SHM_CONV32_CLASSIC") == nullptr);
+                                         sizeof(T) == 4 && knob("SHM_CONV32_CLASSIC") == nullptr);
                 plan_slabs_weighted(n, total_slabs, w.data(), sizeof(T) == 8 ? 4 : 8, slab_bounds);
             } else {
                 for (int sidx = 0; sidx < total_slabs; sidx++) {
@@ -938,9 +948,9 @@ struct Solver final : SolverBase {
     // shm_opts.step1_arith: the tiered kernel unless the caller (or SHM_CONV_EXACT=1, read per call: tests flip it inside one process) asks for the reference's arithmetic
     void select_step1_arith(int arith) {
         if (arith != SHM_STEP1_AUTO && arith != SHM_STEP1_EXACT_F64) throw Error(SHM_ERR_INVALID, "unknown step1_arith");
-        conv_tiered = sizeof(T) == 8 && arith == SHM_STEP1_AUTO && getenv("SHM_CONV_EXACT") == nullptr && tier_exponent_span_ok();
+        conv_tiered = sizeof(T) == 8 && arith == SHM_STEP1_AUTO && knob("SHM_CONV_EXACT") == nullptr && tier_exponent_span_ok();
         // fp32 handles (round 5): the same kernel with every kept pair in its packed-fp32 body and fp32 output; SHM_CONV32_CLASSIC=1: conv_normalize_kernel<float> (A/B)
-        conv_tiered32 = sizeof(T) == 4 && getenv("SHM_CONV32_CLASSIC") == nullptr && tier_exponent_span_ok();
+        conv_tiered32 = sizeof(T) == 4 && knob("SHM_CONV32_CLASSIC") == nullptr && tier_exponent_span_ok();
     }
     // The tiered kernel's near tier works relative to one power of two per block and inserts a term's own power of two into the exponent field by an integer
     // add (yukawa_near): valid while no evaluated term of a block is more than 2^-990 below the block's scale.  A source that is not dropped lies at most
@@ -959,7 +969,7 @@ struct Solver final : SolverBase {
     // ------------------------------------------------------------------------------------------
     // Steps 1+2
     void launch_conv() {
-        const bool slab_log = getenv("SHM_CONV_SLAB_LOG") != nullptr;
+        const bool slab_log = knob("SHM_CONV_SLAB_LOG") != nullptr;
         Event slab_ev[2];
         unsigned long long slab_pairs_seen[2] = {0, 0};
         for (Slab<T>& sl : slabs) {
@@ -980,14 +990,18 @@ struct Solver final : SolverBase {
             P.S = n_clusters * conv_cluster<T>();
             P.n_clusters = n_clusters;
             P.far_gap = (float)conv_far_gap;
-            P.tier_log = conv_tiered32 ? -1.0e30f : (float)conv_tier_log;   // (fp32 solve: every kept source that stays in the fp32 exponent range is "far")
+            // shm_opts.step1_budget b (default kTierBudget = 1e-8) moves the three thresholds that derive from the budget together: the far threshold G by -ln(b / 1e-8)
+            // (terms e^-G below the dominant one carry the packed-fp32 error eps_far: G = 8 at 1e-8), the a-posteriori test (b / eps_far) and the drop threshold (b / 5)
+            const double budget = step1_budget > 0. ? step1_budget : kTierBudget;
+            const double g_shift = std::log(budget / kTierBudget);
+            P.tier_log = conv_tiered32 ? -1.0e30f : (float)std::max(2.0, conv_tier_log - g_shift);   // (fp32 solve: every kept source that stays in the fp32 exponent range is "far")
             P.wscale = conv_wscale;
             {   // a-posteriori test of the packed-fp32 tier (shm_conv_tiered.hip.h): budget on Y / calibrated relative error of a far term as it shows up in X
-                static const double redo_env = getenv("SHM_CONV_REDO_RATIO") ? atof(getenv("SHM_CONV_REDO_RATIO")) : -1.;   // A/B knob (0: never)
-                const double ratio = redo_env >= 0. ? redo_env : kTierBudget / kTierEpsFar;
+                static const double redo_env = knob("SHM_CONV_REDO_RATIO") ? atof(knob("SHM_CONV_REDO_RATIO")) : -1.;   // A/B knob (0: never)
+                const double ratio = redo_env >= 0. ? redo_env : budget / kTierEpsFar;
                 P.far_redo_ratio = ratio > 0. ? (float)ratio : 3.0e38f;
             }
-            P.skip_base = (float)std::min(conv_tiered ? conv_tier_skip_base : conv_skip_base, 3.0e38);
+            P.skip_base = (float)std::min(conv_tiered ? conv_tier_skip_base - g_shift : conv_skip_base, 3.0e38);
             P.inv_lambda = (float)(1.0 / lambda);
             P.tiles_x = (n + kConvTile - 1) / kConvTile;
             P.tiles_y = P.tiles_x;
@@ -996,7 +1010,7 @@ struct Solver final : SolverBase {
             const bool npt4 = (long long)P.tiles_x * P.tiles_y * ((planes + 15) / 16) >= conv_grid_cap;
             // fp32: 8 nodes per lane on grids large enough, culled as two 16-plane halves (see the kernel); fp64 stays at 4 (8 needs 256 VGPRs: 57 against
             // 44 ms at 256^3).  SHM_CONV_NPT4: A/B knob, and the reference for the bit-identity check of the two shapes (tools/skip_check.py)
-            const bool npt4_env = getenv("SHM_CONV_NPT4") != nullptr;   // (read per launch: the check flips it inside one process)
+            const bool npt4_env = knob("SHM_CONV_NPT4") != nullptr;   // (read per launch: the check flips it inside one process)
             const bool npt8 = sizeof(T) == 4 && !npt4_env && npt4 && (long long)P.tiles_x * P.tiles_y * ((planes + 31) / 32) >= conv_grid_cap;
             const int tile_z = npt8 ? 32 : npt4 ? 16 : 8;
             const double half_z = 0.5 * ((npt8 ? 16 : tile_z) - 1);   // extent of the unit that is culled and carries one exponent offset
@@ -1023,7 +1037,7 @@ struct Solver final : SolverBase {
                 const double conv_est_ms = pairs / (sizeof(T) == 8 ? 1.2e9 : 3.5e9);
                 conv_est_total_ms = (&sl == &slabs[0] ? 0. : conv_est_total_ms) + conv_est_ms;
                 const double setup_est_ms = 2.2e-3 * (double)std::min<int64_t>(S, (int64_t)8 * n * n);
-                static const bool no_reserve = getenv("SHM_CONV_NO_RESERVE") != nullptr;  // A/B knob
+                static const bool no_reserve = knob("SHM_CONV_NO_RESERVE") != nullptr;  // A/B knob
                 if (conv_tiered || conv_tiered32) grid = std::min(grid, resident);   // its waves pull work from a queue: exactly the resident workgroups, nothing left to hand out
                 if (!no_reserve && !o_fast_hint && conv_est_ms < 4.0 * setup_est_ms && grid > resident - resident / 8) grid = resident - resident / 8;
             }
@@ -1033,7 +1047,7 @@ struct Solver final : SolverBase {
             // Only where the tiles cost about the same (the kernel spans the grid: lambda * side < 100, nothing is culled) -- with culling the persistent
             // workgroups of ONE launch balance the uneven tiles, and every extra launch adds an uneven tail (rocker 512^3 fp32, 16 launches: +10 %) -- and
             // where Step 1 is long enough to matter (>= 10 ms); at most 16 chunks (256^3: set-up done at 38 instead of 42.7 ms with 8, Step 1 unchanged).
-            static const int split_env = getenv("SHM_CONV_SPLIT") ? atoi(getenv("SHM_CONV_SPLIT")) : 0;   // A/B knob (1: one launch)
+            static const int split_env = knob("SHM_CONV_SPLIT") ? atoi(knob("SHM_CONV_SPLIT")) : 0;   // A/B knob (1: one launch)
             const bool uniform_tiles = lambda * cell * n < 100.;
             // (The tiered fp64 kernel needs none of this: its grid is exactly the resident workgroups -- nothing left to hand out -- and its 176 registers leave room on
             // every SIMD for a wave of the set-up kernels, which therefore run WHILE Step 1 runs; one launch, balanced by its work queue.)
@@ -1084,7 +1098,7 @@ struct Solver final : SolverBase {
                     return;
                 }
                 // the tiles of a launch are handed out by a queue head (culled workloads: their costs differ severalfold); SHM_CONV_STATIC: static stride (A/B knob)
-                static const bool static_tiles = getenv("SHM_CONV_STATIC") != nullptr;
+                static const bool static_tiles = knob("SHM_CONV_STATIC") != nullptr;
                 unsigned* head = nullptr;
                 if (!static_tiles && conv_launch_index < kMaxConvLaunches) head = d_unit_counters.p + 8 * conv_launch_index++;
                 if constexpr (sizeof(T) == 4) {
@@ -1136,7 +1150,7 @@ struct Solver final : SolverBase {
     }
 
     void launch_div(int scrub) {
-        static const bool classic = getenv("SHM_DIV_CLASSIC") != nullptr;   // A/B knob: the one-node-per-thread kernel of rounds 1-3
+        static const bool classic = knob("SHM_DIV_CLASSIC") != nullptr;   // A/B knob: the one-node-per-thread kernel of rounds 1-3
         for (Slab<T>& sl : slabs) {
             if (classic || vec == 1) {   // (n not a multiple of the vector width: scalar kernel)
                 hipLaunchKernelGGL((divergence_kernel<T>), dim3((unsigned)((n + kBlock - 1) / kBlock), (unsigned)n, (unsigned)sl.nzl), dim3(kBlock), 0, stream, sl.gp,
@@ -1151,7 +1165,7 @@ struct Solver final : SolverBase {
             // planes per workgroup: 4 measured best at 256^3 and 512^3 in both precisions (512^3 fp64: 0.79 ms against 0.84 with 32 and 0.80 with 2 --
             // many short marches keep more loads in flight than few deep ones; the first plane's extra load is a fifth of a march)
             int ZC = 4;
-            static const int zc_env = getenv("SHM_DIV_ZC") ? atoi(getenv("SHM_DIV_ZC")) : 0;   // A/B knob
+            static const int zc_env = knob("SHM_DIV_ZC") ? atoi(knob("SHM_DIV_ZC")) : 0;   // A/B knob
             if (zc_env > 0) ZC = zc_env;
             const unsigned nblk = (unsigned)((long long)xchunks * rowgroups * ((sl.nzl + ZC - 1) / ZC));
             hipLaunchKernelGGL((divergence_march_kernel<T, V>), dim3(nblk), dim3(kBlock), 0, stream, sl.gp, LX, xchunks, rowgroups, ZC, sl.Y0.p, sl.Y1.p, sl.Y2.p,
@@ -1313,7 +1327,7 @@ struct Solver final : SolverBase {
     void build_constraints() {
         hipStream_t stream = stream2;  // everything below runs beside the Step-1 kernel of the main stream
         const auto th0 = std::chrono::steady_clock::now();
-        static const int prio_env = getenv("SHM_SETUP_PRIO") ? atoi(getenv("SHM_SETUP_PRIO")) : -1;   // A/B knob: 0 / 1
+        static const int prio_env = knob("SHM_SETUP_PRIO") ? atoi(knob("SHM_SETUP_PRIO")) : -1;   // A/B knob: 0 / 1
         setup_prio = prio_env >= 0 ? prio_env : (conv_tiered && conv_est_total_ms >= 150. && conv_est_total_ms < 1e29 ? 0 : 1);   // (estimate: 256^3 bunny 40, 512^3 320 / 160 ms)
         auto lap = [&](const char* what) { log("[shm]   setup %-28s %.2f ms", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count()); };
         gs_early = green_table_early_ok();
@@ -1328,15 +1342,17 @@ struct Solver final : SolverBase {
         // Direct dual solve (moderate m, explicit S): S itself is inverted on the set-up stream instead of G, and the dual system is solved with two dense
         // mat-vecs after Step 1 -- no G, no B, no iteration (see solve_dual), and none of the host tables
         // below that only they and the sparse sweeps of the iterative dual solver need (entries sorted by node, node -> rows hash, active tiles).
-        const bool no_direct = getenv("SHM_DUAL_NO_DIRECT") != nullptr;   // A/B knob, read per solve (tests of the iterative path flip it inside one process)
-        static const int direct_max_m = getenv("SHM_DUAL_DIRECT_MAX_M") ? atoi(getenv("SHM_DUAL_DIRECT_MAX_M")) : 4096;   // single-level Gauss-Jordan range
+        // (shm_opts.dual_form -- `dual_form_req` -- overrides the rules below: DIRECT wherever the explicit S fits, or one of the two iterative forms)
+        const bool no_direct = knob("SHM_DUAL_NO_DIRECT") != nullptr || dual_form_req == SHM_DUAL_EXPLICIT_S_CG || dual_form_req == SHM_DUAL_THROUGH_GRID;
+        static const int direct_max_m_env = knob("SHM_DUAL_DIRECT_MAX_M") ? atoi(knob("SHM_DUAL_DIRECT_MAX_M")) : 4096;   // single-level Gauss-Jordan range
+        const int direct_max_m = dual_form_req == SHM_DUAL_DIRECT ? 16384 : direct_max_m_env;
         dual_direct = dual_direct_requested && !no_direct && m <= direct_max_m;
         // Round 4: between 4096 and 16384 rows the direct solve pays exactly where this rank's Step 1 outlasts the inversion of S that runs beside it (measured,
         // tools/r04_ab.py, ms per solve iterative / direct: rocker 128^3 (m = 4 169) 23.9 / 19.8, SprayBottle 128^3 (4 141) 70.2 / 65.3, chair 256^3 (6 340) 58.7 / 57.8,
         // chair 512^3 (7 748) 373.6 / 367.5 -- and rocker 256^3 (9 110) 97.4 / 106.9, SprayBottle 256^3 (12 620) 174 / 221, knot 128^3 (12 155) 55.6 / 96.5).  The
         // line is drawn per problem from an estimate of Step 1 that knows what the tiers drop (estimate_step1_ms_tiered: +-25 % over the data files) and of the
         // set-up on an idle device (assembly 1.4e-7 m^2, inversion 5.5e-11 m^3, the Green's table); beside Step 1 the set-up runs at ~0.4 of that speed.
-        static const bool direct_est_off = getenv("SHM_DUAL_DIRECT_EST_OFF") != nullptr;   // A/B knob: the fixed limit alone
+        static const bool direct_est_off = knob("SHM_DUAL_DIRECT_EST_OFF") != nullptr;   // A/B knob: the fixed limit alone
         if (!dual_direct && dual_direct_requested && !no_direct && !direct_est_off && conv_tiered && total_slabs == 1 && precond_available() && !gemm_dct() && n <= 512 &&
             m > direct_max_m && m <= 16384 && conv_est_total_ms < 1e29) {
             const double md = (double)m;
@@ -1353,7 +1369,7 @@ struct Solver final : SolverBase {
         // After the fp32 Step 1 -- which leaves the set-up's kernels no room: they run in its gaps and after it -- the direct solve's extra set-up (the
         // Green's table: three n^4 products, 10 ms at 512^3; the assembly of S) is paid in full, and at 512^3 it costs more than the iterations it replaces
         // (round 4, tools/r04_ab.py: bunny_small 512^3 fp32 112.8 ms direct / 107.6 iterative, bunny.pc 62.7 / 59.4; at 256^3: 15.8 / 18.5, 128^3: 4.7 / 7.3)
-        static const bool direct_always = getenv("SHM_DUAL_DIRECT_ALWAYS") != nullptr;   // A/B knob
+        const bool direct_always = knob("SHM_DUAL_DIRECT_ALWAYS") != nullptr || dual_form_req == SHM_DUAL_DIRECT;
         // (the all-fp64 kernel at 512^3: 321 direct / 329 iterative -- fp64 iterations cost twice as much, so only the fp32 solve changes)
         if (sizeof(T) == 4 && n >= 512 && !gemm_dct() && !direct_always) dual_direct = false;
         dual_direct = dual_direct && schur_wanted();   // (schur_wanted() reads dual_direct: with it set only the structural conditions remain)
@@ -1431,7 +1447,7 @@ struct Solver final : SolverBase {
         lap("G rows");
         DevArray<uint64_t> d_tidx;  // alive until the final synchronisation below
         DevArray<double> d_tval;
-        static const int tl_min_m = getenv("SHM_TL_MIN_M") ? atoi(getenv("SHM_TL_MIN_M")) : 6144;  // dense inverse up to here (m^2 fp32 = 150 MB: L2 / MALL friendly, 3 launches)
+        static const int tl_min_m = knob("SHM_TL_MIN_M") ? atoi(knob("SHM_TL_MIN_M")) : 6144;  // dense inverse up to here (m^2 fp32 = 150 MB: L2 / MALL friendly, 3 launches)
         tl.on = !dual_direct && m > tl_min_m && build_two_level(gptr, gcol, gval, d_tidx, d_tval);
         std::vector<uint64_t> tidx;  // alive (like d_tidx / d_tval) until the final synchronisation below
         std::vector<double> tval;
@@ -1578,7 +1594,7 @@ struct Solver final : SolverBase {
     bool build_two_level(const std::vector<int>& gptr, const std::vector<int>& gcol, const std::vector<double>& gval, DevArray<uint64_t>& d_tidx,
                          DevArray<double>& d_tval) {
         hipStream_t stream = stream2;
-        static const int box_env = getenv("SHM_TL_BOX") ? atoi(getenv("SHM_TL_BOX")) : 0;
+        static const int box_env = knob("SHM_TL_BOX") ? atoi(knob("SHM_TL_BOX")) : 0;
         const int64_t nn = n, pl = (int64_t)n * n;
         std::vector<int> ci((size_t)m), cj((size_t)m), ck((size_t)m);
         for (int r = 0; r < m; r++) {
@@ -1842,6 +1858,27 @@ struct Solver final : SolverBase {
         }
         const TlBoxes V = tl.view();
         const unsigned grows = (unsigned)((tl.nI + kBlock / kWave - 1) / (kBlock / kWave));
+        static const bool classic_chain = knob("SHM_TL_CLASSIC") != nullptr;   // A/B knob (round 5): the five-launch application of rounds 2-4
+        if (!classic_chain) {
+            // three launches: [t = D^-1 w_I | y = T^T w_I | v_S by the last workgroup], u_S = S^-1 v_S, u_I = t - T u_S
+            if (!tl.ticket.p) {
+                tl.ticket.alloc(1);
+                HIPCHK(hipMemsetAsync(tl.ticket.p, 0, sizeof(unsigned), st));
+            }
+            const unsigned g1 = grows + (unsigned)tl.nChunks;
+            if (f32)
+                hipLaunchKernelGGL((tl_rows_cols_kernel<float>), dim3(g1), dim3(kBlock), 0, st, V, tl.rowBox.p, tl.nI, (int)grows, tl.D32.p, tl.chunkBox.p, tl.chunkCol.p, tl.T32.p, w,
+                                   tl.tbuf.p, tl.ybuf.p, tl.nS, tl.sepRow.p, tl.adj_ptr.p, tl.adj_idx.p, tl.vS.p, tl.ticket.p);
+            else
+                hipLaunchKernelGGL((tl_rows_cols_kernel<double>), dim3(g1), dim3(kBlock), 0, st, V, tl.rowBox.p, tl.nI, (int)grows, tl.D.p, tl.chunkBox.p, tl.chunkCol.p, tl.Tm.p, w,
+                                   tl.tbuf.p, tl.ybuf.p, tl.nS, tl.sepRow.p, tl.adj_ptr.p, tl.adj_idx.p, tl.vS.p, tl.ticket.p);
+            if (f32) hipLaunchKernelGGL(ginv_matvec_kernel<float>, dim3(tl.nS), dim3(kBlock), 0, st, tl.nS, tl.nSp, Ginv32.p, tl.vS.p, tl.uS.p);
+            else hipLaunchKernelGGL(ginv_matvec_kernel<double>, dim3(tl.nS), dim3(kBlock), 0, st, tl.nS, tl.nSp, Ginv.p, tl.vS.p, tl.uS.p);
+            const unsigned gfin = grows + (unsigned)((tl.nS + kBlock - 1) / kBlock);
+            if (f32) hipLaunchKernelGGL((tl_finish_kernel<float>), dim3(gfin), dim3(kBlock), 0, st, V, tl.rowBox.p, tl.nI, tl.nS, tl.sepRow.p, tl.T32.p, tl.tbuf.p, tl.uS.p, u);
+            else hipLaunchKernelGGL((tl_finish_kernel<double>), dim3(gfin), dim3(kBlock), 0, st, V, tl.rowBox.p, tl.nI, tl.nS, tl.sepRow.p, tl.Tm.p, tl.tbuf.p, tl.uS.p, u);
+            return;
+        }
         if (f32) hipLaunchKernelGGL((tl_rows_kernel<float>), dim3(grows), dim3(kBlock), 0, st, V, tl.rowBox.p, tl.nI, tl.D32.p, w, tl.tbuf.p);
         else hipLaunchKernelGGL((tl_rows_kernel<double>), dim3(grows), dim3(kBlock), 0, st, V, tl.rowBox.p, tl.nI, tl.D.p, w, tl.tbuf.p);
         if (tl.nChunks > 0) {
@@ -1864,7 +1901,7 @@ struct Solver final : SolverBase {
     void enqueue_gj_invert(double* M, int mp, bool refined_later = false) {
         hipStream_t stream = stream2;
         const int nb = mp / kGJ;
-        static const int outer_env = getenv("SHM_GJ_OUTER") ? atoi(getenv("SHM_GJ_OUTER")) : 0;   // experiment knob: pivot blocks per outer block
+        static const int outer_env = knob("SHM_GJ_OUTER") ? atoi(knob("SHM_GJ_OUTER")) : 0;   // experiment knob: pivot blocks per outer block
         const int outer = outer_env > 0 ? std::min(outer_env, 8) : (nb >= 64 ? 4 : 1);
         gjP.alloc(kGJ * kGJ);
         gjR.alloc((size_t)outer * kGJ * mp);   // [outer * 64][mp]
@@ -1872,8 +1909,8 @@ struct Solver final : SolverBase {
         gjFlag.alloc(2);
         HIPCHK(hipMemsetAsync(gjFlag.p, 0, sizeof(int), stream));
         const int c_ld = outer * kGJ;
-        static const int pivot_env = getenv("SHM_GJ_PIVOT_E") ? atoi(getenv("SHM_GJ_PIVOT_E")) : 0;
-        const bool classic = getenv("SHM_GJ_CLASSIC") != nullptr;   // A/B knob, read per inversion (a test flips it inside one process): three dependent launches per pivot block (rounds 1-3)
+        static const int pivot_env = knob("SHM_GJ_PIVOT_E") ? atoi(knob("SHM_GJ_PIVOT_E")) : 0;
+        const bool classic = knob("SHM_GJ_CLASSIC") != nullptr;   // A/B knob, read per inversion (a test flips it inside one process): three dependent launches per pivot block (rounds 1-3)
         // one launch per pivot block (gj_step_kernel; it inverts the pivot tiles by the scalar elimination) unless a pivot kernel is asked for explicitly
         const bool stepped = outer == 1 && !classic && pivot_env == 0;
         const int pivot_e = pivot_env ? pivot_env : (refined_later ? 16 : 4);   // 16 = block Gauss-Jordan with 4 x 4 pivot blocks (round 3);   // A/B knob: 4 = 256 threads; 2 = 1024 threads (2 % faster on an idle GPU, but four 40-register waves per SIMD do not fit beside Step 1)
@@ -1936,12 +1973,12 @@ struct Solver final : SolverBase {
     // built (signed_heat_grid_solver.cpp:8-35, `rebuild`) -- but it is cheap enough to be rebuilt with every solve (see prepare_schur); S depends on the
     // sources and is assembled per solve.
     bool schur_wanted() const {
-        static const bool off = getenv("SHM_DUAL_NO_DENSE_S") != nullptr;   // A/B knob: apply S through the grid (five sparse sweeps) as before
+        const bool off = knob("SHM_DUAL_NO_DENSE_S") != nullptr || dual_form_req == SHM_DUAL_THROUGH_GRID;   // apply S through the grid (five sparse sweeps)
         // (beyond ~8000 rows the assembly costs Step 1 more time than the dense mat-vec saves the CG: rocker 512^3 fp32, m = 12 612: 29 ms of assembly for
         // 36 x 0.37 ms -- 493-508 against 491-501 ms per solve with S applied through the grid)
         // (beside the tiered fp64 Step 1 -- where the assembly is co-resident and hidden -- up to 16384 rows since round 4: rocker 512^3 fp64, m = 12 612: solve phase
         // 71.5 -> 35.9 ms, 631 -> 609 ms per solve; after the fp32 Step 1, which leaves the set-up's kernels no room, the same choice costs 401 -> 423 ms)
-        static const int max_m_env = getenv("SHM_DENSE_S_MAX_M") ? atoi(getenv("SHM_DENSE_S_MAX_M")) : 0;
+        static const int max_m_env = knob("SHM_DENSE_S_MAX_M") ? atoi(knob("SHM_DENSE_S_MAX_M")) : 0;
         const int max_m = max_m_env > 0 ? max_m_env : (conv_tiered ? 16384 : 8192);
         // n not a power of two: applying S through the grid costs six dense products per CG iteration (shm_dct_gemm.hip.h: 5 ms at n = 362), so the explicit S
         // is worth its assembly up to the sizes its memory allows, whatever Step 1 hides
@@ -1953,7 +1990,7 @@ struct Solver final : SolverBase {
         // cheap anyway (0.11 ms per iteration at 128^3) and the set-up is the critical path already
         // (the direct dual solve replaces the inversion of G, the host's B rows and the whole iteration by the assembly and the inversion of S: a gain at
         // every size it applies to -- 128^3: 12.1 -> 9.6 ms, 64^3: 4.5 -> 2.7 ms per solve -- so it is not subject to this test)
-        static const bool force = getenv("SHM_DUAL_DENSE_S_ALWAYS") != nullptr;
+        const bool force = knob("SHM_DUAL_DENSE_S_ALWAYS") != nullptr || dual_form_req == SHM_DUAL_EXPLICIT_S_CG || dual_form_req == SHM_DUAL_DIRECT;
         const double schur_est_ms = 2.2e-7 * (double)m * (double)m;
         if (force || dual_direct) return true;
         // CG on the explicit S (no inversion): worth it only where an iteration through the grid costs clearly more than the dense mat-vecs -- which grows with
@@ -1971,15 +2008,16 @@ struct Solver final : SolverBase {
     // its limit), build_constraints() queues this BEFORE the host builds the constraint rows, so the table's kernels (0.9 ms at 256^3, 10 ms at 512^3) run while
     // the host works (1 ms) instead of after it; otherwise prepare_schur() queues it once m is known.
     bool green_table_early_ok() const {
-        static const bool off = getenv("SHM_GREEN_LATE") != nullptr;   // A/B knob
-        static const int direct_max_m = getenv("SHM_DUAL_DIRECT_MAX_M") ? atoi(getenv("SHM_DUAL_DIRECT_MAX_M")) : 4096;
-        return !off && dual_direct_requested && getenv("SHM_DUAL_NO_DIRECT") == nullptr && getenv("SHM_DUAL_NO_DENSE_S") == nullptr && total_slabs == 1 && precond_available() &&
-               !gemm_dct() && n <= 512 && S > 0 && S <= direct_max_m && (sizeof(T) == 8 || n < 512 || getenv("SHM_DUAL_DIRECT_ALWAYS") != nullptr);
+        static const bool off = knob("SHM_GREEN_LATE") != nullptr;   // A/B knob
+        static const int direct_max_m = knob("SHM_DUAL_DIRECT_MAX_M") ? atoi(knob("SHM_DUAL_DIRECT_MAX_M")) : 4096;
+        if (dual_form_req == SHM_DUAL_EXPLICIT_S_CG || dual_form_req == SHM_DUAL_THROUGH_GRID) return false;
+        return !off && dual_direct_requested && knob("SHM_DUAL_NO_DIRECT") == nullptr && knob("SHM_DUAL_NO_DENSE_S") == nullptr && total_slabs == 1 && precond_available() &&
+               !gemm_dct() && n <= 512 && S > 0 && S <= direct_max_m && (sizeof(T) == 8 || n < 512 || knob("SHM_DUAL_DIRECT_ALWAYS") != nullptr || dual_form_req == SHM_DUAL_DIRECT);
     }
     void enqueue_green_table(hipStream_t st) {
         const int P = n + 8;   // leading dimension of the last table index (rows stay 64-byte aligned)
         const size_t n1 = (size_t)n + 1;
-        static const bool keep_table = getenv("SHM_SCHUR_KEEP_TABLE") != nullptr;
+        static const bool keep_table = knob("SHM_SCHUR_KEEP_TABLE") != nullptr;
         if (!keep_table) gs_n = 0;
         if (gs_n == n && gs_cell == cell) return;
         {
@@ -2004,11 +2042,11 @@ struct Solver final : SolverBase {
             hipLaunchKernelGGL(cosine_tables_kernel, dim3(grid_for(n1 * n, 1024)), dim3(kBlock), 0, st, n, P, gs_ctab.p, gs_Cm.p, gs_Ct.p);
             hipLaunchKernelGGL(green_symbol_kernel, dim3((unsigned)std::min(n * n, 8 * num_cus)), dim3(kBlock), 0, st, n, gs_lam.p, W0.p);
             // beside the tiered fp64 Step 1 (two 184-register waves per SIMD) only the narrow shape fits on a SIMD; otherwise the 128 x 128 tiles
-            static const bool gemm_wide_env = getenv("SHM_GREEN_WIDE") != nullptr;   // A/B knob
-            const bool narrow = (conv_tiered || conv_tiered32 || getenv("SHM_GREEN_NARROW") != nullptr) && !gemm_wide_env;
+            static const bool gemm_wide_env = knob("SHM_GREEN_WIDE") != nullptr;   // A/B knob
+            const bool narrow = (conv_tiered || conv_tiered32 || knob("SHM_GREEN_NARROW") != nullptr) && !gemm_wide_env;
             auto tiles = [](size_t v) { return (unsigned)((v + kGemmT - 1) / kGemmT); };
             auto gemm = [&](unsigned batches, int M, int N, int K, const double* A, int lda, long long sA, const double* B, int ldb, long long sB, double* C, int ldc, long long sC) {
-                static const int wn_env = getenv("SHM_GREEN_WN") ? atoi(getenv("SHM_GREEN_WN")) : 0;   // A/B knob (round 5)
+                static const int wn_env = knob("SHM_GREEN_WN") ? atoi(knob("SHM_GREEN_WN")) : 0;   // A/B knob (round 5)
                 if (narrow && wn_env == 2)
                     hipLaunchKernelGGL(dgemm_rm_kernel<2>, dim3((unsigned)((N + 63) / 64), tiles((size_t)M), batches), dim3(kBlock), 0, st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, setup_prio);
                 else if (narrow)
@@ -2159,7 +2197,7 @@ struct Solver final : SolverBase {
         const int xchunks = (per_row + tx - 1) / tx;
         const int yblocks = (n + tyb * kStRY - 1) / (tyb * kStRY);
         // planes per workgroup: as many as possible (less z-halo re-reading) while the grid still has >= ~4 workgroups per CU
-        static const int zc_env = getenv("SHM_STENCIL_ZC") ? atoi(getenv("SHM_STENCIL_ZC")) : 0;
+        static const int zc_env = knob("SHM_STENCIL_ZC") ? atoi(knob("SHM_STENCIL_ZC")) : 0;
         int zc = 16;
         while (zc > 4 && (long long)xchunks * yblocks * ((sl.nzl + zc - 1) / zc) < 1024) zc >>= 1;
         if (zc_env > 0) zc = zc_env;
@@ -2200,7 +2238,7 @@ struct Solver final : SolverBase {
         int wx = 0, ry = 8, zc = 16, yblocks = 0, zchunks = 0, nw = 8, part = 0;
     };
     bool fused_available() const {
-        static const bool off = getenv("SHM_CG_CLASSIC") != nullptr;  // A/B knob: the round-1 four-kernel loop
+        static const bool off = knob("SHM_CG_CLASSIC") != nullptr;  // A/B knob: the round-1 four-kernel loop
         return !off && (n + vec - 1) / vec <= 8 * 64;
     }
     FusedCfg fused_cfg(const Slab<T>& sl) const {
@@ -2211,13 +2249,13 @@ struct Solver final : SolverBase {
         // waves per workgroup: 8 (two 512-thread workgroups per CU, out of phase), 16 where a row needs 4 or more waves side by side -- with 8 the
         // workgroup would own only 4 rows (wx = 4) or 2 (wx = 8) and re-read as many border rows from L2 as it owns: 512^3 fp64 (wx = 4), 8 -> 16 waves:
         // DIR 5.33 -> 5.60 TB/s, RES 5.57 -> 5.88, 1.558 -> 1.50 ms per iteration; where wy is already >= 4 (256^3, 512^3 fp32) 16 waves are no better
-        static const int nw_env = getenv("SHM_FUSED_WAVES") ? atoi(getenv("SHM_FUSED_WAVES")) : 0;  // A/B knob: 4, 8 or 16 waves per workgroup
-        static const int ry_env = getenv("SHM_FUSED_RY") ? atoi(getenv("SHM_FUSED_RY")) : 0;
+        static const int nw_env = knob("SHM_FUSED_WAVES") ? atoi(knob("SHM_FUSED_WAVES")) : 0;  // A/B knob: 4, 8 or 16 waves per workgroup
+        static const int ry_env = knob("SHM_FUSED_RY") ? atoi(knob("SHM_FUSED_RY")) : 0;
         c.ry = (vec == 1) ? 4 : 2;
         if (ry_env == 4 || (ry_env == 2 && vec != 1)) c.ry = ry_env;   // (1 row per lane measured no better than 2)
         c.nw = (nw_env == 4 && c.wx <= 4) ? 4 : (c.ry <= 2 && (nw_env == 16 || (nw_env == 0 && c.wx >= 4))) ? 16 : 8;   // (16-wave kernels exist for <= 2 rows per lane)
         const int wy = c.nw / c.wx;
-        static const int zc_env = getenv("SHM_FUSED_ZC") ? atoi(getenv("SHM_FUSED_ZC")) : 0;
+        static const int zc_env = knob("SHM_FUSED_ZC") ? atoi(knob("SHM_FUSED_ZC")) : 0;
         // rows per workgroup wy * ry: 8 rows per lane unless that leaves too few workgroups along y to fill the chip with deep z chunks
         // rows per lane.  The bordering rows / planes a workgroup re-reads are served by L2 (PMC: HBM traffic of both sweeps = 3.0 N T, the
         // algorithmic figure), so small row blocks cost nothing in HBM bytes and what matters is memory-level parallelism: 2 rows per lane keep
@@ -2308,7 +2346,8 @@ struct Solver final : SolverBase {
         }
         if (!st) allreduce(0, 1 + m);
         for (Slab<T>& sl : slabs) {
-            apply_Ginv(sl.red.p + 1, sl.u.p, false, stream);
+            static const bool proj_f32 = knob("SHM_PROJ_F32") != nullptr;   // experiment (round 5): the fp32 solve's projector with the fp32 copies of the matrices
+            apply_Ginv(sl.red.p + 1, sl.u.p, proj_f32 && sizeof(T) == 4, stream);
             const int nred = std::max(1, std::min(16, m / 1024));   // workgroups of the u.w reduction (one per ~1000 rows)
             if (!sl.proj_ticket.p) {
                 sl.proj_ticket.alloc(1);
@@ -2441,7 +2480,7 @@ struct Solver final : SolverBase {
         // Prefetching variant of the dense sweeps (shm_dct.hip.h, PF: the next tile's loads in flight under this tile's FFT): measured SLOWER than two or three
         // plain workgroups per CU out of phase -- 512^3 fp64 0.466 -> 0.449 of the HBM peak, fp32 0.447 -> 0.390 (the 16-32 registers of the prefetch cost a
         // workgroup of occupancy in three of the five sweeps; profiles/r04_dct_prefetch_rejected.txt) -- so it is compiled only into -DSHM_DCT_PF A/B builds
-        static const bool no_pf = getenv("SHM_DCT_NO_PF") != nullptr;
+        static const bool no_pf = knob("SHM_DCT_NO_PF") != nullptr;
 #ifdef SHM_DCT_PF
         constexpr bool kCanPf = LOG2N >= 9 && !SEG;
 #else
@@ -2462,7 +2501,7 @@ struct Solver final : SolverBase {
         DctParams Q = P;
         Q.ntiles = ntiles;
 #ifdef SHM_EXPERIMENT_KNOBS
-        { static const int dbg = getenv("SHM_DCT_SKIP") ? atoi(getenv("SHM_DCT_SKIP")) : 0; Q.debug_skip = dbg; }
+        { static const int dbg = knob("SHM_DCT_SKIP") ? atoi(knob("SHM_DCT_SKIP")) : 0; Q.debug_skip = dbg; }
 #else
         Q.debug_skip = 0;
 #endif
@@ -2736,7 +2775,7 @@ struct Solver final : SolverBase {
         Q.out = Q.in;
         // the recursive z step wins from n = 256 on (256^3: 79 -> 42 us, 512^3: 0.61 -> 0.09 ms per application); below that the transform of
         // all lines is cheaper than one more launch.  SHM_DUAL_Z_FFT: A/B knob for the transform version
-        static const bool fft_z_env = getenv("SHM_DUAL_Z_FFT") != nullptr;
+        static const bool fft_z_env = knob("SHM_DUAL_Z_FFT") != nullptr;
         const bool fft_z = fft_z_env || n < 256;
         if (fft_z) launch_dct<DCT_FUSED, TP, TP, false, false>(Q, tiles_all, sl.S2.p, sl.W1.p, (const TP*)nullptr, nullptr, nullptr, sl.act_z.p);
         else {
@@ -2797,7 +2836,7 @@ struct Solver final : SolverBase {
             HIPCHK(hipMemsetAsync(sl.p.p, 0, sl.ntot * sizeof(T), stream));  // w = A^T nu lives in p: zero outside the touched nodes
         }
         // ---- r = Pm(g - S mu), z, p
-        const bool sparse_ok = total_slabs == 1 && slabs[0].n_act_x > 0 && !getenv("SHM_DENSE_DCT");
+        const bool sparse_ok = total_slabs == 1 && slabs[0].n_act_x > 0 && !knob("SHM_DENSE_DCT");
         const bool dense_S = have_S && total_slabs == 1 && !comm;   // explicit S (shm_schur.hip.h): one dense mat-vec instead of scatter, five sweeps, gather
         auto apply_S = [&](int vec) {   // red[1..m] = S v
             Slab<T>& sl = slabs[0];
@@ -2886,7 +2925,7 @@ struct Solver final : SolverBase {
             rr0 = h_pinned[SC_RR0];
             rr = h_pinned[SC_RR];
 #ifdef SHM_EXPERIMENT_KNOBS
-            static const int force_iters = getenv("SHM_DUAL_FORCE_ITERS") ? atoi(getenv("SHM_DUAL_FORCE_ITERS")) : 0;  // timing experiments only
+            static const int force_iters = knob("SHM_DUAL_FORCE_ITERS") ? atoi(knob("SHM_DUAL_FORCE_ITERS")) : 0;  // timing experiments only
 #else
             const int force_iters = 0;
 #endif
@@ -2970,6 +3009,7 @@ struct Solver final : SolverBase {
         F.conv_tiered = conv_tiered || conv_tiered32;               // ... and beside WHICH Step-1 kernel it runs: the tiered one leaves room only for the narrow GEMM shape (round 4: the
                                                    // whole-grid solver never learnt this and queued the 256-register shape, which waits for Step 1's persistent waves to end)
         F.dual_direct_requested = true;
+        F.dual_form_req = dual_form_req;
         F.build_constraints();
         F.dual_direct_requested = false;  // on the whole-grid solver's set-up stream: overlaps this rank's Step-1 kernel
         c_s2b.record(F.stream2);
@@ -3054,7 +3094,7 @@ struct Solver final : SolverBase {
         // With a communicator (several processes) the overlap is OPT-IN (SHM_HALO_OVERLAP=1) until it has run on real multi-rank RCCL: it relies on RCCL
         // serialising the send/recv of stream_h against the all-reduces the same communicator issues on `stream`, which only the librccl double and the
         // loop-back transport (several slabs in one process: device copies) have exercised so far.  Read per solve: the tests flip it inside one process.
-        const bool halo_serial = getenv("SHM_HALO_SERIAL") != nullptr || (comm != nullptr && getenv("SHM_HALO_OVERLAP") == nullptr);
+        const bool halo_serial = knob("SHM_HALO_SERIAL") != nullptr || (comm != nullptr && knob("SHM_HALO_OVERLAP") == nullptr);
         bool overlap = total_slabs > 1 && !halo_serial;
         for (Slab<T>& sl : slabs) overlap = overlap && fused_cfg(sl).zchunks >= 3;
         if (overlap && !stream_h) HIPCHK(hipStreamCreateWithFlags(&stream_h, hipStreamNonBlocking));
@@ -3094,7 +3134,7 @@ struct Solver final : SolverBase {
         if (st) for (int a = 0; a < kEvPer * kMaxSamples; a++) ev.emplace_back(new Event());
         int nsamples = 0;
         const int sample_stride = pre ? 2 : 8;
-        static const bool no_xoverlap = getenv("SHM_CG_NO_XOVERLAP") != nullptr;   // A/B knob
+        static const bool no_xoverlap = knob("SHM_CG_NO_XOVERLAP") != nullptr;   // A/B knob
         // (512^3, same box: rocker fp64 0.706 -> 0.717, fp32 0.680 -> 0.691 of the roofline, bunny fp64 0.720 -> 0.725, fp32 0.710 -> 0.722; profiles/r04_projection.txt)
         const bool xoverlap = !no_xoverlap && total_slabs == 1 && !comm;
         Event e_xfork, e_xjoin;
@@ -3249,8 +3289,18 @@ struct Solver final : SolverBase {
 
         Event e_start, e_conv, e_div, e_setup, e_pcg, e_end, e_s2a, e_s2b;
         const auto wall0 = std::chrono::steady_clock::now();
+        if (o.dual_form < SHM_DUAL_AUTO || o.dual_form > SHM_DUAL_THROUGH_GRID) throw Error(SHM_ERR_INVALID, "unknown dual_form");
+        if (o.step1_budget != 0. && !(o.step1_budget >= 1e-12 && o.step1_budget <= 1e-3)) throw Error(SHM_ERR_INVALID, "step1_budget must lie in [1e-12, 1e-3] (0: default 1e-8)");
+        dual_form_req = o.dual_form;
+        step1_budget = o.step1_budget;
         select_step1_arith(o.step1_arith);
         e_start.record(stream);
+        // the arrival counters of the projection's ticketed reductions are "zero between launches" by the last workgroup's reset: a launch cut short (a fault) would
+        // leave them non-zero for the rest of the process, so every solve starts from zero.  Projections on the two streams share these counters and the
+        // partial-sum scratch: they are event-serialised (fork / join around the x update), never concurrent.
+        for (Slab<T>& sl : slabs)
+            if (sl.proj_ticket.p) HIPCHK(hipMemsetAsync(sl.proj_ticket.p, 0, sizeof(unsigned), stream));
+        if (tl.ticket.p) HIPCHK(hipMemsetAsync(tl.ticket.p, 0, sizeof(unsigned), stream));
         o_fast_hint = o.fast_integration != 0;
         launch_conv();
         e_conv.record(stream);
@@ -3264,7 +3314,7 @@ struct Solver final : SolverBase {
             solve_gathered(o, st, e_start, e_conv, e_div, wall0);
             return;
         }
-        static const bool setup_alone = getenv("SHM_SETUP_ALONE") != nullptr;  // measurement knob: wait for Step 1 first, so that shm_stats.ms_setup is
+        static const bool setup_alone = knob("SHM_SETUP_ALONE") != nullptr;  // measurement knob: wait for Step 1 first, so that shm_stats.ms_setup is
         if (setup_alone) HIPCHK(hipStreamSynchronize(stream));                  // the set-up's time on an otherwise idle GPU (tools/scaling_model.py)
         e_s2a.record(stream2);
         dual_direct_requested = (o.solver == SHM_SOLVER_DUAL || (o.solver == SHM_SOLVER_AUTO && o.preconditioner != SHM_PRECOND_NONE)) && precond_available() && !comm;
@@ -3694,10 +3744,10 @@ shm_status shm_step1_plane_weights(const shm_sources* src, const shm_grid* grid,
     if (!src || !grid || !weights || src->S <= 0 || !src->pos || !src->wnormal || grid->n < 1 || !(grid->cell > 0.) || !(src->lambda > 0.) ||
         (precision != SHM_F64 && precision != SHM_F32))
         return SHM_ERR_INVALID;
-    const char* tl = getenv("SHM_CONV_TIER_LOG");
+    const char* tl = shm::knob("SHM_CONV_TIER_LOG");
     try {
         shm::step1_plane_weights_host(src->S, src->pos, src->wnormal, src->lambda, grid->n, grid->bbox_min, grid->cell, precision, tl ? atof(tl) : 8.0, weights,
-                                      precision == SHM_F32 && getenv("SHM_CONV32_CLASSIC") == nullptr);
+                                      precision == SHM_F32 && shm::knob("SHM_CONV32_CLASSIC") == nullptr);
     } catch (const std::bad_alloc&) {
         return SHM_ERR_NOMEM;
     } catch (...) {

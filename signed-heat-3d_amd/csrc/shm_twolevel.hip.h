@@ -138,6 +138,59 @@ __global__ __launch_bounds__(kBlock) void tl_cols_kernel(TlBoxes B, const int* _
     if (wave == 0 && l < c) ybuf[c0 + l] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
 
+// Steps 1a + 1b + 2 in ONE launch (round 5; the projection of the stencil CG is a chain of short dependent launches, each worth 5-10 us beside a 0.28 ms sweep):
+//   workgroups [0, grows):                t = D_a^-1 w_I, a wave per interior row (tl_rows_kernel's body);
+//   workgroups [grows, grows + nChunks):  y = T_a^T w_I = E_a^T D_a^-1 w_I  (D_a is symmetric, T_a = D_a^-1 E_a is stored for step 4) -- from w, not from t, so the two
+//                                         parts do not depend on each other (tl_cols_kernel's body with T for E);
+//   the last workgroup to finish:         v_S = w_S - sum of the y of the boxes that border the row (tl_gather_sep_kernel's body).
+// `ticket` is zero between launches (the last workgroup resets it; the solver also clears it when a solve starts).
+template <typename TM>
+__global__ __launch_bounds__(kBlock) void tl_rows_cols_kernel(TlBoxes B, const int* __restrict__ rowBox, int nI, int grows, const TM* __restrict__ Dinv, const int* __restrict__ chunkBox,
+                                                              const int* __restrict__ chunkCol, const TM* __restrict__ Tm, const double* __restrict__ w, double* __restrict__ tbuf,
+                                                              double* __restrict__ ybuf, int nS, const int* __restrict__ sepRow, const int* __restrict__ adj_ptr,
+                                                              const int* __restrict__ adj_idx, double* __restrict__ vS, unsigned* __restrict__ ticket) {
+    __shared__ double part[kBlock / kWave][kWave];
+    __shared__ unsigned last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((int)blockIdx.x < grows) {
+        const int i = blockIdx.x * (kBlock / kWave) + wave;
+        if (i < nI) {
+            const int a = rowBox[i], i0 = B.ptrI[a], s = B.ptrI[a + 1] - i0;
+            const TM* Di = Dinv + B.offD[a] + (size_t)(i - i0) * tl_ld(s);
+            const int* rows = B.rowsI + i0;
+            double acc = 0.;
+            for (int j = lane; j < s; j += kWave) acc += (double)Di[j] * w[rows[j]];
+            acc = wave_sum(acc);
+            if (lane == 0) tbuf[i] = acc;
+        }
+    } else {
+        const int ch = (int)blockIdx.x - grows;
+        const int a = chunkBox[ch];
+        const int i0 = B.ptrI[a], s = B.ptrI[a + 1] - i0, c0 = B.ptrS[a], c = B.ptrS[a + 1] - c0;
+        const int l = chunkCol[ch] + lane;
+        const TM* Ta = Tm + B.offE[a];
+        const int* rows = B.rowsI + i0;
+        double acc = 0.;
+        if (l < c)
+            for (int i = wave; i < s; i += kBlock / kWave) acc += (double)Ta[(size_t)i * c + l] * w[rows[i]];
+        part[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0 && l < c) ybuf[c0 + l] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1u;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    for (int g = threadIdx.x; g < nS; g += kBlock) {
+        double v = w[sepRow[g]];
+        for (int e = adj_ptr[g]; e < adj_ptr[g + 1]; e++) v -= __builtin_nontemporal_load(ybuf + adj_idx[e]);
+        vS[g] = v;
+    }
+    if (threadIdx.x == 0) *ticket = 0u;
+}
+
 // step 2: v_S = w_S - E^T t, gathered per separator row from the boxes that border it (fixed order); the padded tail stays 0
 __global__ __launch_bounds__(kBlock) void tl_gather_sep_kernel(int nS, const int* __restrict__ sepRow, const int* __restrict__ adj_ptr, const int* __restrict__ adj_idx,
                                                                const double* __restrict__ w, const double* __restrict__ ybuf, double* __restrict__ vS) {

@@ -44,7 +44,8 @@ class _Grid(C.Structure):
 
 class _Opts(C.Structure):
     _fields_ = [("fast_integration", C.c_int32), ("scrub_nonfinite", C.c_int32), ("tol", C.c_double), ("max_iters", C.c_int32),
-                ("check_every", C.c_int32), ("preconditioner", C.c_int32), ("solver", C.c_int32), ("step1_arith", C.c_int32)]
+                ("check_every", C.c_int32), ("preconditioner", C.c_int32), ("solver", C.c_int32), ("step1_arith", C.c_int32),
+                ("dual_form", C.c_int32), ("step1_budget", C.c_double)]
 
 
 class ShmStats(C.Structure):
@@ -207,8 +208,12 @@ class GridSolver:
 
     STEP1 = {"auto": 0, "exact_f64": 1}
 
-    def solve(self, tol=0.0, max_iters=0, check_every=0, scrub=True, fast=False, allow_noconv=False, precond="auto", solver="auto", step1="auto"):
-        o = _Opts(int(fast), int(scrub), float(tol), int(max_iters), int(check_every), self.PRECOND[precond], self.SOLVER[solver], self.STEP1[step1])
+    DUAL_FORM = {"auto": 0, "direct": 1, "explicit_s_cg": 2, "through_grid": 3}
+
+    def solve(self, tol=0.0, max_iters=0, check_every=0, scrub=True, fast=False, allow_noconv=False, precond="auto", solver="auto", step1="auto",
+              dual_form="auto", step1_budget=0.0):
+        o = _Opts(int(fast), int(scrub), float(tol), int(max_iters), int(check_every), self.PRECOND[precond], self.SOLVER[solver], self.STEP1[step1],
+                  self.DUAL_FORM[dual_form], float(step1_budget))
         st = ShmStats()
         self._chk(self._lib.shm_grid_solve(self._h, C.byref(o), C.byref(st)), allow=(5,) if allow_noconv else ())
         return st

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol(shm):
     assert declared == set(ABI_SYMBOLS), declared ^ set(ABI_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.shm_grid_abi_version() == 4
+    assert lib.shm_grid_abi_version() == 5
 
 
 def test_no_cpu_fallback(shm):
@@ -42,6 +42,18 @@ def test_stats_struct_layout_matches_header(shm):
     fields = re.findall(r"\b(?:int32_t|int64_t|double)\s+([\w, ]+);", body)
     names = [n.strip() for f in fields for n in f.split(",")]
     assert names == [n for n, _ in shm.ShmStats._fields_]
+
+
+def test_opts_struct_layout_matches_header(shm):
+    """ctypes mirror of shm_opts: same fields, same order, same types as the C struct (ABI 5: dual_form, step1_budget at the end)."""
+    import ctypes as C
+    from signed_heat_3d_amd.grid_abi import _Opts
+    header = open(os.path.join(ROOT, "include", "shm_grid.h")).read()
+    body = header[header.index("typedef struct {\n    int32_t fast_integration;"):header.index("} shm_opts;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    decl = re.findall(r"\b(int32_t|int64_t|double)\s+(\w+);", body)
+    ctype = {"int32_t": C.c_int32, "int64_t": C.c_int64, "double": C.c_double}
+    assert [(n, ctype[t]) for t, n in decl] == list(_Opts._fields_)
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 7, 8])

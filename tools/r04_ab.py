@@ -28,5 +28,5 @@ for a in sys.argv[2:]:
     settings.append((name, dict(e.split("=", 1) for e in envs.split(";") if e)))
 for f, hc, prec in cases:
     for name, env in settings:
-        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", f, hc, prec, name], env=dict(os.environ, **env), capture_output=True, text=True)
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", f, hc, prec, name], env=dict(os.environ, SHM_DEBUG_KNOBS="1", **env), capture_output=True, text=True)
         print(p.stdout.strip() or p.stderr[-300:], flush=True)
