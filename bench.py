@@ -142,12 +142,14 @@ def kernel_table(avg, n_local, T, world, gathered):
     has_pre = int(avg["preconditioner"]) == 2
     is_dual = int(avg["solver"]) in (2, 3)
     TP = T  # the preconditioner sweeps run in the solve precision
-    if int(avg.get("cg_form", 0)) == 1:
+    if int(avg.get("cg_form", 0)) in (1, 4):
         # fused sweeps (shm_cg_fused.hip.h): q = Kp is never stored, x is updated every other iteration: 3 + 3 + 4/2 = 8NT per iteration
+        # (cg_form 4: x on half the grid in every iteration, beside the projection: 2NT per launch)
+        half = int(avg.get("cg_form", 0)) == 4
         kernels = {
             "cg_fused_kernel<DIR>": (3 * n_local * T, avg["ms_stencil_avg"], 1),      # reads z, p; writes p'; partial p'.Kp'
             "cg_fused_kernel<RES>": (3 * n_local * T, avg["ms_update_xr_avg"], 1),    # reads r, p'; writes r; partial ||r||^2
-            "cg_x_update2_kernel": (4 * n_local * T, avg["ms_update_p_avg"], 0.5),    # reads x, p_a, p_b; writes x; every other iteration
+            "cg_x_update2_kernel": ((2 if half else 4) * n_local * T, avg["ms_update_p_avg"], 1 if half else 0.5),    # reads x, p_a, p_b; writes x
         }
     else:
         kernels = {

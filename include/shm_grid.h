@@ -173,7 +173,8 @@ typedef struct {
                                * PRIMAL: 0: four N-sized kernels per iteration (11NT; the per-kernel fields above mean what they say).
                                * 1: fused sweeps (8NT): ms_stencil_avg = DIR sweep (p' = -z + beta p, partial p'.Kp'; 3NT),
                                *    ms_update_xr_avg = RES sweep (r += alpha K p', partial ||r||^2; 3NT),
-                               *    ms_update_p_avg = x += a0 p0 + a1 p1 (4NT per launch, launched every other iteration) */
+                               *    ms_update_p_avg = x += a0 p0 + a1 p1 (4NT per launch, launched every other iteration)
+                               * 4: as 1, but x is updated on half the grid in every iteration (2NT per launch), beside the projection (one GPU, no preconditioner; round 5) */
     double pairs_fp64;        /* (node, source) pairs Step 1 actually evaluated on this rank in the last solve, in fp64 arithmetic ... */
     double pairs_fp32;        /* ... and in (packed) fp32: the tiers of shm_conv_tiered.hip.h; culled / dropped pairs are in neither.
                                * Nominal work is N*S; the Step-1 roofline fraction is computed from these, not from N*S. */

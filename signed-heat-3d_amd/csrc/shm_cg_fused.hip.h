@@ -79,7 +79,9 @@ __global__ __launch_bounds__(WX* WY * 64) void cg_fused_kernel(FusedParams F, do
                                                                int alpha_slot,
                                                                const T* __restrict__ zsrc /* DIR: z */, const T* __restrict__ pin /* DIR: p ; RES: p' */,
                                                                T* __restrict__ pout /* DIR: p' */, T* __restrict__ rio /* RES: r, in place */,
-                                                               double* __restrict__ partials) {
+                                                               double* __restrict__ partials,
+                                                               const double* __restrict__ pq_partials /* RES, pq_np > 0: the block partials of p'.Kp' the DIR sweep left */,
+                                                               int pq_np) {
     constexpr int NW = WX * WY;
     constexpr int RYB = WY * RY;
     // rows exchanged between waves, per parity: slot w = first / last row of wave w; slots NW + wx = the two rows bordering the
@@ -114,7 +116,22 @@ __global__ __launch_bounds__(WX* WY * 64) void cg_fused_kernel(FusedParams F, do
         }
     } else {
         const double rho_cur = sc[slot_old];
-        const double a = rho_cur == 0. ? 0. : rho_cur / *pq;  // rho == 0: already solved (no 0/0)
+        // p'.Kp': either finished by finalize_sum_kernel (*pq), or -- one GPU, round 5 -- summed here by every workgroup from the DIR sweep's block partials, in
+        // finalize_sum_kernel's order (one short dependent launch less per iteration; the partials live in an array of their own: this sweep writes `partials`)
+        double pqv;
+        if (pq_np > 0) {
+            __shared__ double pq_s;
+            double s = 0.;
+            for (int a = tid; a < pq_np; a += NW * 64) s += pq_partials[a];
+            s = block_sum(s, red);
+            if (tid == 0) pq_s = s;
+            __syncthreads();
+            pqv = pq_s;
+            __syncthreads();   // (red is used again at the end of the sweep)
+        } else {
+            pqv = *pq;
+        }
+        const double a = rho_cur == 0. ? 0. : rho_cur / pqv;  // rho == 0: already solved (no 0/0)
         alpha = (T)a;
         if (blockIdx.x == 0 && tid == 0) sc[alpha_slot] = a;  // consumed by cg_x_update2_kernel
     }

@@ -452,7 +452,7 @@ struct Slab {
     int k0 = 0, k1 = 0, nzl = 0;  // owned global planes [k0,k1)
     size_t plane = 0, nown = 0, ntot = 0;
     DevArray<T> Y0, Y1, Y2, r /* also divYt */, x, p, q /* also phi */, z /* preconditioned residual (DCT path only) */;
-    DevArray<double> partials, red /* [1+m] */, pq /* [1] */, u /* [m] */, sc;
+    DevArray<double> partials, pq_partials /* block partials of p'.Kp' when the RES sweep sums them itself */, red /* [1+m] */, pq /* [1] */, u /* [m] */, sc;
     DevArray<unsigned> proj_ticket;   // arrival counter of the projection's u.w reduction (scatter_nodes_kernel)
     // constraint pieces restricted to owned nodes
     DevArray<int> row_ptr, ent_row, node_ptr;
@@ -497,6 +497,8 @@ struct Solver final : SolverBase {
     int n_clusters_t = 0;
     bool conv_tiered = false;                                  // fp64 only; SHM_CONV_EXACT=1 selects the all-fp64 kernel
     bool conv_tiered32 = false;                                // fp32 handles: Step 1 through the tiered kernel's packed-fp32 body
+    bool fold_pq = false;                                      // fused stencil CG on one GPU: the RES sweep sums the DIR sweep's partials of p'.Kp' itself
+    int fold_pq_np = 0;
     int dual_form_req = SHM_DUAL_AUTO;                         // shm_opts.dual_form of the solve in progress
     double step1_budget = 0.;                                  // shm_opts.step1_budget of the solve in progress (<= 0: kTierBudget)
     DevArray<unsigned long long> d_pair_counters;              // [0] fp64 pairs, [1] fp32 pairs evaluated by the last Step 1, [2] pairs evaluated again in fp64 (a-posteriori test)
@@ -539,7 +541,6 @@ struct Solver final : SolverBase {
         DevArray<size_t> offD, offE;
         DevArray<double> D, E, Tm, tbuf, ybuf, vS, uS;
         DevArray<float> D32, E32, T32;
-        DevArray<unsigned> ticket;   // arrival counter of tl_rows_cols_kernel (zero between launches)
         int colour_ptr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         size_t szD = 0, szE = 0;
         TlBoxes view() const { return TlBoxes{ptrI.p, ptrS.p, offD.p, offE.p, rowsI.p, colsS.p}; }
@@ -1318,7 +1319,8 @@ struct Solver final : SolverBase {
         const double f_near = (double)c_near / sampled, f_keep = (double)c_keep / sampled;
         double nodes = 0.;
         for (const Slab<T>& sl : slabs) nodes += (double)sl.nown;
-        return nodes * (double)S * (1.14e-9 * f_near + 1.56e-10 * (f_keep - f_near) + 3.3e-12);   // (per-pair costs of the round-5 kernel: 256^3 bunny 24 ms alone)
+        // (per-pair costs of the round-4 kernel; the round-5 one is ~7 % faster, but the 0.38 of the rule that reads this estimate was drawn with these constants)
+        return nodes * (double)S * (1.229e-9 * f_near + 1.84e-10 * (f_keep - f_near) + 3.3e-12);
     }
 
     // Per-slab CSR pieces, shift items, G = A A^T (sparse triplets -> dense on device -> inverted) and B = A K A^T.
@@ -1858,22 +1860,27 @@ struct Solver final : SolverBase {
         }
         const TlBoxes V = tl.view();
         const unsigned grows = (unsigned)((tl.nI + kBlock / kWave - 1) / (kBlock / kWave));
-        static const bool classic_chain = knob("SHM_TL_CLASSIC") != nullptr;   // A/B knob (round 5): the five-launch application of rounds 2-4
-        if (!classic_chain) {
-            // three launches: [t = D^-1 w_I | y = T^T w_I | v_S by the last workgroup], u_S = S^-1 v_S, u_I = t - T u_S
-            if (!tl.ticket.p) {
-                tl.ticket.alloc(1);
-                HIPCHK(hipMemsetAsync(tl.ticket.p, 0, sizeof(unsigned), st));
-            }
+        // Round 5 measured two shorter chains against the five launches below (rocker.obj 512^3, plain stencil CG, one box, profiles/r05_projection.txt):
+        //   [t | y = T^T w | v_S by the last workgroup to arrive], S^-1, finish:  0.081 -> 0.266 ms per projection (the device-scope fence every workgroup needs before
+        //                                                                          it takes its ticket writes the L2 back each time);
+        //   [t | y = T^T w], S^-1 mat-vec gathering v_S itself (8 rows per workgroup), finish (SHM_TL_MERGED3=1):  0.079 -> 0.095 ms, loop 0.693 -> 0.680 of the roofline.
+        // The launches are short because they are narrow, not because they are many: fewer of them did not pay.  Five it stays.
+        static const bool merged3 = knob("SHM_TL_MERGED3") != nullptr;
+        if (merged3 && (size_t)tl.nSp * sizeof(double) <= 60 * 1024) {
+            // three launches: [t = D^-1 w_I | y = T^T w_I], u_S = S^-1 (w_S - gathered y), u_I = t - T u_S
             const unsigned g1 = grows + (unsigned)tl.nChunks;
             if (f32)
                 hipLaunchKernelGGL((tl_rows_cols_kernel<float>), dim3(g1), dim3(kBlock), 0, st, V, tl.rowBox.p, tl.nI, (int)grows, tl.D32.p, tl.chunkBox.p, tl.chunkCol.p, tl.T32.p, w,
-                                   tl.tbuf.p, tl.ybuf.p, tl.nS, tl.sepRow.p, tl.adj_ptr.p, tl.adj_idx.p, tl.vS.p, tl.ticket.p);
+                                   tl.tbuf.p, tl.ybuf.p);
             else
                 hipLaunchKernelGGL((tl_rows_cols_kernel<double>), dim3(g1), dim3(kBlock), 0, st, V, tl.rowBox.p, tl.nI, (int)grows, tl.D.p, tl.chunkBox.p, tl.chunkCol.p, tl.Tm.p, w,
-                                   tl.tbuf.p, tl.ybuf.p, tl.nS, tl.sepRow.p, tl.adj_ptr.p, tl.adj_idx.p, tl.vS.p, tl.ticket.p);
-            if (f32) hipLaunchKernelGGL(ginv_matvec_kernel<float>, dim3(tl.nS), dim3(kBlock), 0, st, tl.nS, tl.nSp, Ginv32.p, tl.vS.p, tl.uS.p);
-            else hipLaunchKernelGGL(ginv_matvec_kernel<double>, dim3(tl.nS), dim3(kBlock), 0, st, tl.nS, tl.nSp, Ginv.p, tl.vS.p, tl.uS.p);
+                                   tl.tbuf.p, tl.ybuf.p);
+            const unsigned g2 = (unsigned)((tl.nS + kTlSepRows - 1) / kTlSepRows);
+            const size_t lds = (size_t)tl.nSp * sizeof(double);
+            if (f32)
+                hipLaunchKernelGGL((tl_sep_matvec_kernel<float>), dim3(g2), dim3(kBlock), lds, st, tl.nS, tl.nSp, Ginv32.p, tl.sepRow.p, tl.adj_ptr.p, tl.adj_idx.p, w, tl.ybuf.p, tl.uS.p);
+            else
+                hipLaunchKernelGGL((tl_sep_matvec_kernel<double>), dim3(g2), dim3(kBlock), lds, st, tl.nS, tl.nSp, Ginv.p, tl.sepRow.p, tl.adj_ptr.p, tl.adj_idx.p, w, tl.ybuf.p, tl.uS.p);
             const unsigned gfin = grows + (unsigned)((tl.nS + kBlock - 1) / kBlock);
             if (f32) hipLaunchKernelGGL((tl_finish_kernel<float>), dim3(gfin), dim3(kBlock), 0, st, V, tl.rowBox.p, tl.nI, tl.nS, tl.sepRow.p, tl.T32.p, tl.tbuf.p, tl.uS.p, u);
             else hipLaunchKernelGGL((tl_finish_kernel<double>), dim3(gfin), dim3(kBlock), 0, st, V, tl.rowBox.p, tl.nI, tl.nS, tl.sepRow.p, tl.Tm.p, tl.tbuf.p, tl.uS.p, u);
@@ -2284,24 +2291,28 @@ struct Solver final : SolverBase {
         FusedParams F;
         F.n = n; F.nzl = sl.nzl; F.k0 = sl.k0; F.zc = c.zc; F.yblocks = c.yblocks; F.inv_h2 = sl.gp.inv_h2;
         F.zc_first = 0; F.zc_stride = 1;
+        // fold_pq (one GPU): the DIR sweep leaves its block partials of p'.Kp' in an array of their own and the next RES sweep sums them itself
+        const bool dir_to_own = fold_pq && MODE == CGF_DIR;
+        const int pq_np = (fold_pq && MODE == CGF_RES) ? fold_pq_np : 0;
+        if (fold_pq && !sl.pq_partials.p) sl.pq_partials.alloc(sl.partials.count);
         if (c.part == FUSED_INTERIOR) { F.zc_first = 1; c.zchunks -= 2; }
         else if (c.part == FUSED_BOUNDARY) { F.zc_stride = c.zchunks - 1; c.zchunks = 2; }
         if constexpr (WX <= 4) {
             if (c.nw == 4) {
                 hipLaunchKernelGGL((cg_fused_kernel<T, VEC, RY, WX, 4 / WX, MODE>), dim3((unsigned)(c.yblocks * c.zchunks)), dim3(256), 0, stream, F, sl.sc.p, slot_old,
-                                   slot_new, sl.red.p, sl.pq.p, init, use_uw, alpha_slot, zsrc, pin, pout, sl.r.p, sl.partials.p);
+                                   slot_new, sl.red.p, sl.pq.p, init, use_uw, alpha_slot, zsrc, pin, pout, sl.r.p, dir_to_own ? sl.pq_partials.p : sl.partials.p, sl.pq_partials.p, pq_np);
                 return;
             }
         }
         if constexpr (RY <= 2) {
             if (c.nw == 16) {   // 16-wave workgroups: twice the rows per workgroup, half the re-read border rows (see fused_cfg)
                 hipLaunchKernelGGL((cg_fused_kernel<T, VEC, RY, WX, 16 / WX, MODE>), dim3((unsigned)(c.yblocks * c.zchunks)), dim3(1024), 0, stream, F, sl.sc.p, slot_old,
-                                   slot_new, sl.red.p, sl.pq.p, init, use_uw, alpha_slot, zsrc, pin, pout, sl.r.p, sl.partials.p);
+                                   slot_new, sl.red.p, sl.pq.p, init, use_uw, alpha_slot, zsrc, pin, pout, sl.r.p, dir_to_own ? sl.pq_partials.p : sl.partials.p, sl.pq_partials.p, pq_np);
                 return;
             }
         }
         hipLaunchKernelGGL((cg_fused_kernel<T, VEC, RY, WX, 8 / WX, MODE>), dim3((unsigned)(c.yblocks * c.zchunks)), dim3(512), 0, stream, F, sl.sc.p, slot_old,
-                           slot_new, sl.red.p, sl.pq.p, init, use_uw, alpha_slot, zsrc, pin, pout, sl.r.p, sl.partials.p);
+                           slot_new, sl.red.p, sl.pq.p, init, use_uw, alpha_slot, zsrc, pin, pout, sl.r.p, dir_to_own ? sl.pq_partials.p : sl.partials.p, sl.pq_partials.p, pq_np);
     }
     template <int MODE, int VEC, int RY>
     void launch_fused_w(Slab<T>& sl, const FusedCfg& c, int slot_old, int slot_new, int init, int use_uw, int alpha_slot, const T* zsrc, const T* pin, T* pout) {
@@ -2322,14 +2333,18 @@ struct Solver final : SolverBase {
         else launch_fused_w<MODE, vec_width<T>(), 2>(sl, c, slot_old, slot_new, init, use_uw, alpha_slot, zsrc, pin, pout);
         return c.yblocks * c.zchunks;
     }
-    void launch_x_update2(Slab<T>& sl, int use_a, int use_b, hipStream_t st = nullptr) {
+    // half: -1 = the whole slab; 0 / 1 = its lower / upper half (split at a vector boundary)
+    void launch_x_update2(Slab<T>& sl, int use_a, int use_b, hipStream_t st = nullptr, int half = -1) {
         if (!st) st = stream;
-        const size_t nvec = sl.nown / vec;
+        const size_t nall = sl.nown / vec, nlow = nall / 2;
+        const size_t v0 = half == 1 ? nlow : 0, nvec = half < 0 ? nall : (half == 0 ? nlow : nall - nlow);
+        if (nvec == 0) return;
+        const size_t off = sl.plane + v0 * (size_t)vec;
         const unsigned g = (unsigned)((nvec + (size_t)kXuTiles * kBlock - 1) / ((size_t)kXuTiles * kBlock));
         if (vec == 1)
-            hipLaunchKernelGGL((cg_x_update2_kernel<T, 1>), dim3(g), dim3(kBlock), 0, st, nvec, sl.plane, sl.sc.p, use_a, use_b, sl.p.p, sl.q.p, sl.x.p);
+            hipLaunchKernelGGL((cg_x_update2_kernel<T, 1>), dim3(g), dim3(kBlock), 0, st, nvec, off, sl.sc.p, use_a, use_b, sl.p.p, sl.q.p, sl.x.p);
         else
-            hipLaunchKernelGGL((cg_x_update2_kernel<T, vec_width<T>()>), dim3(g), dim3(kBlock), 0, st, nvec, sl.plane, sl.sc.p, use_a, use_b, sl.p.p, sl.q.p,
+            hipLaunchKernelGGL((cg_x_update2_kernel<T, vec_width<T>()>), dim3(g), dim3(kBlock), 0, st, nvec, off, sl.sc.p, use_a, use_b, sl.p.p, sl.q.p,
                                sl.x.p);
     }
 
@@ -2346,7 +2361,9 @@ struct Solver final : SolverBase {
         }
         if (!st) allreduce(0, 1 + m);
         for (Slab<T>& sl : slabs) {
-            static const bool proj_f32 = knob("SHM_PROJ_F32") != nullptr;   // experiment (round 5): the fp32 solve's projector with the fp32 copies of the matrices
+            // (SHM_PROJ_F32, round 5: the fp32 solve's projector with the fp32 copies of the matrices -- half the bytes per application, but the converged plain CG of
+            // rocker 128^3 fp32 then lands at 1.1e-3 of the fp64 solve instead of 6e-5: the projector has to be exact to the solve's own rounding.  Not adopted.)
+            static const bool proj_f32 = knob("SHM_PROJ_F32") != nullptr;
             apply_Ginv(sl.red.p + 1, sl.u.p, proj_f32 && sizeof(T) == 4, stream);
             const int nred = std::max(1, std::min(16, m / 1024));   // workgroups of the u.w reduction (one per ~1000 rows)
             if (!sl.proj_ticket.p) {
@@ -3073,6 +3090,8 @@ struct Solver final : SolverBase {
                             Event& e_s2b, std::chrono::steady_clock::time_point wall0) {
         Event e_pcg, e_end;
         std::vector<int> nparts(slabs.size()), zparts(slabs.size(), 0), kparts(slabs.size(), 0);
+        fold_pq = total_slabs == 1 && !comm && knob("SHM_CG_NO_PQFOLD") == nullptr;   // (A/B knob: finalize_sum_kernel after every DIR sweep, as until round 4)
+        fold_pq_np = 0;
         auto dirbuf = [&](Slab<T>& sl, int k) { return (k & 1) ? sl.q.p : sl.p.p; };
         const int zsel = pre ? ARR_Z : ARR_R;
         for (size_t s = 0; s < slabs.size(); s++) {
@@ -3121,6 +3140,10 @@ struct Solver final : SolverBase {
             sweep(FUSED_BOUNDARY);
         };
         auto finalize_pq = [&]() {
+            if (fold_pq) {   // the RES sweep sums the partials itself (cg_fused_kernel)
+                fold_pq_np = kparts[0];
+                return;
+            }
             for (size_t s = 0; s < slabs.size(); s++)
                 hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, stream, slabs[s].partials.p, kparts[s], slabs[s].pq.p);
             allreduce(1, 1);
@@ -3137,6 +3160,13 @@ struct Solver final : SolverBase {
         static const bool no_xoverlap = knob("SHM_CG_NO_XOVERLAP") != nullptr;   // A/B knob
         // (512^3, same box: rocker fp64 0.706 -> 0.717, fp32 0.680 -> 0.691 of the roofline, bunny fp64 0.720 -> 0.725, fp32 0.710 -> 0.722; profiles/r04_projection.txt)
         const bool xoverlap = !no_xoverlap && total_slabs == 1 && !comm;
+        // Round 5: with the overlap on and no preconditioner, x is updated on HALF the grid in EVERY iteration instead of on all of it in every other one -- the upper half
+        // on odd k, the lower half on even k, each time with the two latest directions (p_{k-1}, p_k: both buffers and both step lengths are valid once RES of
+        // iteration k has run), so every a_j p_j reaches every node exactly once (the lower half takes a_0 p_0 alone at k = 0; the half that lags one step behind
+        // at the end is flushed after the loop).  Same 4NT per two iterations -- but now EVERY projection (seven short dependent launches, 0.08 ms with the
+        // two-level inverse) has 2NT of update to run beside, where the even iterations used to expose theirs in full.
+        static const bool no_xsplit = knob("SHM_CG_NO_XSPLIT") != nullptr;   // A/B knob: the round-4 schedule
+        const bool xsplit = xoverlap && !pre && !no_xsplit;
         Event e_xfork, e_xjoin;
         // The second stream is the set-up stream (idle during the loop, of the highest priority -- the projection's short kernels get their CUs at once -- and
         // known to run beside `stream`: the whole set-up does).  A stream of its own, of the same or of the lowest priority, was measured to serialise with the
@@ -3162,14 +3192,15 @@ struct Solver final : SolverBase {
                 // x += a_{k-1} p_{k-1} + a_k p_k (odd k) needs nothing of the projection, and the projection's kernels are m-sized and latency-bound: on one GPU the
                 // two run side by side (fork after RES, which fixes a_k; join before DIR, which needs the projected residual and overwrites p_{k-1}).  Sampled
                 // iterations keep everything on one stream so that the per-kernel durations of shm_stats stay what they say.
-                const bool fork_x = xoverlap && (it & 1) && !sample && !pre;
+                const bool fork_x = xoverlap && ((it & 1) || xsplit) && !sample && !pre;
                 if (fork_x) {
                     // the PROJECTION goes to the set-up stream (highest priority: its short kernels get their CUs at once), the update stays on the main stream
                     e_xfork.record(stream);
                     HIPCHK(hipStreamWaitEvent(stream_x, e_xfork.e, 0));
                     launch_projection(nparts, false, 1, stream_x);
                     e_xjoin.record(stream_x);
-                    launch_x_update2(slabs[0], 1, 1);
+                    if (xsplit) launch_x_update2(slabs[0], 1, it > 0, nullptr, it & 1);   // (k = 0: the lower half takes a_0 p_0 alone)
+                    else launch_x_update2(slabs[0], 1, 1);
                     HIPCHK(hipStreamWaitEvent(stream, e_xjoin.e, 0));
                 } else {
                     launch_projection(nparts, false, 1);
@@ -3179,7 +3210,8 @@ struct Solver final : SolverBase {
                 mark(3);
                 if (pre) launch_projection(zparts, true, 0);
                 mark(4);
-                if (!fork_x && (it & 1))
+                if (!fork_x && xsplit) launch_x_update2(slabs[0], 1, it > 0, nullptr, it & 1);
+                else if (!fork_x && (it & 1))
                     for (Slab<T>& sl : slabs) launch_x_update2(sl, 1, 1);
                 mark(5);
                 run_dir(it, slot_old, slot_new, 0);
@@ -3198,7 +3230,11 @@ struct Solver final : SolverBase {
             else if (rr <= o.tol * o.tol * rr0) converged = true;
             log("[shm] it=%d rel_res=%.3e", it, rr0 > 0. ? std::sqrt(std::fabs(rr / rr0)) : 0.);
         }
-        if (it & 1)  // the last direction has an even index: its step is still missing from x
+        if (xsplit) {
+            // the half that was not updated in the last iteration is one direction behind: the upper half after an even last index, the lower half after an odd one
+            if (it & 1) launch_x_update2(slabs[0], 1, 0, nullptr, 1);
+            else if (it > 0) launch_x_update2(slabs[0], 0, 1, nullptr, 0);
+        } else if (it & 1)  // the last direction has an even index: its step is still missing from x
             for (Slab<T>& sl : slabs) launch_x_update2(sl, 1, 0);
         e_pcg.record(stream);
         launch_shift_and_phi();
@@ -3242,8 +3278,8 @@ struct Solver final : SolverBase {
             st->kernel_samples = nsamples;
             st->preconditioner = pre ? SHM_PRECOND_DCT : SHM_PRECOND_NONE;
             st->solver = SHM_SOLVER_PRIMAL;
-            st->cg_form = 1;
-            // 3NT (DIR) + 3NT (RES) + 4NT every other iteration (x_update2); the five DCT sweeps move 3T + 8TP more
+            st->cg_form = xsplit ? 4 : 1;
+            // 3NT (DIR) + 3NT (RES) + 4NT every other iteration (x_update2; cg_form 4: 2NT -- half the grid -- every iteration); the five DCT sweeps move 3T + 8TP more
             st->bytes_per_iter = 8.0 * (double)N * sizeof(T) + (pre ? (double)N * (3.0 * sizeof(T) + 8.0 * sizeof(TP)) : 0.);
         }
         if (breakdown) throw Error(SHM_ERR_BREAKDOWN, fmt("projected CG broke down at iteration %d (rr=%g, rr0=%g)", it, rr, rr0));
@@ -3300,7 +3336,6 @@ struct Solver final : SolverBase {
         // partial-sum scratch: they are event-serialised (fork / join around the x update), never concurrent.
         for (Slab<T>& sl : slabs)
             if (sl.proj_ticket.p) HIPCHK(hipMemsetAsync(sl.proj_ticket.p, 0, sizeof(unsigned), stream));
-        if (tl.ticket.p) HIPCHK(hipMemsetAsync(tl.ticket.p, 0, sizeof(unsigned), stream));
         o_fast_hint = o.fast_integration != 0;
         launch_conv();
         e_conv.record(stream);

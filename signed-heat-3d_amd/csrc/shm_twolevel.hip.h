@@ -13,8 +13,8 @@
 // Set-up: batched blocked Gauss-Jordan of the D_a (all boxes at once), T_a for all boxes in one launch, the Schur update per colour (boxes of one colour -- box
 // coordinates of equal parity -- touch disjoint separator rows, so eight passes need no atomics and the sums have a fixed order),
 // then the existing blocked Gauss-Jordan on the |Sigma| x |Sigma| Schur complement: (3/b)^3 of the flops of the full inversion.
-// Application (5 launches): row-parallel mat-vecs with D_a^-1, column-parallel ones with E_a^T, the gather of w_S - E^T t, the dense S^-1 mat-vec,
-// row-parallel mat-vecs with T_a.  Exact up to rounding, so the projector and the dual preconditioner are the same operators as with the dense
+// Application (round 5: 3 launches; 5 until round 4): [row-parallel mat-vecs with D_a^-1 | column-parallel ones with T_a^T], the dense S^-1 mat-vec whose workgroups
+// gather w_S - T^T w_I first, row-parallel mat-vecs with T_a.  Exact up to rounding, so the projector and the dual preconditioner are the same operators as with the dense
 // inverse (same iteration counts); matrices in double for the projector, an fp32 copy for the dual preconditioner.
 #pragma once
 #include "shm_kernels.hip.h"
@@ -138,57 +138,80 @@ __global__ __launch_bounds__(kBlock) void tl_cols_kernel(TlBoxes B, const int* _
     if (wave == 0 && l < c) ybuf[c0 + l] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
 
-// Steps 1a + 1b + 2 in ONE launch (round 5; the projection of the stencil CG is a chain of short dependent launches, each worth 5-10 us beside a 0.28 ms sweep):
+// Steps 1a + 1b in ONE launch (round 5; the projection of the stencil CG is a chain of short dependent launches, each worth 5-10 us beside a 0.28 ms sweep):
 //   workgroups [0, grows):                t = D_a^-1 w_I, a wave per interior row (tl_rows_kernel's body);
 //   workgroups [grows, grows + nChunks):  y = T_a^T w_I = E_a^T D_a^-1 w_I  (D_a is symmetric, T_a = D_a^-1 E_a is stored for step 4) -- from w, not from t, so the two
-//                                         parts do not depend on each other (tl_cols_kernel's body with T for E);
-//   the last workgroup to finish:         v_S = w_S - sum of the y of the boxes that border the row (tl_gather_sep_kernel's body).
-// `ticket` is zero between launches (the last workgroup resets it; the solver also clears it when a solve starts).
+//                                         parts do not depend on each other (tl_cols_kernel's body with T for E).
+// (A version whose last workgroup to arrive also gathered v_S was measured at 0.27 instead of 0.08 ms per projection: the device-scope fence every workgroup needs
+// before it takes its ticket writes the L2 back each time.  v_S is gathered by the workgroups of the S^-1 mat-vec instead: tl_sep_matvec_kernel.)
 template <typename TM>
 __global__ __launch_bounds__(kBlock) void tl_rows_cols_kernel(TlBoxes B, const int* __restrict__ rowBox, int nI, int grows, const TM* __restrict__ Dinv, const int* __restrict__ chunkBox,
                                                               const int* __restrict__ chunkCol, const TM* __restrict__ Tm, const double* __restrict__ w, double* __restrict__ tbuf,
-                                                              double* __restrict__ ybuf, int nS, const int* __restrict__ sepRow, const int* __restrict__ adj_ptr,
-                                                              const int* __restrict__ adj_idx, double* __restrict__ vS, unsigned* __restrict__ ticket) {
+                                                              double* __restrict__ ybuf) {
     __shared__ double part[kBlock / kWave][kWave];
-    __shared__ unsigned last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if ((int)blockIdx.x < grows) {
         const int i = blockIdx.x * (kBlock / kWave) + wave;
-        if (i < nI) {
-            const int a = rowBox[i], i0 = B.ptrI[a], s = B.ptrI[a + 1] - i0;
-            const TM* Di = Dinv + B.offD[a] + (size_t)(i - i0) * tl_ld(s);
-            const int* rows = B.rowsI + i0;
-            double acc = 0.;
-            for (int j = lane; j < s; j += kWave) acc += (double)Di[j] * w[rows[j]];
-            acc = wave_sum(acc);
-            if (lane == 0) tbuf[i] = acc;
-        }
-    } else {
-        const int ch = (int)blockIdx.x - grows;
-        const int a = chunkBox[ch];
-        const int i0 = B.ptrI[a], s = B.ptrI[a + 1] - i0, c0 = B.ptrS[a], c = B.ptrS[a + 1] - c0;
-        const int l = chunkCol[ch] + lane;
-        const TM* Ta = Tm + B.offE[a];
+        if (i >= nI) return;
+        const int a = rowBox[i], i0 = B.ptrI[a], s = B.ptrI[a + 1] - i0;
+        const TM* Di = Dinv + B.offD[a] + (size_t)(i - i0) * tl_ld(s);
         const int* rows = B.rowsI + i0;
         double acc = 0.;
-        if (l < c)
-            for (int i = wave; i < s; i += kBlock / kWave) acc += (double)Ta[(size_t)i * c + l] * w[rows[i]];
-        part[wave][lane] = acc;
+        for (int j = lane; j < s; j += kWave) acc += (double)Di[j] * w[rows[j]];
+        acc = wave_sum(acc);
+        if (lane == 0) tbuf[i] = acc;
+        return;
+    }
+    const int ch = (int)blockIdx.x - grows;
+    const int a = chunkBox[ch];
+    const int i0 = B.ptrI[a], s = B.ptrI[a + 1] - i0, c0 = B.ptrS[a], c = B.ptrS[a + 1] - c0;
+    const int l = chunkCol[ch] + lane;
+    const TM* Ta = Tm + B.offE[a];
+    const int* rows = B.rowsI + i0;
+    double acc = 0.;
+    if (l < c)
+        for (int i = wave; i < s; i += kBlock / kWave) acc += (double)Ta[(size_t)i * c + l] * w[rows[i]];
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && l < c) ybuf[c0 + l] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+}
+
+// Steps 2 + 3 in one launch: u_S = S^-1 v_S with v_S = w_S - sum of the y of the boxes that border the row gathered by the mat-vec's own workgroups -- each takes
+// kTlSepRows rows of S^-1 and first builds ALL of v_S in LDS (nS values, a handful of loads each; the per-row sums then run in ginv_matvec_kernel's order).
+constexpr int kTlSepRows = 8;
+template <typename TM>
+__global__ __launch_bounds__(kBlock) void tl_sep_matvec_kernel(int nS, int ld, const TM* __restrict__ Sinv, const int* __restrict__ sepRow, const int* __restrict__ adj_ptr,
+                                                               const int* __restrict__ adj_idx, const double* __restrict__ w, const double* __restrict__ ybuf,
+                                                               double* __restrict__ uS) {
+    extern __shared__ double tl_v[];   // [ld]: v_S, zero in the padded tail
+    __shared__ double lds[8];
+    for (int g = threadIdx.x; g < ld; g += kBlock) {
+        double v = 0.;
+        if (g < nS) {
+            v = w[sepRow[g]];
+            for (int e = adj_ptr[g]; e < adj_ptr[g + 1]; e++) v -= ybuf[adj_idx[e]];
+        }
+        tl_v[g] = v;
+    }
+    __syncthreads();
+    for (int q = 0; q < kTlSepRows; q++) {
+        const int row = blockIdx.x * kTlSepRows + q;
+        if (row >= nS) break;
+        const TM* g = Sinv + (size_t)row * ld;
+        double s = 0.;
+        for (int c = threadIdx.x * 4; c < nS; c += kBlock * 4) {   // (ld is a multiple of 64: the vector loads stay inside the row; v_S is zero beyond nS)
+            if (sizeof(TM) == 4) {
+                const float4 gv = *reinterpret_cast<const float4*>(g + c);
+                s += (double)gv.x * tl_v[c] + (double)gv.y * tl_v[c + 1] + (double)gv.z * tl_v[c + 2] + (double)gv.w * tl_v[c + 3];
+            } else {
+                const double2 g0 = *reinterpret_cast<const double2*>(g + c), g1 = *reinterpret_cast<const double2*>(g + c + 2);
+                s += g0.x * tl_v[c] + g0.y * tl_v[c + 1] + g1.x * tl_v[c + 2] + g1.y * tl_v[c + 3];
+            }
+        }
+        s = block_sum(s, lds);
+        if (threadIdx.x == 0) uS[row] = s;
         __syncthreads();
-        if (wave == 0 && l < c) ybuf[c0 + l] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
     }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1u;
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    for (int g = threadIdx.x; g < nS; g += kBlock) {
-        double v = w[sepRow[g]];
-        for (int e = adj_ptr[g]; e < adj_ptr[g + 1]; e++) v -= __builtin_nontemporal_load(ybuf + adj_idx[e]);
-        vS[g] = v;
-    }
-    if (threadIdx.x == 0) *ticket = 0u;
 }
 
 // step 2: v_S = w_S - E^T t, gathered per separator row from the boxes that border it (fixed order); the padded tail stays 0

@@ -504,7 +504,10 @@ def test_phi_of_the_default_solve_against_c_oracle_at_full_size(shm, oracle_c, h
     s.close()
     ref = np.zeros(n ** 3)
     sto = np.zeros(5)
-    oracle_c.shmo_set_threads(cores)
+    # (the oracle's CG is a chain of short memory-bound parallel loops: beyond ~64 threads the fork / join of each costs more than the loop -- on the 256-thread
+    # host of the GPU boxes the 128^3 solve took 1037 s with every thread against seconds with 64)
+    threads = min(cores, 64)
+    oracle_c.shmo_set_threads(threads)
     t0 = time.time()
     rc = oracle_c.shmo_compute_distance(n, c_(pre["bbox_min"]), pre["cell"], S, c_(pre["pos"]).reshape(-1), c_(pre["wnormal"]).reshape(-1), c_(pre["area"]), pre["lam"],
                                         1, 0, 1e-10, 100000, ref, sto)
@@ -513,7 +516,7 @@ def test_phi_of_the_default_solve_against_c_oracle_at_full_size(shm, oracle_c, h
     assert rc == 0
     err = float(np.abs(phi - ref).max())
     print("\nphi bunny_small.obj n=%d: default solve (solver %d, %d iterations, rel %.1e) against the C oracle (%d CG iterations, rel %.1e, %.1f s on %d threads): L_inf %.3e, phi in [%.4f, %.4f]"
-          % (n, st.solver, st.iters, st.rel_residual, int(sto[1]), sto[2], t_or, cores, err, phi.min(), phi.max()))
+          % (n, st.solver, st.iters, st.rel_residual, int(sto[1]), sto[2], t_or, threads, err, phi.min(), phi.max()))
     assert err < 1e-7, err
 
 
@@ -1502,4 +1505,4 @@ print(repr(out))
     assert p.returncode == 0, p.stdout + p.stderr
     res = eval(p.stdout.strip().splitlines()[-1])
     for k, (err, iters, form) in res.items():
-        assert form == 1 and err < 1e-7, (k, err, iters, form)
+        assert form in (1, 4) and err < 1e-7, (k, err, iters, form)   # (4: plain CG on one GPU -- x updated on half the grid in every iteration)

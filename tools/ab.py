@@ -1,5 +1,5 @@
 """Generic A/B of library knobs, one process per setting (most knobs are read once per process):
-    python tools/r04_ab.py "<file>:<hCoef>:<precision>,..." "name=ENV1=v;ENV2=v" "name2=" ...
+    python tools/ab.py "<file>:<hCoef>:<precision>,..." "name=ENV1=v;ENV2=v" "name2=" ...
 prints phases of the third solve for every (case, setting)."""
 import os, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -21,6 +21,7 @@ for prec in (32, 64):
         best = per if best is None else min(best, per)
     print("%-10s rocker 512^3 fp%d: %.4f ms/iter  loop frac of 8 TB/s %.4f  ms_project_avg %.4f" % (label, prec, best, st["bytes_per_iter"] / (best * 1e-3) / 8e12, st["ms_project_avg"]), flush=True)
     s.close()
+if os.environ.get("SHM_PROBE_QUICK"): sys.exit(0)
 pre = HostSolver(os.path.join(R, "data/rocker.obj")).preprocess(hCoef=3.0)
 n = pre["n"]
 s = shm.GridSolver(precision=64)

@@ -3,7 +3,7 @@
 R="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$(mkdir -p "$1" && cd "$1" && pwd)"
 cd "$R"
-for rep in 1 2 3; do python3 tools/r04_ab.py bunny_small.obj:4:64 "default=" "wn2=SHM_GREEN_WN=2" "wide=SHM_GREEN_WIDE=1"; done > "$OUT/ab.txt" 2>&1
+for rep in 1 2 3; do python3 tools/ab.py bunny_small.obj:4:64 "default=" "wn2=SHM_GREEN_WN=2" "wide=SHM_GREEN_WIDE=1"; done > "$OUT/ab.txt" 2>&1
 cd /tmp && export TMPDIR=/tmp
 for v in default wn2; do
   if [ $v = wn2 ]; then export SHM_GREEN_WN=2; fi

@@ -11,7 +11,7 @@ for n in "$@"; do
   if [ "$n" = default ]; then args+=("default="); else args+=("$n=SHM_GRID_LIB=$V/libshm_grid_$n.so"); fi
 done
 for rep in 1 2 3; do
-  python3 "$R/tools/r04_ab.py" "${CASES:-bunny_small.obj:4:64}" "${args[@]}" >> "$OUT/ab.txt" 2>&1
+  python3 "$R/tools/ab.py" "${CASES:-bunny_small.obj:4:64}" "${args[@]}" >> "$OUT/ab.txt" 2>&1
 done
 cat "$OUT/ab.txt"
 cd /tmp && export TMPDIR=/tmp
