@@ -38,6 +38,7 @@
 #include "shm_schur.hip.h"
 #include "shm_dct.hip.h"
 #include "shm_dct_gemm.hip.h"
+#include "shm_green_fft.hip.h"
 
 namespace shm {
 
@@ -563,6 +564,8 @@ struct Solver final : SolverBase {
     DevArray<double> gs_lam, gs_ctab, gs_Cm, gs_Ct, gs_W0, gs_W1, gs_T, Sdense, d_rowT;
     DevArray<int> d_rowX;
     std::vector<double> h_gs_lam, h_gs_ctab, h_rowT;   // host staging outlives the asynchronous uploads
+    std::vector<Cplx<double>> h_gs_tw;                 // twiddles of the Green's table's FFT passes (shm_green_fft.hip.h)
+    DevArray<Cplx<double>> gs_tw;
     std::vector<int> h_rowX;
     bool have_S = false;
     bool dual_direct_requested = false, dual_direct = false;   // direct dual solve: S^-1 (Sinv) instead of G^-1; requested by solve(), decided in build_constraints()
@@ -1316,7 +1319,8 @@ struct Solver final : SolverBase {
             }
         }
         const double sampled = (double)K * (double)((S + stride - 1) / stride);
-        const double f_near = (double)c_near / sampled, f_keep = (double)c_keep / sampled;
+        const double f_keep = (double)c_keep / sampled;
+        const double f_near = conv_tiered32 ? 0. : (double)c_near / sampled;   // (fp32 solve: every kept pair goes through the packed-fp32 body)
         double nodes = 0.;
         for (const Slab<T>& sl : slabs) nodes += (double)sl.nown;
         // (per-pair costs of the round-4 kernel; the round-5 one is ~7 % faster, but the 0.38 of the rule that reads this estimate was drawn with these constants)
@@ -1355,7 +1359,7 @@ struct Solver final : SolverBase {
         // line is drawn per problem from an estimate of Step 1 that knows what the tiers drop (estimate_step1_ms_tiered: +-25 % over the data files) and of the
         // set-up on an idle device (assembly 1.4e-7 m^2, inversion 5.5e-11 m^3, the Green's table); beside Step 1 the set-up runs at ~0.4 of that speed.
         static const bool direct_est_off = knob("SHM_DUAL_DIRECT_EST_OFF") != nullptr;   // A/B knob: the fixed limit alone
-        if (!dual_direct && dual_direct_requested && !no_direct && !direct_est_off && conv_tiered && total_slabs == 1 && precond_available() && !gemm_dct() && n <= 512 &&
+        if (!dual_direct && dual_direct_requested && !no_direct && !direct_est_off && (conv_tiered || conv_tiered32) && total_slabs == 1 && precond_available() && !gemm_dct() && n <= 512 &&
             m > direct_max_m && m <= 16384 && conv_est_total_ms < 1e29) {
             const double md = (double)m;
             const double table_ms = 10.0 * std::pow((double)n / 512.0, 4.0);
@@ -1373,7 +1377,9 @@ struct Solver final : SolverBase {
         // (round 4, tools/r04_ab.py: bunny_small 512^3 fp32 112.8 ms direct / 107.6 iterative, bunny.pc 62.7 / 59.4; at 256^3: 15.8 / 18.5, 128^3: 4.7 / 7.3)
         const bool direct_always = knob("SHM_DUAL_DIRECT_ALWAYS") != nullptr || dual_form_req == SHM_DUAL_DIRECT;
         // (the all-fp64 kernel at 512^3: 321 direct / 329 iterative -- fp64 iterations cost twice as much, so only the fp32 solve changes)
-        if (sizeof(T) == 4 && n >= 512 && !gemm_dct() && !direct_always) dual_direct = false;
+        // Round 5: the fp32 solve's Step 1 is the tiered kernel too (two waves per SIMD): its set-up runs beside it like the fp64 solve's, and the direct solve wins
+        // again (tools/r05_fp32_forms_ab.sh, ms per solve iterative / direct: bunny_small 512^3 110.0 / 102.2, bunny.pc 512^3 60.6 / 54.6, chair 512^3 214.3 / 209.4)
+        if (sizeof(T) == 4 && !conv_tiered32 && n >= 512 && !gemm_dct() && !direct_always) dual_direct = false;
         dual_direct = dual_direct && schur_wanted();   // (schur_wanted() reads dual_direct: with it set only the structural conditions remain)
         const bool need_node_tables = !dual_direct;
         // ---- G = A A^T and B = A K A^T from the (node, row, coef) entries sorted by node: rows meet exactly at shared nodes.
@@ -1986,7 +1992,7 @@ struct Solver final : SolverBase {
         // (beside the tiered fp64 Step 1 -- where the assembly is co-resident and hidden -- up to 16384 rows since round 4: rocker 512^3 fp64, m = 12 612: solve phase
         // 71.5 -> 35.9 ms, 631 -> 609 ms per solve; after the fp32 Step 1, which leaves the set-up's kernels no room, the same choice costs 401 -> 423 ms)
         static const int max_m_env = knob("SHM_DENSE_S_MAX_M") ? atoi(knob("SHM_DENSE_S_MAX_M")) : 0;
-        const int max_m = max_m_env > 0 ? max_m_env : (conv_tiered ? 16384 : 8192);
+        const int max_m = max_m_env > 0 ? max_m_env : ((conv_tiered || conv_tiered32) ? 16384 : 8192);
         // n not a power of two: applying S through the grid costs six dense products per CG iteration (shm_dct_gemm.hip.h: 5 ms at n = 362), so the explicit S
         // is worth its assembly up to the sizes its memory allows, whatever Step 1 hides
         if (gemm_dct()) return !off && m > 0 && m <= std::max(max_m, 16384);
@@ -2009,7 +2015,7 @@ struct Solver final : SolverBase {
         const double grid_iter_ms = std::max(0.15, 1.4 * std::pow((double)n / 512.0, 3.0) * (sizeof(T) / 8.0));
         // ... and only beside the tiered fp64 Step 1: after the fp32 (or all-fp64) kernel, which leaves the set-up's kernels no room, the assembly is exposed
         // (chair 512^3 fp32, m = 7 748: 243 ms through the grid, 253 with the explicit S and 17 ms of wait; 256^3 fp32: 38.1 / 43.5)
-        return conv_tiered && conv_est_total_ms >= 3.0 * schur_est_ms && grid_iter_ms > 1.3 * dense_iter_ms;
+        return (conv_tiered || conv_tiered32) && conv_est_total_ms >= 3.0 * schur_est_ms && grid_iter_ms > 1.3 * dense_iter_ms;
     }
     // The Green's table of the grid (depends on n and h alone) on `st`.  Round 4: when the number of sources already guarantees the direct dual solve (m <= S <=
     // its limit), build_constraints() queues this BEFORE the host builds the constraint rows, so the table's kernels (0.9 ms at 256^3, 10 ms at 512^3) run while
@@ -2019,7 +2025,7 @@ struct Solver final : SolverBase {
         static const int direct_max_m = knob("SHM_DUAL_DIRECT_MAX_M") ? atoi(knob("SHM_DUAL_DIRECT_MAX_M")) : 4096;
         if (dual_form_req == SHM_DUAL_EXPLICIT_S_CG || dual_form_req == SHM_DUAL_THROUGH_GRID) return false;
         return !off && dual_direct_requested && knob("SHM_DUAL_NO_DIRECT") == nullptr && knob("SHM_DUAL_NO_DENSE_S") == nullptr && total_slabs == 1 && precond_available() &&
-               !gemm_dct() && n <= 512 && S > 0 && S <= direct_max_m && (sizeof(T) == 8 || n < 512 || knob("SHM_DUAL_DIRECT_ALWAYS") != nullptr || dual_form_req == SHM_DUAL_DIRECT);
+               !gemm_dct() && n <= 512 && S > 0 && S <= direct_max_m && (sizeof(T) == 8 || conv_tiered32 || n < 512 || knob("SHM_DUAL_DIRECT_ALWAYS") != nullptr || dual_form_req == SHM_DUAL_DIRECT);
     }
     void enqueue_green_table(hipStream_t st) {
         const int P = n + 8;   // leading dimension of the last table index (rows stay 64-byte aligned)
@@ -2045,6 +2051,61 @@ struct Solver final : SolverBase {
             gs_Ct.alloc((size_t)n * P);
             W0.alloc(std::max((size_t)n * n * n, (size_t)n * n1 * P));
             W1.alloc((size_t)n * n * P);
+            // Round 5: n = 2^k -- the three cosine contractions as FFT passes (shm_green_fft.hip.h: O(n^3 log n), 0.8 GB of traffic at 256^3) instead of dense
+            // products on the fp64 matrix cores (6 n^4 flop: 1.2 ms at 256^3, 10 ms at 512^3 -- machine time taken from the Step-1 kernel they run beside).
+            // SHM_GREEN_GEMM=1: the products (A/B; they also serve every n that is not a power of two)
+            const bool by_fft = (n & (n - 1)) == 0 && n >= 16 && n <= 512 && knob("SHM_GREEN_GEMM") == nullptr;
+            if (by_fft) {
+                const double pi = 3.14159265358979323846;
+                h_gs_tw.resize(2 * (size_t)n);   // [0, n): e^{-2 pi i t / n} ; [n, 2n): e^{-i pi k / n}
+                for (int t = 0; t < n; t++) {
+                    h_gs_tw[(size_t)t] = {std::cos(2. * pi * t / n), -std::sin(2. * pi * t / n)};
+                    h_gs_tw[(size_t)n + t] = {std::cos(pi * t / n), -std::sin(pi * t / n)};
+                }
+                gs_tw.upload(h_gs_tw, st);
+                // (the padded columns d3 in [n + 1, n + 8) of W1 are transformed like the others by the second and third pass: keep them finite)
+                HIPCHK(hipMemsetAsync(W1.p, 0, (size_t)n * n * P * sizeof(double), st));
+                hipLaunchKernelGGL(green_symbol_kernel, dim3((unsigned)std::min(n * n, 8 * num_cus)), dim3(kBlock), 0, st, n, gs_lam.p, W0.p);
+                const long long Pl = P, n1l = (long long)n1;
+                auto pass = [&](bool xpass, int ntiles, int tiles_a, DctAddr in, DctAddr out, const double* src, double* dst) {
+                    CosiParams C;
+                    C.ntiles = ntiles;
+                    C.tiles_a = tiles_a;
+                    C.in = in;
+                    C.out = out;
+                    const dim3 g((unsigned)std::min(ntiles, 16 * num_cus));
+                    const Cplx<double>*tw = gs_tw.p, *om = gs_tw.p + n;
+                    int l2 = 0;
+                    while ((1 << l2) < n) l2++;
+#define SHM_COSI_CASE(L)                                                                                                                              \
+    case L:                                                                                                                                            \
+        if (xpass) hipLaunchKernelGGL((cosi_lines_kernel<L, true>), g, dim3(kBlock), 0, st, C, src, dst, tw, om, setup_prio);                         \
+        else hipLaunchKernelGGL((cosi_lines_kernel<L, false>), g, dim3(kBlock), 0, st, C, src, dst, tw, om, setup_prio);                              \
+        break;
+                    switch (l2) {
+                        SHM_COSI_CASE(4) SHM_COSI_CASE(5) SHM_COSI_CASE(6) SHM_COSI_CASE(7) SHM_COSI_CASE(8) SHM_COSI_CASE(9)
+                        default: throw Error(SHM_ERR_INVALID, "Green's table by FFT: n out of range");
+                    }
+#undef SHM_COSI_CASE
+                };
+                auto addr = [](long long a_stride, long long b_stride, long long line_stride, long long elem_stride) {
+                    DctAddr A;
+                    A.off = 0; A.a_stride = a_stride; A.b_stride = b_stride; A.line_stride = line_stride; A.elem_stride = elem_stride;
+                    A.seg_stride = 0; A.seg_shift = 30; A.seg_mask = 0x3fffffff;
+                    return A;
+                };
+                const int L = kCosiL;
+                // W1[(k1,k2)][d3] from W0[(k1,k2)][k3]: tiles of L consecutive rows
+                pass(true, n * n / L, n * n / L, addr((long long)L * n, 0, n, 1), addr((long long)L * Pl, 0, Pl, 1), W0.p, W1.p);
+                // W2[k1][d2][d3] from W1[k1][k2][d3]: per k1, tiles of L consecutive d3
+                pass(false, n * (P / L), P / L, addr(L, (long long)n * Pl, 1, Pl), addr(L, n1l * Pl, 1, Pl), W1.p, W2.p);
+                // T[d1][(d2,d3)] from W2[k1][(d2,d3)]: tiles of L consecutive (d2,d3)
+                pass(false, (int)(n1l * Pl / L), (int)(n1l * Pl / L), addr(L, 0, 1, n1l * Pl), addr(L, 0, 1, n1l * Pl), W2.p, gs_T.p);
+                HIPCHK(hipGetLastError());
+                gs_n = n;
+                gs_cell = cell;
+                return;
+            }
             HIPCHK(hipMemsetAsync(gs_Ct.p, 0, (size_t)n * P * sizeof(double), st));
             hipLaunchKernelGGL(cosine_tables_kernel, dim3(grid_for(n1 * n, 1024)), dim3(kBlock), 0, st, n, P, gs_ctab.p, gs_Cm.p, gs_Ct.p);
             hipLaunchKernelGGL(green_symbol_kernel, dim3((unsigned)std::min(n * n, 8 * num_cus)), dim3(kBlock), 0, st, n, gs_lam.p, W0.p);
