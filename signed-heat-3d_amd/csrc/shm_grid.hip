@@ -3213,7 +3213,10 @@ struct Solver final : SolverBase {
         finalize_pq();
         HIPCHK(hipGetLastError());
 
-        const int kMaxSamples = 32, kEvPer = 8;
+        // Per-kernel durations are sampled on a few iterations only: a sampled iteration keeps everything on one stream (no projection beside the x update) and records
+        // eight events, i.e. it runs ~40 us slower than the others -- 32 of them were 16 % of the 200-iteration stencil-PCG leg of bench.py and 40 % of a DCT-preconditioned
+        // solve (round 5: 12; the kernels are steady, their averages do not move)
+        const int kMaxSamples = 12, kEvPer = 8;
         std::vector<std::unique_ptr<Event>> ev;
         if (st) for (int a = 0; a < kEvPer * kMaxSamples; a++) ev.emplace_back(new Event());
         int nsamples = 0;

@@ -1779,9 +1779,14 @@ __global__ __launch_bounds__(kBlock) void gj_update_kernel(double* __restrict__ 
 #ifndef SHM_GJ_STEP_PAIRS
 #define SHM_GJ_STEP_PAIRS 1   // gj_step_kernel's pivot inversion: two elimination steps per barrier (0: one, as in the separate pivot kernel -- A/B builds)
 #endif
+#ifndef SHM_GJ_STEP_WAVES
+#define SHM_GJ_STEP_WAVES 3     // register cap of gj_step_kernel through its occupancy: 4 -> 128 registers, 21 of them spilled (rounds 4: Step 1 held 2 x 184 of a SIMD's 512
+                                // and a 144-register build did not run beside it); 3 (round 5: Step 1 holds 2 x 176): 144 registers, no spill, runs beside it (wait 0.00 ms at
+                                // 128^3 / 256^3, profiles/r05_gj_step.txt) -- set-up alone at m = 2842 4.05 -> 3.93 ms
+#endif
 constexpr int kGjStepScratch = 8 * (kGJ + 1);
 constexpr int kGjStepLds = kGJ * (kGJ + 1) + kGjStepScratch;
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void gj_step_kernel(
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_GJ_STEP_WAVES, SHM_GJ_STEP_WAVES))) void gj_step_kernel(
     double* __restrict__ G, int ld, int nb, int k, const double* __restrict__ Rp /* [64][ld] of step k-1 */, const double* __restrict__ Cp /* [ld][64] */,
     double* __restrict__ Rn, double* __restrict__ Cn, int* __restrict__ flag, int prio) {
     __shared__ double smem[kGjStepLds];

@@ -207,7 +207,7 @@ def test_kernel_register_schedules():
     # of the last product in scratch, each stored and reloaded ONCE per workgroup, outside every loop (checked in the ISA; a capped build with 74 registers
     # spilled inside the inversion loop measured 1.5x slower and is what this bound keeps out)
     step_spill = spilled.pop("shm::gj_step_kernel", 0)
-    assert step_spill <= 24, step_spill
+    assert step_spill == 0, step_spill      # (round 5: 144 registers at three waves per SIMD -- the 128-register cap of round 4 spilled 21)
     assert not spilled, spilled
     conv = by_name["void shm::conv_normalize_kernel<double, 4>"]
     assert conv["VGPRs"] >= 200 and conv["Occupancy"] == 2, conv
@@ -222,8 +222,9 @@ def test_kernel_register_schedules():
               "shm::gj_step_kernel"):
         v = by_name[k]
         waves_per_simd = 4 if "gj_pivot_kernel<2>" in k else 1      # (1024-thread workgroup: four waves on every SIMD)
-        # (round 4, measured: a 144-register build of gj_step_kernel does NOT run beside Step 1 although 2 x 184 + 144 = 512; the 137 of gj_pivot_block4_kernel do)
-        assert waves_per_simd * (v["VGPRs"] + v.get("AGPRs", 0)) <= min(room, 140) and v["LDS Size"] <= 42 * 1024, (k, v, room)
+        # (round 4, measured: a 144-register build of gj_step_kernel does NOT run beside a Step 1 of 2 x 184 registers although 2 x 184 + 144 = 512; the 137 of
+        # gj_pivot_block4_kernel do: 16 registers of slack.  Round 5: Step 1 holds 2 x 176 -- room 160 -- and the 144-register gj_step_kernel runs beside it, measured)
+        assert waves_per_simd * (v["VGPRs"] + v.get("AGPRs", 0)) <= room - 16 and v["LDS Size"] <= 42 * 1024, (k, v, room)
     conv32 = by_name["void shm::conv_normalize_kernel<float, 8>"]   # two sources in flight, three waves per SIMD (measured best with the tile queue)
     assert conv32["VGPRs"] <= 168 and conv32["Occupancy"] >= 3, conv32
     for k, v in by_name.items():   # the shipped shape of the fused stencil-CG sweeps: two rows per lane, four waves per SIMD
