@@ -1,4 +1,5 @@
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r03/convpmc; rm -rf $OUT; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+export SHM_DEBUG_KNOBS=1   # experiment knobs of the library are read only behind this gate
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT -o f -- python3 $R/tools/conv_only.py > $OUT/f.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT -o w -- python3 $R/tools/conv_only.py > $OUT/w.log 2>&1
 cd $R; python3 - <<'P'

@@ -1,4 +1,5 @@
 #!/bin/bash
+export SHM_DEBUG_KNOBS=1   # experiment knobs of the library are read only behind this gate
 # Set-up beside Step 1 at 256^3: the A/B of the Green's-table GEMM shape, then a kernel trace of one solve (timeline of the set-up kernels inside Step 1's span).
 R="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$(mkdir -p "$1" && cd "$1" && pwd)"

@@ -3,6 +3,7 @@
 beside Step 1 (the shipped schedule: co-resident with the tiered fp64 kernel, time-sliced against the fp32 one), with what the solve then still waits
 for.  Feeds the constants of tools/scaling_model.py.      python tools/setup_alone.py [workload ...]"""
 import os, subprocess, sys
+import os as _os; _os.environ.setdefault("SHM_DEBUG_KNOBS", "1")   # this tool drives the library's experiment knobs (read only behind this gate)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import WORKLOADS

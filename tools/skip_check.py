@@ -1,6 +1,7 @@
 """Step-1 cluster skipping is exact to rounding: same Y with and without it (SHM_CONV_NO_SKIP=1), fp32 and fp64; and the fp32 kernel with 8 nodes
 per lane (two culled halves per tile) gives the bits of the one with 4 (SHM_CONV_NPT4=1)."""
 import os, sys, numpy as np
+import os as _os; _os.environ.setdefault("SHM_DEBUG_KNOBS", "1")   # this tool drives the library's experiment knobs (read only behind this gate)
 sys.path.insert(0, os.getcwd())
 import shm_import
 shm = shm_import.load()

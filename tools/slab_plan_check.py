@@ -3,6 +3,7 @@ the same launches a P-rank run would make, one slab after the other) with the eq
 Step-1 time and evaluated pairs (SHM_CONV_SLAB_LOG=1) beside the host estimate the plan was cut by.
     python tools/slab_plan_check.py [workload ...]      # default: rocker_512_f32 bunny_small_256_f64 ; P = 4, 8"""
 import os, re, subprocess, sys
+import os as _os; _os.environ.setdefault("SHM_DEBUG_KNOBS", "1")   # this tool drives the library's experiment knobs (read only behind this gate)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,6 +1,7 @@
 """Every shipped data file at five grid sizes: the tiered fp64 Step 1 (shipped) against the all-fp64 kernel (SHM_CONV_EXACT=1) -- max|dY| over the nodes
 where both are finite, whether the non-finite sets agree, max|dphi|, and the share of pairs each tier took.     python tools/tier_robustness.py"""
 import os, sys, numpy as np
+import os as _os; _os.environ.setdefault("SHM_DEBUG_KNOBS", "1")   # this tool drives the library's experiment knobs (read only behind this gate)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import shm_import
 shm = shm_import.load()

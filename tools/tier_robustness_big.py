@@ -3,6 +3,7 @@ max|dY| and max|dphi| over sampled z-planes (every `stride`-th plane plus the tw
 pairs each tier took, and whether the non-finite sets agree.  Continues tools/tier_robustness.py (all files at 16^3 ... 256^3).
     python tools/tier_robustness_big.py [--skip-1024]"""
 import os
+import os as _os; _os.environ.setdefault("SHM_DEBUG_KNOBS", "1")   # this tool drives the library's experiment knobs (read only behind this gate)
 import sys
 import time
 

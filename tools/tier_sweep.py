@@ -1,6 +1,7 @@
 """Tiered fp64 Step 1 (csrc/shm_conv_tiered.hip.h): time, executed pairs per tier, and the error of Y and phi against the all-fp64 kernel
 (SHM_CONV_EXACT=1) for a range of far thresholds G (SHM_CONV_TIER_LOG).   python tools/tier_sweep.py [file hCoef [G ...]]"""
 import os, sys, numpy as np
+import os as _os; _os.environ.setdefault("SHM_DEBUG_KNOBS", "1")   # this tool drives the library's experiment knobs (read only behind this gate)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import shm_import
 shm = shm_import.load()

@@ -3,6 +3,7 @@ evaluates the node's sum term by term in fp64: |X| against the L1 norm of its te
 the source geometry cancel), the share of the terms below e^-8 of the node's largest term (what a per-pair rule would send to the packed-fp32 tier) and
 lambda * r of the nearest source.     python tools/tier_worst_nodes.py [file hCoef]..."""
 import os
+import os as _os; _os.environ.setdefault("SHM_DEBUG_KNOBS", "1")   # this tool drives the library's experiment knobs (read only behind this gate)
 import sys
 
 import numpy as np
