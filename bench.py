@@ -121,14 +121,16 @@ def step1_roofline(avg, nominal_pairs, precision, tiered=None):
     t = avg["ms_conv"] * 1e-3
     ev = p64 + p32
     t_at_peak = 18.0 * p64 / 78.6e12 + 18.0 * p32 / 157.3e12
-    if tiered is None:
-        tiered = precision == 64 and not os.environ.get("SHM_CONV_EXACT")
+    if tiered is None:   # (SHM_CONV_EXACT / SHM_CONV32_CLASSIC are experiment knobs of the library: read only under SHM_DEBUG_KNOBS=1)
+        knobs = os.environ.get("SHM_DEBUG_KNOBS", "0") not in ("", "0")
+        tiered = not (knobs and os.environ.get("SHM_CONV_EXACT" if precision == 64 else "SHM_CONV32_CLASSIC"))
     return {"kernel": "conv_tiered_kernel" if tiered else "conv_normalize_kernel", "bound": "valu",
             "pairs_nominal": nominal_pairs, "pairs_fp64": p64, "pairs_fp32": p32,
             "pairs_evaluated_over_nominal": ev / nominal_pairs if nominal_pairs else None,
             "pairs_note": "pairs_fp64 / pairs_fp32 = (node, source) pairs the kernel evaluated in fp64 / packed fp32 (its own counters; shm_stats); nominal = N*S per rank. "
-                          "fp64 solve: terms below e^-8 of a node block's dominant terms take the packed-fp32 tier (error budget on Y: 1e-8, SHM_CONV_EXACT=1 = all fp64); "
-                          "sources whose terms vanish against the budget are dropped and count in neither",
+                          "fp64 solve: terms below e^-8 of a node block's dominant terms take the packed-fp32 tier (error budget on Y: 1e-8; shm_opts.step1_arith = EXACT_F64: all "
+                          "fp64); fp32 solve: every kept pair in packed fp32 (the few sources outside the fp32 exponent range of a block in fp64); sources whose terms vanish "
+                          "against the budget are dropped and count in neither",
             "nominal_pairs_per_s": nominal_pairs / t, "evaluated_pairs_per_s": ev / t,
             "achieved_TFLOPs_18_per_evaluated_pair": 18.0 * ev / t / 1e12,
             "peak_TFLOPs_weighted": (18.0 * ev / t_at_peak / 1e12) if t_at_peak > 0 else None,
@@ -452,7 +454,7 @@ def main():
         traffic = None
         # HBM bytes per launch from the rocprofv3 PMC passes of THIS command (tools/pmc_traffic.py; FETCH_SIZE doubled per the gfx950
         # correction), committed per round; PMC counters cannot be collected from inside the run
-        tfile = next((f for f in (os.path.join(ROOT, "profiles", "r04_pmc_traffic.json"), os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"))
+        tfile = next((f for f in (os.path.join(ROOT, "profiles", "r05_pmc_traffic.json"), os.path.join(ROOT, "profiles", "r04_pmc_traffic.json"))
                       if os.path.exists(f)), "")
         if os.path.exists(tfile):
             try:
@@ -466,7 +468,7 @@ def main():
             # the arithmetic the path computes in.  fp64 handles: everything in fp64 except Step 1's far tier -- (node, source) pairs whose terms are below e^-8 of
             # their node block's dominant terms are summed in packed fp32 (step1.pairs_fp32; error budget on Y 1e-8, asserted against the C oracle at full
             # size in tests/); `also.exact_fp64` is the same workload with every pair in fp64
-            "dtype": ("f64 (Step 1: f64 / packed-f32 tiers)" if not os.environ.get("SHM_CONV_EXACT") else "f64") if precision == 64 else "f32",
+            "dtype": "f64 (Step 1: f64 / packed-f32 tiers)" if precision == 64 else "f32",
             "data": "reference data file %s (no RNG; sources + grid resident in HBM before the timed region)" % path,
             "config": {"workload": args.workload, "grid": "%d^3" % n, "sources": int(pre["S"]), "constraint_rows": int(avg["m"]),
                        "tol": args.tol if args.tol > 0 else (1e-8 if precision == 64 else 1e-5), "cg_iters": int(avg["iters"]),
@@ -516,7 +518,7 @@ def main():
             out["roofline"] = {"kernel": s1["kernel"], "bound": "valu",
                                "bound_detail": "compute: vector-ALU issue (no matrix-core shape in the kernel, no MFMA instruction); peak = the vector peaks of the two "
                                                "arithmetic tiers (78.6 TFLOP/s fp64, 157.3 TFLOP/s fp32) weighted by the pairs each tier evaluated; SQ counters of this "
-                                               "kernel: profiles/r04_sq_counters_conv.txt",
+                                               "kernel: profiles/r05_sq_counters_conv.txt",
                                "achieved": s1["achieved_TFLOPs_18_per_evaluated_pair"], "peak": s1["peak_TFLOPs_weighted"], "unit": "TFLOP/s", "frac": s1["frac"],
                                "traffic": conv_traffic,
                                "note": "%d launch(es) per step, duration = phases_ms.ms_conv (HIP events on the solver's stream around all of them); achieved = 18 nominal "

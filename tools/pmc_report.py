@@ -1,9 +1,9 @@
-"""Post-process the PMC passes of tools/profile_r04.sh into profiles-ready files.  Everything is accounted PER STEP (= per solve): a counter is summed over
+"""Post-process the PMC passes of tools/profile_r05.sh into profiles-ready files.  Everything is accounted PER STEP (= per solve): a counter is summed over
 all launches of a kernel inside one solve, and the launch count is printed beside it.
-  r04_pmc_traffic.json      HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes -- MI355X_MICROARCH.md,
+  r05_pmc_traffic.json      HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes -- MI355X_MICROARCH.md,
                             HBM section; both counters in KB) per kernel: per launch, launches per step, per step
-  r04_sq_counters_conv.txt  SQ / GRBM counters of the Step-1 kernel of one solve (VALU issue, LDS, effective clock), with the executed pairs of that solve
-    python tools/pmc_report_r04.py <dir with the *_results.db> <out dir> [executed_pairs_fp64 executed_pairs_fp32]"""
+  r05_sq_counters_conv.txt  SQ / GRBM counters of the Step-1 kernel of one solve (VALU issue, LDS, effective clock), with the executed pairs of that solve
+    python tools/pmc_report.py <dir with the *_results.db> <out dir> [executed_pairs_fp64 executed_pairs_fp32]"""
 import json
 import re
 import sqlite3
@@ -57,7 +57,7 @@ if __name__ == "__main__":
     d, out = sys.argv[1], sys.argv[2]
     t256 = traffic(d + "/pmc_fetch_results.db", d + "/pmc_write_results.db", 256 ** 3, 8)
     res = {
-        "_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/profile_r04.sh), each over ONE solve (`bench.py --steps 1 --warmup 0`); "
+        "_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/profile_r05.sh), each over ONE solve (`bench.py --steps 1 --warmup 0`); "
                  "hbm bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE tallies 128-B requests at 64 B; Infinity-Cache hits "
                  "are counted as fetches).  Every figure is per STEP (sum over the kernel's launches in the solve), with the launch count beside it.  "
                  "per_kernel_256 = bunny_small 256^3 fp64, dual solver; per_kernel_pcg512 / _f32 = `--workload bunny_small_512_f64|f32 --solver primal --precond none "
@@ -98,7 +98,7 @@ if __name__ == "__main__":
                                                                      for k, v in t.items() if k.startswith("cg_")}
         except Exception as e:
             res["per_kernel_" + tag] = {"failed": repr(e)}
-    json.dump(res, open(out + "/r04_pmc_traffic.json", "w"), indent=1)
+    json.dump(res, open(out + "/r05_pmc_traffic.json", "w"), indent=1)
     # ---- SQ counters of the Step-1 kernel, per step
     lines = ["SQ / GRBM counters of the Step-1 kernel ALONE (tools/conv_only.py: 2 x shm_grid_run_conv on bunny_small 256^3 fp64, no set-up kernels on the device).",
              "Two passes (SQ has 8 counter slots).  Every counter is the sum over all SEs / XCDs, PER STEP (= per Step 1: the sum over the run's launches divided by the",
@@ -145,6 +145,6 @@ if __name__ == "__main__":
         lines.append("  LDS bank-conflict cycles per LDS instruction = %.3f" % (vals["SQ_LDS_BANK_CONFLICT"] / max(vals["SQ_INSTS_LDS"], 1)))
     if "SQ_WAIT_INST_ANY" in vals and "SQ_WAVE_CYCLES" in vals:
         lines.append("  SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES = %.3f" % (vals["SQ_WAIT_INST_ANY"] / max(vals["SQ_WAVE_CYCLES"], 1)))
-    open(out + "/r04_sq_counters_conv.txt", "w").write("\n".join(lines) + "\n")
+    open(out + "/r05_sq_counters_conv.txt", "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
     print(json.dumps(res["bunny_small_256_f64"], indent=1))

@@ -41,6 +41,6 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTI
 rocprofv3 --kernel-trace --stats -d "$OUT" -o rocker512f32 -- python3 "$R"/bench.py --no-cpu-baseline --no-also --workload rocker_512_f32 --steps 2 --warmup 1 > "$OUT/rocker512f32.log" 2>&1
 ls -la "$OUT"
 for f in bench256 bench512 pcg512 pcg512f32 pcg512rocker pcg512rockerf32 rocker512f32; do python3 "$R"/profiles/rocpd_summary.py "$OUT/${f}_results.db" "$OUT/${f}_kernel_stats.txt" > /dev/null; done
-python3 "$R"/tools/pmc_report_r04.py "$OUT" "$OUT" > "$OUT/pmc_report.log" 2>&1
+python3 "$R"/tools/pmc_report.py "$OUT" "$OUT" > "$OUT/pmc_report.log" 2>&1
 python3 "$R"/tools/timeline.py "$OUT/bench256_results.db" 60 > "$OUT/timeline_256.txt" 2>&1
 tail -3 "$OUT/bench256.log" "$OUT/pcg512.log" "$OUT/pcg512f32.log" "$OUT/pcg512rocker.log" "$OUT/pcg512rockerf32.log" | cut -c1-400
