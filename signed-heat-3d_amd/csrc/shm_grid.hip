@@ -1011,7 +1011,8 @@ struct Solver final : SolverBase {
             P.tiles_y = P.tiles_x;
             // nodes per lane (a z-column sharing dx^2 + dy^2): 4 when the grid still yields a full wave of workgroups, else 2
             const int planes = P.kk_end - P.kk_begin;
-            const bool npt4 = (long long)P.tiles_x * P.tiles_y * ((planes + 15) / 16) >= conv_grid_cap;
+            static const int npt_env = knob("SHM_TIER_NPT") ? atoi(knob("SHM_TIER_NPT")) : 0;   // A/B knob (round 5): 2 / 4 nodes per lane whatever the grid
+            const bool npt4 = npt_env ? npt_env == 4 : (long long)P.tiles_x * P.tiles_y * ((planes + 15) / 16) >= conv_grid_cap;
             // fp32: 8 nodes per lane on grids large enough, culled as two 16-plane halves (see the kernel); fp64 stays at 4 (8 needs 256 VGPRs: 57 against
             // 44 ms at 256^3).  SHM_CONV_NPT4: A/B knob, and the reference for the bit-identity check of the two shapes (tools/skip_check.py)
             const bool npt4_env = knob("SHM_CONV_NPT4") != nullptr;   // (read per launch: the check flips it inside one process)

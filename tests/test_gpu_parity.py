@@ -126,6 +126,65 @@ def test_far_tier_exponent_range_guard(shm, oracle_c, lam_scale):
 
 
 @pytest.mark.parametrize("precision", [64, 32])
+def test_tiered_kernel_hands_over_beyond_its_exponent_span(shm, oracle_c, precision):
+    """The tiered kernel puts a term's power of two into the exponent field by an integer add, each 8 x 8 x 4 block relative to its own exponent: valid while a block's
+    evaluated exponents span less than 2^-990 (Solver::tier_exponent_span_ok).  lambda x 20 on the 16^3 fixture (lambda * cell = 83: a block spans 4 x 5.2 x 83 nats)
+    is beyond that: Step 1 must run in the all-fp64 kernel (fp64 handle: no packed-fp32 pairs at all, Y to 1e-10 of the C oracle, the reference's 0/0 nodes far from every
+    source reproduced) or the classic fp32 kernel (fp32 handle: finite everywhere, directions of the fp64 oracle)."""
+    d = load_golden("bunny_small_n16")
+    n, lam, cell = int(d["n"]), float(d["lam"]) * 20.0, float(d["cell"])
+    s = shm.GridSolver(precision=precision)
+    s.set_problem(d["pos"], d["wnormal"], d["area"], lam, n, d["bbox_min"], cell)
+    s.run_conv()
+    Y = np.stack([s.get_field(k) for k in (0, 1, 2)], axis=1)
+    st = s.solve(scrub=True, allow_noconv=True, max_iters=2)
+    s.close()
+    ref = np.zeros(3 * n ** 3)
+    oracle_c.shmo_conv_normalize(n, c_(d["bbox_min"]), cell, len(d["area"]), c_(d["pos"]).reshape(-1), c_(d["wnormal"]).reshape(-1), lam, 0, n, ref)
+    ref = ref.reshape(-1, 3)
+    ok = np.isfinite(ref).all(axis=1)
+    assert ok.mean() > 0.05      # (beyond lambda r ~ 745 the reference's own sum underflows: 0/0 -- the far corners of this grid)
+    if precision == 64:
+        assert st.pairs_fp32 == 0 and st.pairs_fp64 > 0
+        assert (np.isfinite(Y).all(axis=1) == ok).all()
+        assert np.abs(Y[ok] - ref[ok]).max() < 1e-10
+    else:
+        assert np.isfinite(Y).all()
+        dots = (Y[ok] * ref[ok]).sum(axis=1)
+        assert np.median(1 - dots) < 1e-6 and np.quantile(1 - dots, 0.99) < 1e-3
+
+
+def test_opts_dual_form_and_step1_budget(shm):
+    """ABI 5: shm_opts.dual_form selects the dual solver's form (stats.cg_form says what ran; the same phi in every form), shm_opts.step1_budget moves the
+    tiers' thresholds together (a larger budget sends more pairs to the packed-fp32 tier and stays inside itself); out-of-range values are refused."""
+    d = load_golden("bunny_small_n32")
+    s = make_solver(shm, d)
+    want = {"direct": 2, "explicit_s_cg": 3, "through_grid": 0}
+    phis = {}
+    for form, cg in want.items():
+        st = s.solve(tol=1e-10, dual_form=form)
+        assert st.solver == 2 and st.cg_form == cg, (form, st.solver, st.cg_form)
+        phis[form] = s.get_phi()[0]
+        assert np.abs(phis[form] - d["phi"]).max() < 1e-7
+    assert np.abs(phis["direct"] - phis["through_grid"]).max() < 1e-8
+    st_auto = s.solve(tol=1e-10)
+    assert st_auto.cg_form == 2      # (what AUTO picks for 316 rows)
+    # the Step-1 budget
+    far = {}
+    for budget in (0.0, 1e-6, 1e-10):
+        st = s.solve(tol=1e-10, step1_budget=budget)
+        far[budget] = st.pairs_fp32 / (st.pairs_fp32 + st.pairs_fp64)
+        assert np.abs(s.get_phi()[0] - d["phi"]).max() < (1e-7 if budget < 1e-7 else 1e-5)
+    assert far[1e-6] > far[0.0] > far[1e-10]
+    for bad in (1e-2, 1e-14, -1.0):
+        with pytest.raises(shm.ShmError):
+            s.solve(step1_budget=bad)
+    with pytest.raises(KeyError):
+        s.solve(dual_form="no_such_form")
+    s.close()
+
+
+@pytest.mark.parametrize("precision", [64, 32])
 def test_step1_is_translation_invariant(shm, precision):
     """Step 1 computes in grid-centred coordinates (Solver::set_problem): a mesh far from the origin -- here the 32^3 fixture moved by (1000, -2000, 500), where
     fp32 resolves coordinates to 1e-4 only -- gives the Y of the mesh at the origin (fp64: to rounding of the fp64 differences; fp32: to fp32 rounding)."""
