@@ -1,4 +1,5 @@
-// Step 1 + 2 of the fp64 solve with error-budgeted precision tiers (gfx950, wave64).
+// Step 1 + 2 with error-budgeted precision tiers (gfx950, wave64): the fp64 solve's kernel since round 3, the fp32 solve's as well since round 5 (every kept
+// pair in the packed-fp32 body, fp32 output: conv_tiered_kernel<NPT, float, false>).
 //   reference: signed_heat_grid_solver.cpp:48-65 (mesh), :157-174 (points); yukawaPotential signed_heat_3d.cpp:45-49.
 //
 // X(x) = sum_s w_s e^{-lambda r}/r is dominated, at every node, by the handful of sources nearest to it: a source whose term is a factor
@@ -7,8 +8,8 @@
 //   far   (packed fp32 with the sub-tile's exponent offset, two nodes per v_pk_*_f32 instruction, ~3e-6 per term),
 // classified per (wave sub-tile, SOURCE) -- not per (workgroup tile, cluster of 64) as the e^-25 branch of conv_normalize_kernel was: a
 // wave owns a compact 8 x 8 x NPT block of nodes and each of its 64 lanes tests one source of a 64-source cluster against that block's
-// bounds, a ballot turns the 64 answers into two scalar masks, and the wave then walks the near mask through the fp64 body and the far
-// mask through the packed fp32 body (scalar bit scans: no divergence, no per-cluster bounding sphere in the bound).
+// bounds, a ballot turns the 64 answers into two scalar masks, every lane stages its source at its rank in its mask, and the wave then walks the dense
+// near list through the fp64 body and the dense far list through the packed fp32 body (no divergence, no per-cluster bounding sphere in the bound).
 //   far(s)  <=>  lambda (dist(b_s, box_w) - r_hi_w) > G + ln(|w_s| / |w_near|)
 // with box_w the block's bounding box, r_hi_w the distance from the block's farthest corner to the source s* nearest to its centre -- an upper
 // bound of every node's distance to its nearest source -- and w_near the weight of s*: every term of s is then below e^-G of the dominant term
@@ -27,8 +28,10 @@
 // with eps_far the calibrated relative error of a packed-fp32 term as it shows up in X (3e-6: five times the largest |dY| |X| / L1_far observed over ten data
 // files at up to 1024^3; the rounding errors of the terms are independent, their sum grows slower than L1_far).  A block with a failing node walks the
 // sources a second time and evaluates its far sources in fp64 on top of the near sums it already holds -- no packed-fp32 term is left in it.
-// What the far tier contributes to Y is bounded by eps32 * sum_far |term| / |X|; `tools/tier_budget.py` evaluates that on the host
-// and the GPU tests hold Y to the stated budget against the all-fp64 kernel (SHM_CONV_EXACT=1).
+// The GPU tests hold Y to the stated budget against the C oracle at the full sizes of BASELINE.json (planes through the measured worst nodes) and against
+// the all-fp64 kernel (shm_opts.step1_arith = EXACT_F64); shm_opts.step1_budget moves the budget (G, the test and the drop threshold together).
+// Round 5: exponent insertion by an integer add with a per-block exponent (yukawa_near), squared z offsets staged per source,
+// weights broadcast by op_sel, and a register diet (181 -> 171 with four pairs of a near source in flight) -- 16.4 -> 15.4 VALU instructions per nominal pair.
 #pragma once
 #include "shm_kernels.hip.h"
 
@@ -166,9 +169,6 @@ constexpr int kTierFill = kTierCluster * kTierChunk;
 #ifndef SHM_TIER_LDS_FETCH
 #define SHM_TIER_LDS_FETCH 1    // the next cluster's sources travel global -> LDS directly; 0: through 12 registers per lane (rounds 2-3)
 #endif
-#ifndef SHM_TIER_PRIO
-#define SHM_TIER_PRIO 0
-#endif
 #ifndef SHM_TIER_NEAR_BATCH
 #define SHM_TIER_NEAR_BATCH 4   // pairs whose e^{-lambda r}/r chains are interleaved stage by stage (round 5: all four of a lane's z-column; 2: +2.5 % Step 1)
 #endif
@@ -180,11 +180,10 @@ constexpr int kTierFill = kTierCluster * kTierChunk;
 // outside the far tier's exponent range goes through the packed-fp32 body (no L1 sums, no second pass; the few out-of-range sources keep the fp64 body), Y is
 // stored in fp32.  What the fp32 solve gains over conv_normalize_kernel<float> is the culling per (8 x 8 x NPT block, SOURCE) instead of per (8 x 8 x 32 tile,
 // cluster of 32) -- SprayBottle.pc at 256^3: 2 x -- and this kernel's cheaper far body.
+// Register budget: <= 184 (two of its waves + one wave of a set-up kernel per SIMD; tests/test_abi_and_host.py pins it from the compiler's report -- the
+// amdgpu_num_vgpr attribute is not honoured beside waves_per_eu, so the budget is kept by construction: 171 / 168 registers).
 template <int NPT, typename TY, bool CHECK>
-#ifndef SHM_TIER_VGPR_CAP
-#define SHM_TIER_VGPR_CAP 184   // two of its waves + one of a set-up kernel per SIMD
-#endif
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER_WAVES_PER_EU, SHM_TIER_WAVES_PER_EU), amdgpu_num_vgpr(SHM_TIER_VGPR_CAP))) void conv_tiered_kernel(
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER_WAVES_PER_EU, SHM_TIER_WAVES_PER_EU))) void conv_tiered_kernel(
     ConvParams P, const double* __restrict__ src /* [S][6]: pos xyz, wn xyz */, const float* __restrict__ clusters,
     const double* __restrict__ exp_tab_g /* [2048]: 2^(j/2048) */, TY* __restrict__ Y0, TY* __restrict__ Y1, TY* __restrict__ Y2,
     unsigned long long* __restrict__ counters, unsigned* __restrict__ next_unit /* [8] queue heads, zeroed before the launch */) {
@@ -201,7 +200,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
     __shared__ __attribute__((aligned(16))) float farC[kWaves][(kTierCluster + kPad) * 2];
     // the next cluster's sources travel global -> LDS directly (global_load_lds_dwordx4: three 16-byte pieces of every lane's 48-byte record, each piece
     // landing at wave base + lane * 16), not through 12 registers per lane held across the two loops: those registers are what the per-node L1 sums of the
-    // a-posteriori test now live in (the kernel must stay within 184 VGPRs for the set-up kernels to run beside it)
+    // a-posteriori test live in (round 4; the kernel must stay within 184 VGPRs for the set-up kernels to run beside it)
 #if SHM_TIER_LDS_FETCH
     __shared__ double2 raw[kWaves][3][kTierCluster];
 #endif
@@ -211,9 +210,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
     float* const tA = farA[wave];
     float* const tB = farB[wave];
     float* const tC = farC[wave];
-#if SHM_TIER_PRIO
-    __builtin_amdgcn_s_setprio(SHM_TIER_PRIO);
-#endif
     for (int a = threadIdx.x; a < 2048; a += kBlock) {
         uint2v tv = __builtin_bit_cast(uint2v, exp_tab_g[a]);
         tv.y -= (unsigned)a << 9;
