@@ -235,10 +235,16 @@ shm_status shm_grid_apply_projector(shm_solver* s, double* v);
 /* out = M^-1 v with the DCT preconditioner alone (no projection); v,out: n^3 doubles on the host (world==1). */
 shm_status shm_grid_apply_preconditioner(shm_solver* s, const double* v, double* out);
 
-/* --- isosurface of the resident phi (headless stand-in for the demo's Polyscope marching cubes, src/main.cpp:116-128,167-191):
- * marching tetrahedra (Kuhn split), inside = phi < isovalue, normals towards increasing phi, vertices welded per grid edge.
- * Covers the cells whose lower z-plane this process owns.  Call shm_grid_isosurface, size the buffers, then _get_. */
+/* --- isosurface of the resident phi (headless stand-in for the demo's contour, src/main.cpp:116-128,167-191: Polyscope's marching cubes on the node
+ * scalar quantity, setIsosurfaceLevel + registerIsosurfaceAsMesh).  inside = phi < isovalue, normals towards increasing phi, one vertex per cut grid edge
+ * (linear interpolation), welded across cells.  Covers the cells whose lower z-plane this process owns.  Call shm_grid_isosurface, size the buffers, then _get_.
+ *   SHM_ISO_MARCHING_CUBES (what shm_grid_isosurface runs, round 5): 256-case table, ambiguous faces resolved per face so that neighbouring cells agree
+ *                          (watertight; csrc/shm_mc_table.h, generated by tools/gen_mc_table.py)
+ *   SHM_ISO_MARCHING_TETS  (rounds 1-4): Kuhn split of every cell into six tetrahedra; also watertight, about 2.3x the triangles, extra vertices on the
+ *                          face and body diagonals */
+enum { SHM_ISO_MARCHING_CUBES = 0, SHM_ISO_MARCHING_TETS = 1 };
 shm_status shm_grid_isosurface(shm_solver* s, double isovalue, int64_t* n_vertices, int64_t* n_triangles);
+shm_status shm_grid_isosurface_ex(shm_solver* s, double isovalue, int32_t method, int64_t* n_vertices, int64_t* n_triangles);
 shm_status shm_grid_get_isosurface(shm_solver* s, double* vertices /* [3*nv] */, int64_t* triangles /* [3*nt] */);
 
 /* --- multi-GPU bootstrap ------------------------------------------------------------------------ */

@@ -442,7 +442,7 @@ struct SolverBase {
     virtual void apply_projector(double*) = 0;
     virtual void apply_preconditioner(const double*, double*) = 0;
     virtual void get_schur(double*, int32_t*) = 0;
-    virtual void isosurface(double, int64_t*, int64_t*) = 0;
+    virtual void isosurface(double, int, int64_t*, int64_t*) = 0;
     virtual void get_isosurface(double*, int64_t*) = 0;
 };
 
@@ -3719,8 +3719,10 @@ struct Solver final : SolverBase {
     std::vector<double> iso_vertices;
     std::vector<int64_t> iso_triangles;
 
-    void isosurface(double iso, int64_t* nv, int64_t* nt) override {
+    void isosurface(double iso, int method, int64_t* nv, int64_t* nt) override {
         need_problem();
+        if (method != SHM_ISO_MARCHING_CUBES && method != SHM_ISO_MARCHING_TETS) throw Error(SHM_ERR_INVALID, fmt("isosurface: unknown method %d", method));
+        const bool mc = method == SHM_ISO_MARCHING_CUBES;
         if (!have_phi) throw Error(SHM_ERR_STATE, "no phi: shm_grid_solve has not completed");
         HIPCHK(hipSetDevice(cfg.device));
         halo_exchange(ARR_Q);  // phi lives in q; cells of the top owned plane need the plane above
@@ -3738,8 +3740,10 @@ struct Solver final : SolverBase {
             HIPCHK(hipMemsetAsync(counter.p, 0, sizeof(unsigned long long), stream));
             const size_t ncells = (size_t)(n - 1) * (n - 1) * (size_t)std::max(0, std::min(sl.nzl, n - 1 - sl.k0));
             const int grid = grid_for(ncells, 8192);
-            hipLaunchKernelGGL((iso_kernel<T, false>), dim3(grid), dim3(kBlock), 0, stream, P, sl.q.p, counter.p, (double*)nullptr, (unsigned long long*)nullptr,
-                               (unsigned long long*)nullptr, 0ULL);
+            if (mc) hipLaunchKernelGGL((iso_mc_kernel<T, false>), dim3(grid), dim3(kBlock), 0, stream, P, sl.q.p, counter.p, (double*)nullptr, (unsigned long long*)nullptr,
+                                       (unsigned long long*)nullptr, 0ULL);
+            else hipLaunchKernelGGL((iso_kernel<T, false>), dim3(grid), dim3(kBlock), 0, stream, P, sl.q.p, counter.p, (double*)nullptr, (unsigned long long*)nullptr,
+                                    (unsigned long long*)nullptr, 0ULL);
             unsigned long long ntri = 0;
             HIPCHK(hipMemcpyAsync(&ntri, counter.p, sizeof ntri, hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
@@ -3748,7 +3752,8 @@ struct Solver final : SolverBase {
             keys.alloc(ntri * 3);
             sortk.alloc(ntri);
             HIPCHK(hipMemsetAsync(counter.p, 0, sizeof(unsigned long long), stream));
-            hipLaunchKernelGGL((iso_kernel<T, true>), dim3(grid), dim3(kBlock), 0, stream, P, sl.q.p, counter.p, pos.p, keys.p, sortk.p, ntri);
+            if (mc) hipLaunchKernelGGL((iso_mc_kernel<T, true>), dim3(grid), dim3(kBlock), 0, stream, P, sl.q.p, counter.p, pos.p, keys.p, sortk.p, ntri);
+            else hipLaunchKernelGGL((iso_kernel<T, true>), dim3(grid), dim3(kBlock), 0, stream, P, sl.q.p, counter.p, pos.p, keys.p, sortk.p, ntri);
             HIPCHK(hipGetLastError());
             std::vector<double> hpos(ntri * 9);
             std::vector<unsigned long long> hkeys(ntri * 3), hsort(ntri);
@@ -3995,7 +4000,10 @@ shm_status shm_grid_apply_preconditioner(shm_solver* s, const double* v, double*
 }
 
 shm_status shm_grid_isosurface(shm_solver* s, double isovalue, int64_t* n_vertices, int64_t* n_triangles) {
-    return guard(s, [&] { s->impl->isosurface(isovalue, n_vertices, n_triangles); });
+    return guard(s, [&] { s->impl->isosurface(isovalue, SHM_ISO_MARCHING_CUBES, n_vertices, n_triangles); });
+}
+shm_status shm_grid_isosurface_ex(shm_solver* s, double isovalue, int32_t method, int64_t* n_vertices, int64_t* n_triangles) {
+    return guard(s, [&] { s->impl->isosurface(isovalue, method, n_vertices, n_triangles); });
 }
 shm_status shm_grid_get_isosurface(shm_solver* s, double* vertices, int64_t* triangles) {
     return guard(s, [&] { s->impl->get_isosurface(vertices, triangles); });

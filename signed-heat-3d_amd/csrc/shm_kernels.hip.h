@@ -11,6 +11,8 @@
 
 #include <type_traits>
 
+#include "shm_mc_table.h"
+
 namespace shm {
 
 constexpr int kWave = 64;       // CDNA wavefront
@@ -2088,6 +2090,70 @@ __global__ __launch_bounds__(kBlock) void iso_kernel(IsoParams P, const T* __res
                     tri_sort[slot] = gnode * 16ULL + (unsigned long long)(t * 2 + tr);
                 }
             }
+        }
+    }
+    if (!EMIT) {
+        mycount = block_sum(mycount, red);
+        if (threadIdx.x == 0 && mycount > 0.) atomicAdd(counter, (unsigned long long)mycount);
+    }
+}
+
+// Marching cubes on the same cells (what the demo's contour runs, src/main.cpp:121-124, through Polyscope): the case table of shm_mc_table.h (generated by
+// tools/gen_mc_table.py: ambiguous faces resolved by the face's own flags, so the surface is watertight), one surface vertex per cut grid edge by linear
+// interpolation from the edge's lower node, triangles oriented towards increasing phi.  Same two passes, buffers, welding keys and sort keys as iso_kernel.
+template <typename T, bool EMIT>
+__global__ __launch_bounds__(kBlock) void iso_mc_kernel(IsoParams P, const T* __restrict__ phi /* ghost layout */, unsigned long long* __restrict__ counter,
+                                                        double* __restrict__ tri_pos /* [cap][9] */, unsigned long long* __restrict__ tri_keys /* [cap][3] */,
+                                                        unsigned long long* __restrict__ tri_sort /* [cap] */, unsigned long long cap) {
+    __shared__ double red[8];
+    const int n = P.n, nc = n - 1;
+    const size_t plane = (size_t)n * n;
+    const int kend = min(P.nzl, n - 1 - P.k0);
+    const size_t ncells = (size_t)nc * nc * (size_t)max(kend, 0);
+    double mycount = 0.;
+    for (size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x; c < ncells; c += (size_t)gridDim.x * kBlock) {
+        const int kk = (int)(c / ((size_t)nc * nc));
+        const int rem = (int)(c - (size_t)kk * nc * nc);
+        const int j = rem / nc, i = rem - j * nc;
+        const size_t base = (size_t)(kk + 1) * plane + (size_t)j * n + i;
+        double v[8];
+        int inside = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            v[q] = (double)phi[base + (q & 1) + ((q >> 1) & 1) * (size_t)n + ((q >> 2) & 1) * plane];
+            inside |= (v[q] < P.iso ? 1 : 0) << q;
+        }
+        const int nt = kMcCount[inside];
+        if (nt == 0) continue;
+        if (!EMIT) {
+            mycount += nt;
+            continue;
+        }
+        const int k = P.k0 + kk;
+        const unsigned long long gnode = (unsigned long long)i + (unsigned long long)j * n + (unsigned long long)k * plane;
+        for (int tr = 0; tr < nt; tr++) {
+            const unsigned long long slot = atomicAdd(counter, 1ULL);
+            if (slot >= cap) continue;
+            for (int a = 0; a < 3; a++) {
+                const int e = kMcTris[inside][3 * tr + a];
+                const int qa = kMcEdge[e][0], qb = kMcEdge[e][1];   // qa < qb: the lower node of the grid edge first, whichever side is inside
+                double va = v[0], vb = v[0];
+#pragma unroll
+                for (int q = 1; q < 8; q++) {   // (selects instead of a dynamically indexed register array)
+                    va = q == qa ? v[q] : va;
+                    vb = q == qb ? v[q] : vb;
+                }
+                const double tt = (P.iso - va) / (vb - va);
+                const int ax = qa ^ qb;   // 1, 2 or 4: the edge's axis
+                const double pa[3] = {(i + (qa & 1)) * P.cell + P.bbox_min[0], (j + ((qa >> 1) & 1)) * P.cell + P.bbox_min[1], (k + ((qa >> 2) & 1)) * P.cell + P.bbox_min[2]};
+                tri_pos[slot * 9 + a * 3 + 0] = pa[0] + (ax == 1 ? tt * P.cell : 0.);
+                tri_pos[slot * 9 + a * 3 + 1] = pa[1] + (ax == 2 ? tt * P.cell : 0.);
+                tri_pos[slot * 9 + a * 3 + 2] = pa[2] + (ax == 4 ? tt * P.cell : 0.);
+                const unsigned long long ga = gnode + (qa & 1) + ((qa >> 1) & 1) * (unsigned long long)n + ((qa >> 2) & 1) * plane;
+                const unsigned long long gb = gnode + (qb & 1) + ((qb >> 1) & 1) * (unsigned long long)n + ((qb >> 2) & 1) * plane;
+                tri_keys[slot * 3 + a] = ga << 32 | gb;
+            }
+            tri_sort[slot] = gnode * 16ULL + (unsigned long long)tr;
         }
     }
     if (!EMIT) {

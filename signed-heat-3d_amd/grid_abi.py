@@ -19,7 +19,7 @@ STATUS_NAMES = {0: "SHM_OK", 1: "SHM_ERR_INVALID", 2: "SHM_ERR_HIP", 3: "SHM_ERR
 # every symbol include/shm_grid.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = ["shm_grid_owned_planes", "shm_grid_create", "shm_grid_destroy", "shm_grid_last_error", "shm_grid_abi_version", "shm_grid_set_problem",
                "shm_grid_solve", "shm_grid_get_phi", "shm_grid_compute_distance", "shm_grid_run_conv", "shm_grid_run_conv_arith", "shm_grid_run_divergence",
-               "shm_grid_get_field", "shm_grid_get_field_planes", "shm_grid_apply_laplacian", "shm_grid_get_constraints", "shm_grid_get_schur", "shm_grid_apply_projector", "shm_grid_apply_preconditioner", "shm_grid_isosurface", "shm_grid_get_isosurface",
+               "shm_grid_get_field", "shm_grid_get_field_planes", "shm_grid_apply_laplacian", "shm_grid_get_constraints", "shm_grid_get_schur", "shm_grid_apply_projector", "shm_grid_apply_preconditioner", "shm_grid_isosurface", "shm_grid_isosurface_ex", "shm_grid_get_isosurface",
                "shm_comm_unique_id", "shm_plan_slab", "shm_step1_plane_weights", "shm_plan_slab_weighted"]
 
 
@@ -98,6 +98,7 @@ def load_library():
     lib.shm_grid_apply_projector.argtypes = [C.c_void_p, C.c_void_p]
     lib.shm_grid_apply_preconditioner.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.shm_grid_isosurface.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.shm_grid_isosurface_ex.argtypes = [C.c_void_p, C.c_double, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.shm_grid_get_isosurface.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.shm_grid_owned_planes.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.shm_comm_unique_id.argtypes = [C.c_void_p]
@@ -281,10 +282,16 @@ class GridSolver:
         self._chk(self._lib.shm_grid_apply_preconditioner(self._h, v.ctypes.data, out.ctypes.data))
         return out
 
-    def isosurface(self, isovalue=0.0):
-        """Marching-tetrahedra isosurface of the resident phi: (vertices [nv,3] float64, triangles [nt,3] int64)."""
+    ISO_METHOD = {"marching_cubes": 0, "marching_tets": 1}
+
+    def isosurface(self, isovalue=0.0, method="marching_cubes"):
+        """Isosurface of the resident phi: (vertices [nv,3] float64, triangles [nt,3] int64).  method: "marching_cubes" (the demo's contour,
+        src/main.cpp:121-124) or "marching_tets" (Kuhn split)."""
         nv, nt = C.c_int64(), C.c_int64()
-        self._chk(self._lib.shm_grid_isosurface(self._h, float(isovalue), C.byref(nv), C.byref(nt)))
+        if method == "marching_cubes":
+            self._chk(self._lib.shm_grid_isosurface(self._h, float(isovalue), C.byref(nv), C.byref(nt)))
+        else:
+            self._chk(self._lib.shm_grid_isosurface_ex(self._h, float(isovalue), self.ISO_METHOD[method], C.byref(nv), C.byref(nt)))
         V = np.empty((nv.value, 3), dtype=np.float64)
         F = np.empty((nt.value, 3), dtype=np.int64)
         self._chk(self._lib.shm_grid_get_isosurface(self._h, V.ctypes.data, F.ctypes.data))

@@ -37,7 +37,7 @@ class SignedHeatGridSolver {
     bool VERBOSE = true;
 
     // Headless stand-in for the demo's contour()/export path (src/main.cpp:116-128,167-191, done there by Polyscope's marching
-    // cubes): isosurface of the phi of the LAST computeDistance() call, extracted on the device (marching tetrahedra).
+    // cubes): isosurface of the phi of the LAST computeDistance() call, extracted on the device (marching cubes: shm_grid_isosurface).
     void isosurface(double isoval, std::vector<Vector3>& vertices, std::vector<std::array<size_t, 3>>& faces);
 
     // Read-only views of the grid block the reference keeps private (used by the CLI / tests / the Polyscope

@@ -259,3 +259,73 @@ def test_weighted_slab_plan_is_a_partition_and_balances_its_own_weights(shm):
     # degenerate weights: the equal-plane plan (up to the granule)
     assert [shm.plan_slab_weighted(64, 4, s, np.ones(64), 4) for s in range(4)] == [(0, 16), (16, 32), (32, 48), (48, 64)]
     assert [shm.plan_slab_weighted(64, 4, s, np.zeros(64), 4) for s in range(4)] == [(0, 16), (16, 32), (32, 48), (48, 64)]
+
+
+# ---- marching-cubes case table (device kernel: iso_mc_kernel, checked against tests/iso_ref.py in test_gpu_parity.py) ----------------------
+def _mesh_is_closed_and_oriented(tris):
+    from collections import Counter
+    e = Counter()
+    for a, b, c in tris:
+        for u, v in ((a, b), (b, c), (c, a)):
+            e[(u, v)] += 1
+    return all(cnt == 1 and e.get((v, u), 0) == 1 for (u, v), cnt in e.items())
+
+
+def test_marching_cubes_table_is_the_generators_and_watertight():
+    """csrc/shm_mc_table.h is the output of tools/gen_mc_table.py (regenerated here and compared byte for byte), and the construction does what it says:
+    on random sign patterns -- every one of the 256 cases occurs, ambiguous faces and all -- the surface of a field that is positive on the boundary is closed,
+    every edge used exactly once in each direction (no cracks between cells, consistent orientation), and it encloses the inside nodes."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_mc_table", os.path.join(ROOT, "tools", "gen_mc_table.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    T = g.build_table()
+    assert g.check_table(T) == 5 and sum(len(t) for t in T) == 820
+    assert open(os.path.join(ROOT, "signed-heat-3d_amd", "csrc", "shm_mc_table.h")).read() == g.header(T)
+    for c in range(256):   # complementary cases cut the same edges; a case and its mirror image in x have the same number of triangles
+        assert {e for t in T[c] for e in t} == {e for t in T[255 - c] for e in t}
+        mirrored = sum(((c >> q) & 1) << (q ^ 1) for q in range(8))
+        assert len(T[c]) == len(T[mirrored])
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from iso_ref import marching_cubes
+    rng = np.random.default_rng(5)
+    seen = set()
+    for n in (7, 12, 14):
+        phi = rng.standard_normal((n, n, n))
+        phi[0, :, :] = phi[-1, :, :] = phi[:, 0, :] = phi[:, -1, :] = phi[:, :, 0] = phi[:, :, -1] = 1.0 + rng.random()
+        pts, tris = marching_cubes(phi.ravel(), n, np.zeros(3), 1.0, 0.0)
+        assert len(tris) > 50 and _mesh_is_closed_and_oriented(tris)
+        inside = phi < 0
+        case = np.zeros((n - 1, n - 1, n - 1), dtype=np.int32)
+        for q in range(8):
+            case |= inside[(q >> 2) & 1:n - 1 + ((q >> 2) & 1), (q >> 1) & 1:n - 1 + ((q >> 1) & 1), (q & 1):n - 1 + (q & 1)].astype(np.int32) << q
+        seen |= set(case.ravel().tolist())
+        # normals towards increasing phi: the closed surface around the inside nodes has positive signed volume
+        P = np.array([pts[k] for t in tris for k in t]).reshape(-1, 3, 3)
+        vol = np.einsum("ij,ij->i", P[:, 0], np.cross(P[:, 1], P[:, 2])).sum() / 6.0
+        assert vol > 0
+    assert len(seen) >= 250, len(seen)
+
+
+def test_marching_cubes_reference_on_an_analytic_sphere():
+    """The python restatement the device kernel is held to, on phi = |x| - r: closed, oriented outwards, area and volume of the sphere to discretisation accuracy,
+    every vertex on the sphere to O(h^2), and fewer triangles than marching tetrahedra on the same field."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from iso_ref import marching_cubes, marching_tets
+    n, r = 24, 0.8
+    h = 2.0 / (n - 1)
+    ax = -1.0 + h * np.arange(n)
+    Z, Y, X = np.meshgrid(ax, ax, ax, indexing="ij")
+    phi = np.sqrt(X * X + Y * Y + Z * Z) - r
+    pts, tris = marching_cubes(phi.ravel(), n, np.array([-1.0, -1.0, -1.0]), h, 0.0)
+    assert _mesh_is_closed_and_oriented(tris)
+    V = np.array(list(pts.values()))
+    assert np.abs(np.linalg.norm(V, axis=1) - r).max() < 0.6 * h * h / r
+    P = np.array([pts[k] for t in tris for k in t]).reshape(-1, 3, 3)
+    vol = np.einsum("ij,ij->i", P[:, 0], np.cross(P[:, 1], P[:, 2])).sum() / 6.0
+    area = 0.5 * np.linalg.norm(np.cross(P[:, 1] - P[:, 0], P[:, 2] - P[:, 0]), axis=1).sum()
+    assert abs(vol - 4.0 / 3.0 * np.pi * r ** 3) < 0.02 * vol and abs(area - 4 * np.pi * r * r) < 0.02 * area
+    nrm = np.cross(P[:, 1] - P[:, 0], P[:, 2] - P[:, 0])
+    assert (np.einsum("ij,ij->i", nrm, P.mean(axis=1)) > 0).all()      # outwards = towards increasing phi
+    _, tets = marching_tets(phi.ravel(), n, np.array([-1.0, -1.0, -1.0]), h, 0.0)
+    assert len(tris) < 0.6 * len(tets)

@@ -1180,7 +1180,7 @@ def test_headless_cli_reproduces_golden(tmp_path):
     assert p.returncode == 0 and "Isosurface written to" in p.stderr, p.stderr
     lines = open(obj).read().split("\n")
     nv, nf = sum(l.startswith("v ") for l in lines), sum(l.startswith("f ") for l in lines)
-    assert nv > 1000 and nf > 2 * nv - 100
+    assert nv > 500 and abs(nf - (2 * nv - 4)) <= 8          # marching cubes: closed surface(s) of genus 0 (F = 2V - 4 per component)
     # --f (fastIntegration)
     p = subprocess.run([exe, os.path.join(ROOT, "data", "bunny_small.obj"), "--g", "--f", "--h", "1", "--out", out], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
@@ -1189,15 +1189,31 @@ def test_headless_cli_reproduces_golden(tmp_path):
 
 
 # ---- isosurface extraction ------------------------------------------------------------------------
+@pytest.mark.parametrize("method", ["marching_cubes", "marching_tets"])
 @pytest.mark.parametrize("slabs", [1, 3])
-def test_isosurface_matches_python_marching_tets(shm, slabs):
-    from iso_ref import marching_tets
+def test_isosurface_matches_python_restatement(shm, slabs, method):
+    """iso_mc_kernel (the demo's contour: Polyscope marching cubes, src/main.cpp:121-124) and iso_kernel (marching tetrahedra) against tests/iso_ref.py:
+    same vertices, same triangles (as welded-vertex triples, orientation included), watertight, oriented towards increasing phi."""
+    import iso_ref
     d = load_golden("bunny_small_n32")
     s = make_solver(shm, d, local_slabs=slabs)
     s.solve(tol=1e-10, solver="primal", precond="none" if slabs == 3 else "auto")
     phi, _ = s.get_phi()
-    V, F = s.isosurface(0.0)
-    pts, tris = marching_tets(phi, 32, d["bbox_min"], float(d["cell"]), 0.0)
+    V, F = s.isosurface(0.0, method=method)
+    pts, tris = getattr(iso_ref, method)(phi, 32, d["bbox_min"], float(d["cell"]), 0.0)
+    if method == "marching_cubes":
+        Vd, Fd = s.isosurface(0.0)
+        assert np.array_equal(Vd, V) and np.array_equal(Fd, F)      # the default entry point is marching cubes
+        # triangle by triangle: positions of the three corners, rotated to start at the smallest, as a sorted list
+        def canon(T):   # noqa: E306
+            out = []
+            for t in T:
+                k = min(range(3), key=lambda a: tuple(t[a]))
+                out.append(np.concatenate([t[(k + a) % 3] for a in range(3)]))
+            return np.array(sorted(map(tuple, np.round(np.array(out), 11))))
+        got = canon(V[F])
+        ref = canon(np.array([[pts[k] for k in t] for t in tris]))
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-10
     assert len(V) == len(pts) and len(F) == len(tris)
     ref = np.array(sorted(map(tuple, np.round(np.array(list(pts.values())), 12))))
     got = np.array(sorted(map(tuple, np.round(V, 12))))
@@ -1238,6 +1254,12 @@ def test_isosurface_of_a_sphere_known_answer(shm):
     p0, p1, p2 = V[F[:, 0]], V[F[:, 1]], V[F[:, 2]]
     area = 0.5 * np.linalg.norm(np.cross(p1 - p0, p2 - p0), axis=1).sum()
     assert abs(area - 4 * math.pi) < 0.08 * 4 * math.pi
+    assert len(F) == 2 * len(V) - 4                                         # one closed genus-0 surface
+    Vt, Ft = s.isosurface(0.0, method="marching_tets")
+    assert len(Ft) == 2 * len(Vt) - 4 and len(F) < 0.6 * len(Ft)            # the same surface with fewer triangles
+    import ctypes as C
+    nv, nt = C.c_int64(), C.c_int64()
+    assert s._lib.shm_grid_isosurface_ex(s._h, 0.0, 7, C.byref(nv), C.byref(nt)) == 1   # SHM_ERR_INVALID: unknown method
 
 
 @pytest.mark.skipif(not __import__("os").environ.get("SHM_BIG_TESTS"), reason="1024^3 (~100 GB of HBM, minutes): set SHM_BIG_TESTS=1")
