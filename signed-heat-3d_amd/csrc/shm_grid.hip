@@ -461,6 +461,9 @@ struct Slab {
     DevArray<double> ent_coef, nent_coef;
     DevArray<ShiftItem> shift_items;
     DevArray<double> dv;  // dual solver m-vectors: mu, r, p, z, t1, t2, g (7 x mp)
+    DevArray<double> div_partials;   // per-workgroup sums of b written by the divergence kernel (div_sum_blocks of them; 0: not available, sum b with sum_kernel)
+    int div_sum_blocks = 0;
+    DevArray<T> touched_save;   // the touched nodes' entries of b while b - A^T mu stands in their place (final stage of the dual solve)
     DevArray<T> W1, W2;  // DCT work arrays (precision TP == T); W2 only with several slabs (packed transposes)
     DevArray<T> S1, S2, S4;  // sparse-sweep buffers of the dual solver's per-iteration solve (single slab)
     DevArray<int> act_x, act_y;  // active tiles of the x sweeps / y sweeps
@@ -569,7 +572,7 @@ struct Solver final : SolverBase {
     std::vector<int> h_rowX;
     bool have_S = false;
     bool dual_direct_requested = false, dual_direct = false;   // direct dual solve: S^-1 (Sinv) instead of G^-1; requested by solve(), decided in build_constraints()
-    DevArray<double> Sinv;
+    DevArray<double> Sinv, Sinv_ones /* S^-1 1: the border of the direct solve, formed once per set-up behind the inversion */;
     // s_setprio(3) in the set-up kernels that share the SIMDs with the tiered Step 1: they are short and on the critical path when Step 1 is (64^3 ... 256^3, thin
     // slabs of a multi-GPU run); where Step 1 outlasts the set-up several times over the raised priority only costs Step 1 issue slots at the wrong moments
     // (512^3: 198.8 -> 196-197 ms, bunny.pc 512^3: 106.0 -> 104-105 ms without it; 128^3: 6.2 -> 7.7 ms, hence the switch).  Decided per solve in build_constraints().
@@ -1160,6 +1163,7 @@ struct Solver final : SolverBase {
             if (classic || vec == 1) {   // (n not a multiple of the vector width: scalar kernel)
                 hipLaunchKernelGGL((divergence_kernel<T>), dim3((unsigned)((n + kBlock - 1) / kBlock), (unsigned)n, (unsigned)sl.nzl), dim3(kBlock), 0, stream, sl.gp,
                                    sl.Y0.p, sl.Y1.p, sl.Y2.p, sl.r.p, scrub);
+                sl.div_sum_blocks = 0;
                 continue;
             }
             constexpr int V = vec_width<T>();
@@ -1173,8 +1177,10 @@ struct Solver final : SolverBase {
             static const int zc_env = knob("SHM_DIV_ZC") ? atoi(knob("SHM_DIV_ZC")) : 0;   // A/B knob
             if (zc_env > 0) ZC = zc_env;
             const unsigned nblk = (unsigned)((long long)xchunks * rowgroups * ((sl.nzl + ZC - 1) / ZC));
+            sl.div_partials.alloc(nblk);
+            sl.div_sum_blocks = (int)nblk;
             hipLaunchKernelGGL((divergence_march_kernel<T, V>), dim3(nblk), dim3(kBlock), 0, stream, sl.gp, LX, xchunks, rowgroups, ZC, sl.Y0.p, sl.Y1.p, sl.Y2.p,
-                               sl.r.p, scrub);
+                               sl.r.p, scrub, sl.div_partials.p);
         }
         HIPCHK(hipGetLastError());
         have_div = true;
@@ -1580,6 +1586,7 @@ struct Solver final : SolverBase {
             sl.red.alloc((size_t)m + 1);
             sl.u.alloc((size_t)std::max(m, 1));
             sl.dv.alloc((size_t)7 * std::max(mp, 64));
+            sl.touched_save.alloc((size_t)std::max(sl.n_touched, 1));
         }
         lap("slab uploads");
         if (total_slabs == 1 && fft_available() && need_node_tables) build_active_tiles(unode);   // (the sparse sweeps exist for the FFT transforms only)
@@ -2194,6 +2201,9 @@ struct Solver final : SolverBase {
             HIPCHK(hipMemcpyAsync(Sinv.p, Sdense.p, (size_t)mp * mp * sizeof(double), hipMemcpyDeviceToDevice, st));
             if (mp > m) hipLaunchKernelGGL(set_diagonal_kernel, dim3((unsigned)((mp - m + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, Sinv.p, mp, m, mp, 1.0);   // identity tail
             enqueue_gj_invert(Sinv.p, mp, true);
+            Sinv_ones.alloc((size_t)2 * mp);
+            hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, Sinv_ones.p + mp, m, 1.0);
+            hipLaunchKernelGGL(ginv_matvec_kernel<double>, dim3(m), dim3(kBlock), 0, st, m, mp, Sinv.p, Sinv_ones.p + mp, Sinv_ones.p);
         } else {
             e_sch_done->record(st);
             HIPCHK(hipStreamWaitEvent(stream2, e_sch_done->e, 0));   // "set-up done" on stream2 (what the solve waits for) now includes S
@@ -2655,12 +2665,15 @@ struct Solver final : SolverBase {
             default: return sl.q.p;
         }
     }
-    int launch_precond(bool dot, int in_sel = ARR_R, int out_sel = ARR_Z) {
-        if (gemm_dct()) return launch_precond_gemm(dot, in_sel, out_sel);
+    int launch_precond(bool dot, int in_sel = ARR_R, int out_sel = ARR_Z, double scale = 1.0 /* out = scale * K^+ in (transform sweeps only: it rides in the spectral step's normalisation) */) {
+        if (gemm_dct()) {
+            if (scale != 1.0) throw Error(SHM_ERR_INVALID, "launch_precond: no scale on the dense-product transforms");
+            return launch_precond_gemm(dot, in_sel, out_sel);
+        }
         const long long nn = n, plane = (long long)n * n;
         const int P = total_slabs;
         const int nzl = n / P, nyl = n / P;  // planes per slab == pencil rows per slab (P | n)
-        const double inv8 = 8.0 / ((double)n * n * n);
+        const double inv8 = scale * 8.0 / ((double)n * n * n);
         const int kDctLines = dct_lines_for(log2n, (int)sizeof(TP));                      // real lines per tile (16, or 8 from n = 512 on)
         const int tiles_slab = (int)((long long)nzl * nn / kDctLines);  // tiles of one slab for the x and y sweeps
         int log2nyl = 0;
@@ -2887,10 +2900,10 @@ struct Solver final : SolverBase {
                                    sl.ent_coef.p, arr(sl, sel), sl.partials.p, 0, sl.red.p);
             allreduce(0, 1 + m);
         };
-        auto scatter = [&](int vec, int sel, int accumulate) {  // arr(sel) (+)= A^T v
+        auto scatter = [&](int vec, int sel, int accumulate, double scale = 1.0, bool save = false) {  // arr(sel) (+)= scale A^T v
             for (Slab<T>& sl : slabs)
                 hipLaunchKernelGGL((scatter_rows_to_nodes_kernel<T>), dim3((sl.n_touched + kBlock - 1) / kBlock + 1), dim3(kBlock), 0, stream, sl.n_touched,
-                                   sl.node_id.p, sl.node_ptr.p, sl.ent_row.p, sl.nent_coef.p, mv(sl, vec), accumulate, arr(sl, sel));
+                                   sl.node_id.p, sl.node_ptr.p, sl.ent_row.p, sl.nent_coef.p, mv(sl, vec), accumulate, arr(sl, sel), scale, save ? sl.touched_save.p : (T*)nullptr);
         };
         auto precondition = [&](int init) {  // z = Pm(G^-1 B G^-1 r); p = z (+ beta p)
             for (Slab<T>& sl : slabs) {
@@ -2905,6 +2918,10 @@ struct Solver final : SolverBase {
         gather(ARR_Z);
         for (Slab<T>& sl : slabs) {
             HIPCHK(hipMemcpyAsync(mv(sl, V_G), sl.red.p + 1, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            if (sl.div_sum_blocks > 0) {   // the divergence kernel summed b as it wrote it (round 5: one pass over the grid less)
+                hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, stream, sl.div_partials.p, sl.div_sum_blocks, sl.pq.p);
+                continue;
+            }
             const int g = grid_for(sl.nown, 1024);
             hipLaunchKernelGGL((sum_kernel<T>), dim3(g), dim3(kBlock), 0, stream, sl.nown, sl.plane, sl.r.p, sl.partials.p);
             hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, stream, sl.partials.p, g, sl.pq.p);
@@ -2912,11 +2929,12 @@ struct Solver final : SolverBase {
         allreduce(1, 1);
         for (Slab<T>& sl : slabs) {
             hipLaunchKernelGGL(dual_init_mu_kernel, dim3(1), dim3(kDualBlock), 0, stream, m, sl.pq.p, mv(sl, V_MU), sl.sc.p);
-            HIPCHK(hipMemsetAsync(sl.p.p, 0, sl.ntot * sizeof(T), stream));  // w = A^T nu lives in p: zero outside the touched nodes
         }
         // ---- r = Pm(g - S mu), z, p
         const bool sparse_ok = total_slabs == 1 && slabs[0].n_act_x > 0 && !knob("SHM_DENSE_DCT");
         const bool dense_S = have_S && total_slabs == 1 && !comm;   // explicit S (shm_schur.hip.h): one dense mat-vec instead of scatter, five sweeps, gather
+        if (!dense_S)
+            for (Slab<T>& sl : slabs) HIPCHK(hipMemsetAsync(sl.p.p, 0, sl.ntot * sizeof(T), stream));  // w = A^T nu lives in p: zero outside the touched nodes
         auto apply_S = [&](int vec) {   // red[1..m] = S v
             Slab<T>& sl = slabs[0];
             hipLaunchKernelGGL(ginv_matvec_kernel<double>, dim3(m), dim3(kBlock), 0, stream, m, mp, Sdense.p, mv(sl, vec), sl.red.p + 1);
@@ -2940,15 +2958,39 @@ struct Solver final : SolverBase {
         int nsamples = 0, it = 0;
         double rr0 = 0., rr = 0.;
         bool converged = false, breakdown = false;
+        // ---- x = K^+ (A^T mu - b)   (the additive constant cancels in the shift), shift, phi
+        // Transform sweeps: b - A^T mu is formed IN PLACE on the touched nodes of r and the sign rides in the spectral normalisation (-K^+ (b - A^T mu): bit for bit
+        // the same numbers, floating-point subtraction being sign-symmetric), then the touched nodes get b back exactly.  (Rounds 2-4 wrote -b into q with a
+        // whole-grid kernel first: 56 us of the 0.8 ms solve phase at 256^3.)
+        auto finish = [&]() {
+            if (gemm_dct()) {
+                for (Slab<T>& sl : slabs)
+                    hipLaunchKernelGGL((negate_kernel<T>), dim3(grid_for(sl.ntot, 4096)), dim3(kBlock), 0, stream, sl.ntot, sl.r.p, sl.q.p);
+                scatter(V_MU, ARR_Q, 1);
+                launch_precond(false, ARR_Q, ARR_X);
+            } else {
+                scatter(V_MU, ARR_R, 1, -1.0, true);
+                launch_precond(false, ARR_R, ARR_X, -1.0);
+                for (Slab<T>& sl : slabs)
+                    hipLaunchKernelGGL((restore_nodes_kernel<T>), dim3((sl.n_touched + kBlock - 1) / kBlock + 1), dim3(kBlock), 0, stream, sl.n_touched, sl.node_id.p,
+                                       sl.touched_save.p, sl.r.p);
+            }
+            gather(ARR_X);  // A x0: constant over the rows at convergence; its mean is the KKT solution's additive constant
+            for (Slab<T>& sl : slabs) hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, stream, sl.red.p + 1, m, sl.sc.p + SC_AXSUM);
+            e_pcg.record(stream);
+            launch_shift_and_phi();
+            e_end.record(stream);
+            HIPCHK(hipMemcpyAsync(h_pinned, slabs[0].sc.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+        };
+        bool finished = false;
         if (direct) {
             // Direct solve of the bordered system [[S, 1], [1^T, 0]] [delta; c] = [r; 0] for the correction of mu_0 (whose sum is already sum(b)):
-            // u = S^-1 r, v = S^-1 1, delta = u - (1^T u / 1^T v) v;  then r = Pm(g - S mu) again with the explicit S.  The first pass IS the solution
-            // (cond(S) ~ 5e2 ... 7e4 on the bunny grids: 1e-12 and better); further passes are iterative refinement, taken only while the residual
-            // test of the CG path -- the same one -- is not met.
+            // u = S^-1 r, v = S^-1 1 (formed behind the inversion, in the set-up), delta = u - (1^T u / 1^T v) v;  then r = Pm(g - S mu) again with the explicit S.
+            // The first pass IS the solution (cond(S) ~ 5e2 ... 7e4 on the bunny grids: 1e-12 and better); further passes are iterative refinement, taken only
+            // while the residual test of the CG path -- the same one -- is not met.
             Slab<T>& sl = slabs[0];
             auto apply_Sinv = [&](const double* w, double* u) { hipLaunchKernelGGL(ginv_matvec_kernel<double>, dim3(m), dim3(kBlock), 0, stream, m, mp, Sinv.p, w, u); };
-            hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, mv(sl, V_T2), m, 1.0);
-            apply_Sinv(mv(sl, V_T2), mv(sl, V_Z));
             // At most six passes, and never more than max_iters.  A tolerance below what the arithmetic can deliver (about eps * cond(S): cond is 5e2 ... 7e4
             // here) would otherwise end in SHM_ERR_NOCONV although mu is at rounding accuracy: when a pass no longer reduces the residual by at least a
             // factor of four and the residual already sits below 1e-9 of the right-hand side, the stagnation IS convergence; rel_residual reports what was reached.
@@ -2958,7 +3000,7 @@ struct Solver final : SolverBase {
                 const bool sample = st && nsamples < kMaxSamples;
                 if (sample) ev[3 * nsamples]->record(stream);
                 apply_Sinv(mv(sl, V_R), mv(sl, V_T1));
-                hipLaunchKernelGGL(dual_bordered_kernel, dim3(1), dim3(kDualBlock), 0, stream, m, mv(sl, V_T1), mv(sl, V_Z), (const double*)nullptr, 1, mv(sl, V_MU));
+                hipLaunchKernelGGL(dual_bordered_kernel, dim3(1), dim3(kDualBlock), 0, stream, m, mv(sl, V_T1), Sinv_ones.p, (const double*)nullptr, 1, mv(sl, V_MU));
                 if (sample) ev[3 * nsamples + 1]->record(stream);
                 apply_S(V_MU);
                 hipLaunchKernelGGL(dual_init_residual_kernel, dim3(1), dim3(kDualBlock), 0, stream, m, mv(sl, V_G), sl.red.p + 1, mv(sl, V_R), sl.sc.p, 0);
@@ -2968,8 +3010,10 @@ struct Solver final : SolverBase {
                 }
                 it++;
                 HIPCHK(hipGetLastError());
-                HIPCHK(hipMemcpyAsync(h_pinned, sl.sc.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream));
-                HIPCHK(hipStreamSynchronize(stream));
+                // The final stage is queued behind the pass without waiting for its residual: one host round trip per solve instead of two.  Should the pass
+                // not have converged (not seen on any test case: the first pass is the solution), refinement passes follow and the final stage runs again.
+                finish();
+                finished = true;
                 rr0 = h_pinned[SC_RR0];
                 rr = h_pinned[SC_RR];
                 if (!std::isfinite(rr) || !std::isfinite(rr0)) breakdown = true;
@@ -3013,18 +3057,7 @@ struct Solver final : SolverBase {
             else if (rr <= o.tol * o.tol * rr0) converged = true;
             log("[shm] dual it=%d rel_res=%.3e", it, rr0 > 0. ? std::sqrt(std::fabs(rr / rr0)) : 0.);
         }
-        // ---- x = K^+ (A^T mu - b)   (the additive constant cancels in the shift)
-        for (Slab<T>& sl : slabs)
-            hipLaunchKernelGGL((negate_kernel<T>), dim3(grid_for(sl.ntot, 4096)), dim3(kBlock), 0, stream, sl.ntot, sl.r.p, sl.q.p);
-        scatter(V_MU, ARR_Q, 1);
-        launch_precond(false, ARR_Q, ARR_X);
-        gather(ARR_X);  // A x0: constant over the rows at convergence; its mean is the KKT solution's additive constant
-        for (Slab<T>& sl : slabs) hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, stream, sl.red.p + 1, m, sl.sc.p + SC_AXSUM);
-        e_pcg.record(stream);
-        launch_shift_and_phi();
-        e_end.record(stream);
-        HIPCHK(hipMemcpyAsync(h_pinned, slabs[0].sc.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
+        if (!finished) finish();
         have_phi = true;
         have_div = false;  // r still holds b, but q (= phi now) and p were reused
         if (st) {
@@ -3116,6 +3149,7 @@ struct Solver final : SolverBase {
         f_start.record(F.stream);
         f_setup.record(F.stream);
         F.have_div = true;
+        fs.div_sum_blocks = 0;   // (b came from the ranks' slabs: no partial sums of the whole grid)
         shm_stats cst;
         memset(&cst, 0, sizeof cst);
         // "did not converge" still leaves phi (include/shm_grid.h: SHM_ERR_NOCONV): finish the hand-over, then report it

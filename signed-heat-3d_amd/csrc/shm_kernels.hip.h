@@ -564,7 +564,10 @@ __device__ __forceinline__ void store_vec(T* p, const T (&v)[VEC]) {
 // Logical blocks: x chunk fastest, then row group, then z chunk.
 template <typename T, int VEC>
 __global__ __launch_bounds__(kBlock) void divergence_march_kernel(GridParams G, int LX, int xchunks, int rowgroups, int ZC, const T* __restrict__ Y0,
-                                                                  const T* __restrict__ Y1, const T* __restrict__ Y2, T* __restrict__ b, int scrub) {
+                                                                  const T* __restrict__ Y1, const T* __restrict__ Y2, T* __restrict__ b, int scrub,
+                                                                  double* __restrict__ sum_partials = nullptr /* [gridDim.x]: sum of the workgroup's b (the dual solver's 1^T b) */) {
+    __shared__ double red[8];
+    double mysum = 0.;
     const int n = G.n;
     const size_t plane = (size_t)n * n;
     const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -614,9 +617,14 @@ __global__ __launch_bounds__(kBlock) void divergence_march_kernel(GridParams G, 
             if (k == n - 2) a -= ih * Y2[c + e + plane];
             if (scrub && !isfinite(a)) a = (T)0;
             acc[e] = a;
+            mysum += (double)a;
             y2m[e] = y2[e];
         }
         store_vec<T, VEC>(b + c, acc);
+    }
+    if (sum_partials) {   // (wave-uniform: every lane of the workgroup arrives)
+        mysum = block_sum(mysum, red);
+        if (threadIdx.x == 0) sum_partials[blockIdx.x] = mysum;
     }
 }
 
@@ -1082,12 +1090,21 @@ __device__ __forceinline__ double block_sum_1024(double v, double* lds /* >= 17 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void scatter_rows_to_nodes_kernel(int nnodes, const uint32_t* __restrict__ node_id, const int* __restrict__ node_ptr,
                                                                        const int* __restrict__ ent_row, const double* __restrict__ ent_coef,
-                                                                       const double* __restrict__ v, int accumulate, T* __restrict__ w) {
+                                                                       const double* __restrict__ v, int accumulate, T* __restrict__ w, double scale = 1.0,
+                                                                       T* __restrict__ saved = nullptr /* [nnodes]: the touched nodes' values before the update */) {
     const int t = blockIdx.x * kBlock + threadIdx.x;
     if (t >= nnodes) return;
     double s = 0.;
     for (int e = node_ptr[t]; e < node_ptr[t + 1]; e++) s += ent_coef[e] * v[ent_row[e]];
-    w[node_id[t]] = (T)((accumulate ? (double)w[node_id[t]] : 0.) + s);
+    const T old = w[node_id[t]];
+    if (saved) saved[t] = old;
+    w[node_id[t]] = (T)((accumulate ? (double)old : 0.) + scale * s);
+}
+// w[node] = saved[...]: undoes an in-place scatter_rows_to_nodes_kernel exactly
+template <typename T>
+__global__ __launch_bounds__(kBlock) void restore_nodes_kernel(int nnodes, const uint32_t* __restrict__ node_id, const T* __restrict__ saved, T* __restrict__ w) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t < nnodes) w[node_id[t]] = saved[t];
 }
 
 // y = B x for the sparse m x m matrix B = A K A^T (CSR); one thread per row
