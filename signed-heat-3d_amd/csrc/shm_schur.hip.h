@@ -146,53 +146,82 @@ __global__ __launch_bounds__(kBlock) void schur_assemble_kernel(int m, int ld, i
     if (prio) __builtin_amdgcn_s_setprio(3);   // runs on the SIMDs Step 1 occupies (see gj_panels_kernel)
     const int i = blockIdx.y * 16 + (threadIdx.x >> 4), j = blockIdx.x * 16 + (threadIdx.x & 15);
     if (i >= m || j >= m || j < i) return;   // (diagonal tiles: the upper entry writes its mirror image too, so S is exactly symmetric)
-    int D[3], E[3];
-    double wt[3][6];
+    // Round 5 (late): everything that depends on ONE axis and its image flag is formed once per entry -- the three table indices of the x and y windows as
+    // element offsets (24-bit multiplications: indices <= n + 1 <= 1025, row pitches < 2^24), and for the z window its first index and the weights of the three
+    // consecutive table entries [zb, zb + 2] it covers (a window |D - 1|, |D|, |D + 1| or its folded counterpart: ascending, descending, or folded onto two
+    // entries) -- instead of once per image and term.  The image loop is unrolled, so every index below is static: 2000 -> 700 vector instructions per entry, no
+    // scratch (the weights used to be indexed by the image's flags), no per-term selects.  The kernel runs beside Step 1, which loses what it issues
+    // (profiles/r05_schur_assembly.txt).  Sums are formed in a different order than in rounds 3-4 (last-bit differences in S).
+    unsigned ox[2][3], oy[2][3], oz[2];    // [image flag][window term]
+    double wx[2][3], wy[2][3], wz[2][3];   // wz: per table entry zb + s, not per window term
+    const unsigned pitch_y = (unsigned)P, pitch_x = (unsigned)(n + 1) * (unsigned)P;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         const int Xi = rowX[4 * i + a], Xj = rowX[4 * j + a];
         const double ti = rowT[3 * i + a], tj = rowT[3 * j + a];
         const double wi0 = 1. - ti, wi1 = ti, wj0 = 1. - tj, wj1 = tj;
-        D[a] = Xi - Xj;
-        E[a] = Xi + Xj + 1;
-        wt[a][0] = wi0 * wj1;
-        wt[a][1] = wi0 * wj0 + wi1 * wj1;
-        wt[a][2] = wi1 * wj0;
-        wt[a][3] = wi0 * wj0;
-        wt[a][4] = wi0 * wj1 + wi1 * wj0;
-        wt[a][5] = wi1 * wj1;
+        const int D = Xi - Xj, E = Xi + Xj + 1;
+        const double wd[3] = {wi0 * wj1, wi0 * wj0 + wi1 * wj1, wi1 * wj0};   // difference window, terms |D - 1|, |D|, |D + 1|
+        const double ws[3] = {wi0 * wj0, wi0 * wj1 + wi1 * wj0, wi1 * wj1};   // sum window, terms fold(E), fold(E + 1), fold(E + 2)
+        int pd[3], ps[3];
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            pd[e] = abs(D - 1 + e);
+            ps[e] = schur_fold(E + e, n);
+        }
+        if (a == 0) {
+#pragma unroll
+            for (int e = 0; e < 3; e++) {
+                ox[0][e] = __umul24((unsigned)pd[e], pitch_x);
+                ox[1][e] = __umul24((unsigned)ps[e], pitch_x);
+                wx[0][e] = wd[e];
+                wx[1][e] = ws[e];
+            }
+        } else if (a == 1) {
+#pragma unroll
+            for (int e = 0; e < 3; e++) {
+                oy[0][e] = __umul24((unsigned)pd[e], pitch_y);
+                oy[1][e] = __umul24((unsigned)ps[e], pitch_y);
+                wy[0][e] = wd[e];
+                wy[1][e] = ws[e];
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < 2; f++) {
+                const int* pz = f ? ps : pd;
+                const double* wv = f ? ws : wd;
+                const int zb = min(pz[0], min(pz[1], pz[2]));
+                oz[f] = (unsigned)zb;
+#pragma unroll
+                for (int sl = 0; sl < 3; sl++) {
+                    double w = 0.;
+#pragma unroll
+                    for (int e = 0; e < 3; e++) w += pz[e] - zb == sl ? wv[e] : 0.;
+                    wz[f][sl] = w;
+                }
+            }
+        }
     }
     double acc = 0.;
-#pragma unroll 1
+#pragma unroll
     for (int combo = 0; combo < 8; combo++) {   // image (sigma_x, sigma_y, sigma_z): 27 terms each
-        const int sg[3] = {combo & 1, (combo >> 1) & 1, combo >> 2};
-        int pos[3][3];
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int e = 0; e < 3; e++) pos[a][e] = sg[a] ? schur_fold(E[a] + e, n) : abs(D[a] - 1 + e);
-        const int zb = min(pos[2][0], min(pos[2][1], pos[2][2]));
+        const int fx = combo & 1, fy = (combo >> 1) & 1, fz = combo >> 2;
+        const double* base = T + oz[fz];
         double sc = 0.;
 #pragma unroll
         for (int p = 0; p < 3; p++) {
             double sp = 0.;
 #pragma unroll
             for (int q = 0; q < 3; q++) {
-                const double* row = T + ((size_t)pos[0][p] * (n + 1) + pos[1][q]) * P;
-                // the three entries along the last axis lie in [zb, zb + 2] (a window |D - 1|, |D|, |D + 1| or its folded counterpart): two loads (16 + 8
-                // bytes, 8-byte aligned) instead of three -- the kernel is bound by the cache lines its loads touch per instruction (round 4: 1.8 -> 1.1 ms
-                // at m = 2842, profiles/r04_schur_assemble.txt); rows are P = n + 8 long, so zb + 2 stays inside the row
-                const schur_f64x2 lo = *reinterpret_cast<const schur_f64x2*>(row + zb);
-                const double hi = row[zb + 2];
-                double sq = 0.;
-#pragma unroll
-                for (int r = 0; r < 3; r++) {
-                    const int o = pos[2][r] - zb;
-                    sq += wt[2][3 * sg[2] + r] * (o == 0 ? lo.x : (o == 1 ? lo.y : hi));
-                }
-                sp += wt[1][3 * sg[1] + q] * sq;
+                // the three entries along the last axis lie in [zb, zb + 2]: two loads (16 + 8 bytes, 8-byte aligned) instead of three -- the kernel is bound by the
+                // cache lines its loads touch per instruction (round 4: 1.8 -> 1.1 ms at m = 2842, profiles/r04_schur_assemble.txt); rows are P = n + 8 long, so
+                // zb + 2 stays inside the row
+                const double* row = base + (ox[fx][p] + oy[fy][q]);
+                const schur_f64x2 lo = *reinterpret_cast<const schur_f64x2*>(row);
+                const double hi = row[2];
+                sp += wy[fy][q] * (wz[fz][0] * lo.x + wz[fz][1] * lo.y + wz[fz][2] * hi);
             }
-            sc += wt[0][3 * sg[0] + p] * sp;
+            sc += wx[fx][p] * sp;
         }
         acc += sc;
     }
