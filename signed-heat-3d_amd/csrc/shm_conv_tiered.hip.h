@@ -169,6 +169,9 @@ constexpr int kTierFill = kTierCluster * kTierChunk;
 #ifndef SHM_TIER_LDS_FETCH
 #define SHM_TIER_LDS_FETCH 1    // the next cluster's sources travel global -> LDS directly; 0: through 12 registers per lane (rounds 2-3)
 #endif
+#ifndef SHM_TIER_LOOKAHEAD
+#define SHM_TIER_LOOKAHEAD 1
+#endif
 #ifndef SHM_TIER_NEAR_BATCH
 #define SHM_TIER_NEAR_BATCH 4   // pairs whose e^{-lambda r}/r chains are interleaved stage by stage (round 5: all four of a lane's z-column; 2: +2.5 % Step 1)
 #endif
@@ -360,18 +363,37 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
             for (int a = 0; a < 6; a++) nq[a] = qn[a];
         };
 #endif
+        // the whole cluster against the block (bounding sphere, scalar loads): dropped before anything is fetched or staged
+        auto cluster_kept = [&](int c) {
+            const float* rec = clusters + (size_t)c * kConvClusterRec;
+            const float gdx = cx - rec[0], gdy = cy - rec[1], gdz = cz - rec[2];
+            const float gap = sqrtf(gdx * gdx + gdy * gdy + gdz * gdz) * 0.999999f - rt_w - rec[3] - r_hi_w;
+            return !(gap * lam_l2 > skip_l2 + (rec[4] * 1.4426950408889634f + lws) - lnear_w);   // (rec[4]: ln of the cluster's largest UNscaled weight)
+        };
+#if SHM_TIER_LOOKAHEAD
+        // Round 5 (late): the fetch runs one KEPT cluster ahead.  Rounds 3-5 fetched cluster c + 1 whatever became of it: a kept cluster behind a dropped one waited
+        // out the whole memory latency of a fetch issued a few dozen cycles earlier (and every dropped cluster's 3 KB were fetched for nothing) -- little on an
+        // idle device, but the constraint set-up's gathers share the CU's memory pipeline and stretch exactly that latency (profiles/r05_setup_interference.txt).
+        auto next_kept = [&](int c) {
+            while (c < P.n_clusters && !cluster_kept(c)) c++;
+            return c;
+        };
+        int c_first = next_kept(0);
+        if (c_first < P.n_clusters) fetch_cluster(c_first);
+#pragma unroll 1
+        for (int c = c_first; c < P.n_clusters;) {
+            c = next_kept(c + 1);   // (the scan overlaps the fetch in flight)
+            const int c_fetch = c;
+#else
         fetch_cluster(0);
 #pragma unroll 1
         for (int c = 0; c < P.n_clusters; c++) {
-            {   // the whole cluster against the block (bounding sphere, scalar loads): dropped before anything is staged
-                const float* rec = clusters + (size_t)c * kConvClusterRec;
-                const float gdx = cx - rec[0], gdy = cy - rec[1], gdz = cz - rec[2];
-                const float gap = sqrtf(gdx * gdx + gdy * gdy + gdz * gdz) * 0.999999f - rt_w - rec[3] - r_hi_w;
-                if (gap * lam_l2 > skip_l2 + (rec[4] * 1.4426950408889634f + lws) - lnear_w) {   // (rec[4]: ln of the cluster's largest UNscaled weight)
-                    if (c + 1 < P.n_clusters) fetch_cluster(c + 1);
-                    continue;
-                }
+            if (!cluster_kept(c)) {
+                if (c + 1 < P.n_clusters) fetch_cluster(c + 1);
+                continue;
             }
+            const int c_fetch = c + 1;
+#endif
             double q[6];
 #if SHM_TIER_LDS_FETCH
             {
@@ -384,7 +406,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
 #pragma unroll
             for (int a = 0; a < 6; a++) q[a] = nq[a];
 #endif
-            if (c + 1 < P.n_clusters) fetch_cluster(c + 1);
+            if (c_fetch < P.n_clusters) fetch_cluster(c_fetch);
             // one source per lane: near / far / dropped for this wave's block of nodes
             unsigned long long nearmask, farmask;
             {

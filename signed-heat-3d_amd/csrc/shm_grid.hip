@@ -1919,6 +1919,12 @@ struct Solver final : SolverBase {
     // `refined_later`: the caller checks the inverse by a residual and refines (the direct dual solve with S^-1): the pivot blocks may then be inverted by the
     // 16-step block kernel, whose result differs from the scalar 64-step one at the 1e-11 level on ill-conditioned matrices (A A^T: near-dependent rows of
     // neighbouring cells; the projector test holds A P v to 1e-11 without refinement, so G keeps the scalar kernel)
+    // SHM_SETUP_SKIP (experiment knob, bit mask): leave out the set-up's device work piece by piece -- 2: the assembly of S, 4: the Gauss-Jordan launches (1 = the Green's
+    // table: SHM_SCHUR_KEEP_TABLE).  The solve's RESULT is then wrong; only Step 1's duration beside what is left means anything (tools/ab.py prints it).
+    static int setup_skip() {
+        static const int v = knob("SHM_SETUP_SKIP") ? atoi(knob("SHM_SETUP_SKIP")) : 0;
+        return v;
+    }
     void enqueue_gj_invert(double* M, int mp, bool refined_later = false) {
         hipStream_t stream = stream2;
         const int nb = mp / kGJ;
@@ -1929,6 +1935,7 @@ struct Solver final : SolverBase {
         gjC.alloc((size_t)mp * outer * kGJ);   // [mp][outer * 64]
         gjFlag.alloc(2);
         HIPCHK(hipMemsetAsync(gjFlag.p, 0, sizeof(int), stream));
+        if (setup_skip() & 4) return;   // (timing experiments: see setup_skip)
         const int c_ld = outer * kGJ;
         static const int pivot_env = knob("SHM_GJ_PIVOT_E") ? atoi(knob("SHM_GJ_PIVOT_E")) : 0;
         const bool classic = knob("SHM_GJ_CLASSIC") != nullptr;   // A/B knob, read per inversion (a test flips it inside one process): three dependent launches per pivot block (rounds 1-3)
@@ -2194,7 +2201,8 @@ struct Solver final : SolverBase {
         if (gs_early) HIPCHK(hipStreamWaitEvent(st, e_gs_done->e, 0));
         HIPCHK(hipMemsetAsync(Sdense.p, 0, (size_t)mp * mp * sizeof(double), st));
         const unsigned mt = (unsigned)((m + 15) / 16);
-        hipLaunchKernelGGL(schur_assemble_kernel, dim3(mt, mt), dim3(kBlock), 0, st, m, mp, n, P, d_rowX.p, d_rowT.p, gs_T.p, Sdense.p, setup_prio);
+        if (setup_skip() & 2) hipLaunchKernelGGL(set_diagonal_kernel, dim3((unsigned)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, Sdense.p, mp, 0, m, 1.0);   // (something invertible)
+        else hipLaunchKernelGGL(schur_assemble_kernel, dim3(mt, mt), dim3(kBlock), 0, st, m, mp, n, P, d_rowX.p, d_rowT.p, gs_T.p, Sdense.p, setup_prio);
         HIPCHK(hipGetLastError());
         if (dual_direct) {
             Sinv.alloc((size_t)mp * mp);
