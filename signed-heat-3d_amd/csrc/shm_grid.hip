@@ -2436,7 +2436,7 @@ struct Solver final : SolverBase {
         hipStream_t stream = st ? st : this->stream;   // (another stream only on one slab without a communicator: no all-reduce below)
         for (size_t s = 0; s < slabs.size(); s++) {
             Slab<T>& sl = slabs[s];
-            hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(1 + (m + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, m, sl.row_ptr.p, sl.ent_node.p,
+            hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(1 + (8 * m + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, m, sl.row_ptr.p, sl.ent_node.p,
                                sl.ent_coef.p, on_z ? sl.z.p : sl.r.p, sl.partials.p, nparts[s], sl.red.p);
         }
         if (!st) allreduce(0, 1 + m);
@@ -2904,7 +2904,7 @@ struct Solver final : SolverBase {
         const std::vector<int> nopart(slabs.size(), 0);
         auto gather = [&](int sel) {  // red[1..m] = A * arr(sel), all-reduced
             for (Slab<T>& sl : slabs)
-                hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(1 + (m + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, m, sl.row_ptr.p, sl.ent_node.p,
+                hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(1 + (8 * m + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, m, sl.row_ptr.p, sl.ent_node.p,
                                    sl.ent_coef.p, arr(sl, sel), sl.partials.p, 0, sl.red.p);
             allreduce(0, 1 + m);
         };

@@ -864,11 +864,20 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(int m, const int* _
         if (threadIdx.x == 0) red[0] = s;
         return;
     }
-    const int row = (blockIdx.x - 1) * kBlock + threadIdx.x;
-    if (row >= m) return;
+    // Eight lanes per row, one entry each (a row has at most the eight corners of its cell), summed in entry order by every lane of the group.  (Rounds 1-5 walked the
+    // entries in one thread: eight dependent index -> value load pairs in a row, 10 us on an idle device and 50 us beside a sweep that saturates the HBM -- the
+    // projection of the stencil CG runs beside the x update and had become the longer of the two, profiles/r05_projection.txt.)
+    const int gid = (blockIdx.x - 1) * kBlock + threadIdx.x, row = gid >> 3, k = gid & 7;
+    double term = 0.;
+    if (row < m) {
+        const int e = row_ptr[row] + k;
+        if (e < row_ptr[row + 1]) term = ent_coef[e] * (double)v[ent_node[e]];
+    }
+    const int base = (int)(threadIdx.x & 63) & ~7;
     double s = 0.;
-    for (int e = row_ptr[row]; e < row_ptr[row + 1]; e++) s += ent_coef[e] * (double)v[ent_node[e]];
-    red[1 + row] = s;
+#pragma unroll
+    for (int a = 0; a < 8; a++) s += __shfl(term, base + a, 64);
+    if (row < m && k == 0) red[1 + row] = s;
 }
 
 // u = Ginv * w  (Ginv = (A A^T)^-1, dense, row-major, leading dimension ld, a multiple of 4).  One workgroup per row, four

@@ -131,8 +131,23 @@ __global__ __launch_bounds__(kBlock) void tl_cols_kernel(TlBoxes B, const int* _
     const int l = chunkCol[blockIdx.x] + lane;
     const TM* Ea = E + B.offE[a];
     double acc = 0.;
-    if (l < c)
-        for (int i = wave; i < s; i += kBlock / kWave) acc += (double)Ea[(size_t)i * c + l] * tbuf[i0 + i];
+    if (l < c) {
+        // four of the wave's rows in flight (round 5, late: one load per trip left the kernel at a row's memory latency per four rows of the box -- 14 us on an idle
+        // device, 60 us beside the x update of the stencil CG, whose iteration then waited for the projection; profiles/r05_projection.txt)
+        constexpr int W = kBlock / kWave;
+        double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
+        int i = wave;
+        for (; i + 3 * W < s; i += 4 * W) {
+            const double e0 = (double)Ea[(size_t)i * c + l], e1 = (double)Ea[(size_t)(i + W) * c + l], e2 = (double)Ea[(size_t)(i + 2 * W) * c + l],
+                         e3 = (double)Ea[(size_t)(i + 3 * W) * c + l];
+            a0 += e0 * tbuf[i0 + i];
+            a1 += e1 * tbuf[i0 + i + W];
+            a2 += e2 * tbuf[i0 + i + 2 * W];
+            a3 += e3 * tbuf[i0 + i + 3 * W];
+        }
+        for (; i < s; i += W) a0 += (double)Ea[(size_t)i * c + l] * tbuf[i0 + i];
+        acc = (a0 + a1) + (a2 + a3);
+    }
     part[wave][lane] = acc;
     __syncthreads();
     if (wave == 0 && l < c) ybuf[c0 + l] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
