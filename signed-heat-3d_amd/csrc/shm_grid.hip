@@ -500,6 +500,7 @@ struct Solver final : SolverBase {
     DevArray<float> d_clusters_t;
     int n_clusters_t = 0;
     bool conv_tiered = false;                                  // fp64 only; SHM_CONV_EXACT=1 selects the all-fp64 kernel
+    bool conv_tier_exact = false;                              // ... with every pair in its fp64 body (SHM_STEP1_EXACT_F64 where the exponent span allows)
     bool conv_tiered32 = false;                                // fp32 handles: Step 1 through the tiered kernel's packed-fp32 body
     bool fold_pq = false;                                      // fused stencil CG on one GPU: the RES sweep sums the DIR sweep's partials of p'.Kp' itself
     int fold_pq_np = 0;
@@ -956,6 +957,12 @@ struct Solver final : SolverBase {
     void select_step1_arith(int arith) {
         if (arith != SHM_STEP1_AUTO && arith != SHM_STEP1_EXACT_F64) throw Error(SHM_ERR_INVALID, "unknown step1_arith");
         conv_tiered = sizeof(T) == 8 && arith == SHM_STEP1_AUTO && knob("SHM_CONV_EXACT") == nullptr && tier_exponent_span_ok();
+        // SHM_STEP1_EXACT_F64 (round 5, late): the same kernel with nothing far and nothing dropped -- every (node, source) pair through its fp64 body, which is the
+        // leaner of the two fp64 bodies since this round (exponent by integer add, four pairs of a source in flight: 22 vector instructions per pair against the
+        // all-fp64 kernel's 30) and leaves the set-up room beside it -- where EVERY pair of the grid stays inside the exponent span of a block's scale; the
+        // all-fp64 kernel (gradual underflow by v_ldexp_f64) otherwise and behind SHM_CONV_EXACT_CLASSIC=1 (A/B knob).
+        conv_tier_exact = sizeof(T) == 8 && arith == SHM_STEP1_EXACT_F64 && knob("SHM_CONV_EXACT_CLASSIC") == nullptr && tier_exponent_span_ok(true);
+        conv_tiered = conv_tiered || conv_tier_exact;
         // fp32 handles (round 5): the same kernel with every kept pair in its packed-fp32 body and fp32 output; SHM_CONV32_CLASSIC=1: conv_normalize_kernel<float> (A/B)
         conv_tiered32 = sizeof(T) == 4 && knob("SHM_CONV32_CLASSIC") == nullptr && tier_exponent_span_ok();
     }
@@ -964,9 +971,11 @@ struct Solver final : SolverBase {
     // (skip + ln(w_s / w_near)) / lambda further from the block than the block's nearest source, and a block spans 2 rt: the evaluated exponents of a block span
     // at most lambda' (4 rt) + skip' + log2(w_max / w_min) bits (62 bits stand in for a nearest source of weight zero: the kernel's floor of 1e-37 on w_near^2).
     // Beyond that -- a cell of some 25 mean edge lengths, tCoef ~ 1e-3 -- Step 1 runs in the all-fp64 kernel, whose v_ldexp_f64 underflows gradually.
-    bool tier_exponent_span_ok() const {
+    bool tier_exponent_span_ok(bool every_pair = false) const {
         const double rt = std::sqrt(2 * 3.5 * 3.5 + 1.5 * 1.5) * cell;
-        const double bits = (4.0 * rt * lambda + std::min(sizeof(T) == 8 ? conv_tier_skip_base : conv_skip_base, 1.0e6) + std::max(conv_w_span, 43.0)) * 1.4426950408889634 + 16.0;
+        // (every_pair: nothing is dropped -- a block's evaluated sources lie up to the grid's diagonal further away than its nearest one; sources sit inside the grid's box)
+        const double reach = every_pair ? lambda * std::sqrt(3.0) * (double)(n - 1) * cell : std::min(sizeof(T) == 8 ? conv_tier_skip_base : conv_skip_base, 1.0e6);
+        const double bits = (4.0 * rt * lambda + reach + std::max(conv_w_span, 43.0)) * 1.4426950408889634 + 16.0;
         return bits < 990.0;
     }
     void need_problem() const {
@@ -1001,14 +1010,14 @@ struct Solver final : SolverBase {
             // (terms e^-G below the dominant one carry the packed-fp32 error eps_far: G = 8 at 1e-8), the a-posteriori test (b / eps_far) and the drop threshold (b / 5)
             const double budget = step1_budget > 0. ? step1_budget : kTierBudget;
             const double g_shift = std::log(budget / kTierBudget);
-            P.tier_log = conv_tiered32 ? -1.0e30f : (float)std::max(2.0, conv_tier_log - g_shift);   // (fp32 solve: every kept source that stays in the fp32 exponent range is "far")
+            P.tier_log = conv_tier_exact ? 3.0e38f : conv_tiered32 ? -1.0e30f : (float)std::max(2.0, conv_tier_log - g_shift);   // (fp32 solve: every kept source that stays in the fp32 exponent range is "far")
             P.wscale = conv_wscale;
             {   // a-posteriori test of the packed-fp32 tier (shm_conv_tiered.hip.h): budget on Y / calibrated relative error of a far term as it shows up in X
                 static const double redo_env = knob("SHM_CONV_REDO_RATIO") ? atof(knob("SHM_CONV_REDO_RATIO")) : -1.;   // A/B knob (0: never)
                 const double ratio = redo_env >= 0. ? redo_env : budget / kTierEpsFar;
                 P.far_redo_ratio = ratio > 0. ? (float)ratio : 3.0e38f;
             }
-            P.skip_base = (float)std::min(conv_tiered ? conv_tier_skip_base - g_shift : conv_skip_base, 3.0e38);
+            P.skip_base = conv_tier_exact ? 3.0e38f : (float)std::min(conv_tiered ? conv_tier_skip_base - g_shift : conv_skip_base, 3.0e38);
             P.inv_lambda = (float)(1.0 / lambda);
             P.tiles_x = (n + kConvTile - 1) / kConvTile;
             P.tiles_y = P.tiles_x;
@@ -1297,6 +1306,11 @@ struct Solver final : SolverBase {
     // a fixed rate -- conv_est_total_ms -- are off by up to 9x on the culled inputs.
     double estimate_step1_ms_tiered() const {
         if (S <= 0) return 0.;
+        if (conv_tier_exact) {   // every pair through the fp64 body
+            double nodes = 0.;
+            for (const Slab<T>& sl : slabs) nodes += (double)sl.nown;
+            return nodes * (double)S * 1.229e-9;
+        }
         const int K = (int)std::max<int64_t>(32, std::min<int64_t>(128, 2000000 / S));
         const int64_t stride = std::max<int64_t>(1, (S * K + 1999999) / 2000000);   // <= 2e6 (sample, source) pairs whatever S (the floor of 32 samples alone let point
                                                                                      // clouds of 1e5-1e6 sources run tens of ms here): ~2 ms of host time, paid before the set-up is queued

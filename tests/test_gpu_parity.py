@@ -277,6 +277,53 @@ def test_step1_full_size_against_c_oracle(shm, oracle_c, fname, hCoef, precision
         assert worst["auto"] < Y_BUDGET_F32, worst
 
 
+@pytest.mark.parametrize("path,hcoef", [("bunny_small.obj", 2.0), ("bunny_small.obj", 3.0), ("rocker.obj", 2.0), ("bunny.pc", 2.0)])
+def test_exact_f64_step1_two_kernels_agree(shm, path, hcoef, monkeypatch):
+    """shm_opts.step1_arith = SHM_STEP1_EXACT_F64 runs the tiered kernel with nothing far and nothing dropped (round 5) where every pair of the grid stays inside a
+    block's exponent span, the all-fp64 kernel of rounds 1-4 otherwise and behind SHM_CONV_EXACT_CLASSIC=1: the two agree to rounding, every pair is counted as an
+    fp64 pair, and a wide exponent span (lambda x 8) hands over to the classic kernel with the same answer."""
+    import os
+    from conftest import ROOT
+    from signed_heat_3d_amd.host_abi import HostSolver
+    pre = HostSolver(os.path.join(ROOT, "data", path)).preprocess(hCoef=hcoef)
+    n, S = pre["n"], len(pre["area"])
+    out = {}
+    for classic in (False, True):
+        if classic:
+            monkeypatch.setenv("SHM_CONV_EXACT_CLASSIC", "1")
+        else:
+            monkeypatch.delenv("SHM_CONV_EXACT_CLASSIC", raising=False)
+        s = shm.GridSolver()
+        s.set_problem(pre["pos"], pre["wnormal"], pre["area"], pre["lam"], n, pre["bbox_min"], pre["cell"])
+        st = s.solve(tol=1e-10, scrub=not path.endswith(".pc"), step1="exact_f64")
+        out[classic] = (np.stack([s.get_field(k) for k in (0, 1, 2)], axis=1), s.get_phi()[0], st)
+        s.close()
+    (Yn, pn, stn), (Yc, pc, stc) = out[False], out[True]
+    ok = np.isfinite(Yc).all(axis=1)
+    assert (np.isfinite(Yn).all(axis=1) == ok).all()
+    dY, dphi = np.abs(Yn[ok] - Yc[ok]).max(), np.abs(pn - pc).max()
+    print("\nexact f64, tiered body vs all-fp64 kernel: %s n=%d max|dY| %.2e max|dphi| %.2e" % (path, n, dY, dphi))
+    assert dY < 1e-11 and dphi < 1e-10        # (rounding: where |X| is small against its terms -- the medial axis -- the direction amplifies the last bits of the sums)
+    assert stn.pairs_fp32 == 0 and stn.pairs_redone == 0
+    nz = int((np.abs(np.asarray(pre["wnormal"]).reshape(-1, 3)).sum(axis=1) > 0).sum())
+    assert stn.pairs_fp64 >= n ** 3 * nz          # every node against every source of non-zero weight (blocks are padded to 8 x 8 x NPT nodes)
+    # beyond the exponent span the classic kernel takes over (same entry point, same answer as asking for it)
+    monkeypatch.delenv("SHM_CONV_EXACT_CLASSIC", raising=False)
+    s = shm.GridSolver()
+    s.set_problem(pre["pos"], pre["wnormal"], pre["area"], pre["lam"] * 8.0, n, pre["bbox_min"], pre["cell"])
+    s.run_conv(step1="exact_f64")
+    Yw = np.stack([s.get_field(k) for k in (0, 1, 2)], axis=1)
+    s.close()
+    monkeypatch.setenv("SHM_CONV_EXACT_CLASSIC", "1")
+    s = shm.GridSolver()
+    s.set_problem(pre["pos"], pre["wnormal"], pre["area"], pre["lam"] * 8.0, n, pre["bbox_min"], pre["cell"])
+    s.run_conv(step1="exact_f64")
+    Yw2 = np.stack([s.get_field(k) for k in (0, 1, 2)], axis=1)
+    s.close()
+    okw = np.isfinite(Yw2).all(axis=1)
+    assert (np.isfinite(Yw).all(axis=1) == okw).all() and np.array_equal(Yw[okw], Yw2[okw])   # (the same kernel ran)
+
+
 @pytest.mark.parametrize("case,scrub", [("bunny_small_n16", True), ("bunny_small_n32", True), ("bunny_pc_n32", False)])
 def test_divergence_matches_golden(shm, case, scrub):
     d = load_golden(case)
