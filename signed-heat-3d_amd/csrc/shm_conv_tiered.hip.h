@@ -253,7 +253,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
             q_off++;
         }
         if (unit == 0xffffffffu) break;
-        const int tz = (int)(unit / (unsigned)(P.tiles_x * P.tiles_y)), trem = (int)unit - tz * (P.tiles_x * P.tiles_y);
+        const int tzq = (int)(unit / (unsigned)(P.tiles_x * P.tiles_y)), trem = (int)unit - tzq * (P.tiles_x * P.tiles_y);
+        const int tz = P.layer_order ? P.layer_order[tzq] : tzq;   // (the queues run from the layers at the grid's centre to the ones at its faces: launch_conv)
         const int ty = trem / P.tiles_x, tx = trem - ty * P.tiles_x;
         const int i0 = tx * kTierTX, j0 = ty * kTierTY, kk0 = P.kk_begin + tz * NPT;
 

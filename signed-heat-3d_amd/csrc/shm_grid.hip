@@ -461,6 +461,8 @@ struct Slab {
     DevArray<double> ent_coef, nent_coef;
     DevArray<ShiftItem> shift_items;
     DevArray<double> dv;  // dual solver m-vectors: mu, r, p, z, t1, t2, g (7 x mp)
+    DevArray<int> layer_order;   // tiered Step 1: z-layers of blocks in queue order (layer_order_for)
+    long long layer_order_key = -1;
     DevArray<double> div_partials;   // per-workgroup sums of b written by the divergence kernel (div_sum_blocks of them; 0: not available, sum b with sum_kernel)
     int div_sum_blocks = 0;
     DevArray<T> touched_save;   // the touched nodes' entries of b while b - A^T mu stands in their place (final stage of the dual solve)
@@ -984,6 +986,28 @@ struct Solver final : SolverBase {
 
     // ------------------------------------------------------------------------------------------
     // Steps 1+2
+    // Order of the z-layers of blocks in the tiered kernel's work queues (round 5, late).  The queues used to run bottom to top, each XCD's a contiguous range of layers: the
+    // last blocks handed out were whatever stood at the end of the slowest range, and a wave finishing its last block leaves its SIMD slot idle for the rest of the kernel
+    // (2.2 % of the wave-cycles at 256^3, profiles/r05_sq_counters_conv.txt).  The blocks that cost most are the ones near the sources -- the grid's centre (buildGrid centres
+    // the grid on the input) --, the ones at the faces drop most sources.  So: layers sorted by the distance of their GLOBAL plane from the grid's mid-plane, dealt round-robin to
+    // the eight queues (every XCD gets the same mix and runs centre -> face), i.e. the blocks handed out last are the cheapest ones.  Within a layer nothing changes (x-adjacent
+    // blocks stay neighbours in one queue: their halves of a 128-byte line of Y still meet in one L2).  SHM_TIER_LAYER_ORDER=0: bottom to top (A/B knob).
+    const int* layer_order_for(Slab<T>& sl, int kk_begin, int layers, int npt) {
+        static const bool off = knob("SHM_TIER_LAYER_ORDER") != nullptr && atoi(knob("SHM_TIER_LAYER_ORDER")) == 0;
+        if (off || layers < 16) return nullptr;
+        const long long key = ((long long)kk_begin << 40) ^ ((long long)layers << 20) ^ ((long long)npt << 8) ^ (long long)sl.k0 * 0x9E3779B1LL;
+        if (sl.layer_order.p && sl.layer_order_key == key) return sl.layer_order.p;
+        std::vector<std::pair<double, int>> byc((size_t)layers);
+        for (int l = 0; l < layers; l++) byc[(size_t)l] = {std::fabs((double)(sl.k0 + kk_begin - 1 + l * npt) + 0.5 * (npt - 1) - 0.5 * (n - 1)), l};
+        std::stable_sort(byc.begin(), byc.end());
+        std::vector<int> order;
+        order.reserve((size_t)layers);
+        for (int q = 0; q < 8; q++)
+            for (int r = q; r < layers; r += 8) order.push_back(byc[(size_t)r].second);
+        sl.layer_order.upload(order, stream);
+        sl.layer_order_key = key;
+        return sl.layer_order.p;
+    }
     void launch_conv() {
         const bool slab_log = knob("SHM_CONV_SLAB_LOG") != nullptr;
         Event slab_ev[2];
@@ -994,6 +1018,7 @@ struct Solver final : SolverBase {
                 slab_ev[0].record(stream);
             }
             ConvParams P;
+            P.layer_order = nullptr;
             P.n = n;
             P.kk_begin = 1;  // owned planes only: the ghost planes of Y are exchanged (exchange_Y_halos), not recomputed -- a ghost plane
             P.kk_end = sl.nzl + 1;  // would cost a whole 16-plane tile layer of Step 1 (41 % extra on 8 GPUs at 256^3)
@@ -1097,7 +1122,9 @@ struct Solver final : SolverBase {
                     const int npt = npt4 ? 4 : 2;
                     Pc.tiles_x = (n + kTierTX - 1) / kTierTX;
                     Pc.tiles_y = (n + kTierTY - 1) / kTierTY;
-                    Pc.n_tiles = Pc.tiles_x * Pc.tiles_y * ((Pc.kk_end - Pc.kk_begin + npt - 1) / npt);
+                    const int layers = (Pc.kk_end - Pc.kk_begin + npt - 1) / npt;
+                    Pc.n_tiles = Pc.tiles_x * Pc.tiles_y * layers;
+                    Pc.layer_order = layer_order_for(sl, Pc.kk_begin, layers, npt);
                     const dim3 gt((unsigned)std::min<long long>((Pc.n_tiles + 3) / 4, grid));
                     if constexpr (sizeof(T) == 8) {
                         if (npt4)

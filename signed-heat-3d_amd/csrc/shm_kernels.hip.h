@@ -152,6 +152,7 @@ struct ConvParams {
     double pad_pos[3];     // tiered fp64 path: where the zero-weight padding entries of a compacted source list sit (bbox_min - n cell: a grid side from every node)
     float far_redo_ratio;  // tiered fp64 path: a block whose packed-fp32 sums exceed this fraction of |X| at any node evaluates its far sources again in fp64
                            // (= budget on Y / calibrated relative error of a packed-fp32 term; 3e38: never)
+    const int* layer_order;   // tiered path: z-layer of blocks that stands at position p of the work queues' order (nullptr: p itself) -- see launch_conv
 };
 
 typedef float float2v __attribute__((ext_vector_type(2)));
