@@ -371,30 +371,31 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
             const float gap = sqrtf(gdx * gdx + gdy * gdy + gdz * gdz) * 0.999999f - rt_w - rec[3] - r_hi_w;
             return !(gap * lam_l2 > skip_l2 + (rec[4] * 1.4426950408889634f + lws) - lnear_w);   // (rec[4]: ln of the cluster's largest UNscaled weight)
         };
-#if SHM_TIER_LOOKAHEAD
-        // Round 5 (late): the fetch runs one KEPT cluster ahead.  Rounds 3-5 fetched cluster c + 1 whatever became of it: a kept cluster behind a dropped one waited
-        // out the whole memory latency of a fetch issued a few dozen cycles earlier (and every dropped cluster's 3 KB were fetched for nothing) -- little on an
-        // idle device, but the constraint set-up's gathers share the CU's memory pipeline and stretch exactly that latency (profiles/r05_setup_interference.txt).
+        // Round 5 (late): in the fp64 solve the fetch runs one KEPT cluster ahead.  Rounds 3-5 fetched cluster c + 1 whatever became of it: a kept cluster behind a dropped one
+        // waited out the whole memory latency of a fetch issued a few dozen cycles earlier (-3 ... 4 % of Step 1 at 128^3 and on rocker 128^3, nothing at 256^3 where few
+        // clusters are dropped; profiles/r05_setup_interference.txt).  The fp32 solve keeps the plain order: there it measured 7-8 % SLOWER (rocker / SprayBottle 256^3 fp32 --
+        // its kept clusters are all-far and short, and the scan for the next one then sits between a cluster's fetch and its use instead of beside the evaluation).
+        constexpr bool kLookahead = SHM_TIER_LOOKAHEAD != 0 && sizeof(TY) == 8;
         auto next_kept = [&](int c) {
             while (c < P.n_clusters && !cluster_kept(c)) c++;
             return c;
         };
-        int c_first = next_kept(0);
-        if (c_first < P.n_clusters) fetch_cluster(c_first);
+        int c = kLookahead ? next_kept(0) : 0;
+        if (c < P.n_clusters) fetch_cluster(c);
 #pragma unroll 1
-        for (int c = c_first; c < P.n_clusters;) {
-            c = next_kept(c + 1);   // (the scan overlaps the fetch in flight)
-            const int c_fetch = c;
-#else
-        fetch_cluster(0);
-#pragma unroll 1
-        for (int c = 0; c < P.n_clusters; c++) {
-            if (!cluster_kept(c)) {
-                if (c + 1 < P.n_clusters) fetch_cluster(c + 1);
-                continue;
+        while (c < P.n_clusters) {
+            int c_next;
+            if constexpr (kLookahead) {
+                c_next = next_kept(c + 1);   // (the scan overlaps the fetch in flight)
+            } else {
+                c_next = c + 1;
+                if (!cluster_kept(c)) {
+                    if (c_next < P.n_clusters) fetch_cluster(c_next);
+                    c = c_next;
+                    continue;
+                }
             }
-            const int c_fetch = c + 1;
-#endif
+            const int c_fetch = c_next;
             double q[6];
 #if SHM_TIER_LDS_FETCH
             {
@@ -529,6 +530,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                     }
                 }
             }
+            c = c_next;
         }
         if (!CHECK) break;
         if (pass == 0) {

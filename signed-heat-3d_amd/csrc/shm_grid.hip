@@ -993,7 +993,7 @@ struct Solver final : SolverBase {
     // the eight queues (every XCD gets the same mix and runs centre -> face), i.e. the blocks handed out last are the cheapest ones.  Within a layer nothing changes (x-adjacent
     // blocks stay neighbours in one queue: their halves of a 128-byte line of Y still meet in one L2).  SHM_TIER_LAYER_ORDER=0: bottom to top (A/B knob).
     const int* layer_order_for(Slab<T>& sl, int kk_begin, int layers, int npt) {
-        static const bool off = knob("SHM_TIER_LAYER_ORDER") != nullptr && atoi(knob("SHM_TIER_LAYER_ORDER")) == 0;
+        const bool off = knob("SHM_TIER_LAYER_ORDER") != nullptr && atoi(knob("SHM_TIER_LAYER_ORDER")) == 0;   // (read per launch: a test flips it inside one process)
         if (off || layers < 16) return nullptr;
         const long long key = ((long long)kk_begin << 40) ^ ((long long)layers << 20) ^ ((long long)npt << 8) ^ (long long)sl.k0 * 0x9E3779B1LL;
         if (sl.layer_order.p && sl.layer_order_key == key) return sl.layer_order.p;

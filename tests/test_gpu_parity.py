@@ -277,6 +277,26 @@ def test_step1_full_size_against_c_oracle(shm, oracle_c, fname, hCoef, precision
         assert worst["auto"] < Y_BUDGET_F32, worst
 
 
+@pytest.mark.parametrize("precision", [64, 32])
+def test_step1_block_order_does_not_change_Y(shm, precision, monkeypatch):
+    """The tiered kernel's work queues hand the z-layers of blocks out from the grid's centre to its faces (round 5; SHM_TIER_LAYER_ORDER=0: bottom to top).  A block's
+    result does not depend on when it is computed: Y is bit-identical either way, on one slab and on three (whose layers are ordered by their GLOBAL planes)."""
+    import os
+    from conftest import ROOT
+    from signed_heat_3d_amd.host_abi import HostSolver
+    pre = HostSolver(os.path.join(ROOT, "data", "bunny_small.obj")).preprocess(hCoef=3.0)     # 128^3: 32 layers of four planes
+    for slabs in (1, 3):
+        Y = {}
+        for order in ("1", "0"):
+            monkeypatch.setenv("SHM_TIER_LAYER_ORDER", order)
+            s = shm.GridSolver(precision=precision, local_slabs=slabs)
+            s.set_problem(pre["pos"], pre["wnormal"], pre["area"], pre["lam"], pre["n"], pre["bbox_min"], pre["cell"])
+            s.run_conv()
+            Y[order] = np.stack([s.get_field(k) for k in (0, 1, 2)], axis=1)
+            s.close()
+        assert np.array_equal(Y["1"], Y["0"], equal_nan=True)
+
+
 @pytest.mark.parametrize("path,hcoef", [("bunny_small.obj", 2.0), ("bunny_small.obj", 3.0), ("rocker.obj", 2.0), ("bunny.pc", 2.0)])
 def test_exact_f64_step1_two_kernels_agree(shm, path, hcoef, monkeypatch):
     """shm_opts.step1_arith = SHM_STEP1_EXACT_F64 runs the tiered kernel with nothing far and nothing dropped (round 5) where every pair of the grid stays inside a
