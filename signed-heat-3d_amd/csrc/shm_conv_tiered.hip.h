@@ -169,9 +169,6 @@ constexpr int kTierFill = kTierCluster * kTierChunk;
 #ifndef SHM_TIER_LDS_FETCH
 #define SHM_TIER_LDS_FETCH 1    // the next cluster's sources travel global -> LDS directly; 0: through 12 registers per lane (rounds 2-3)
 #endif
-#ifndef SHM_TIER_NEAREST_PRUNE
-#define SHM_TIER_NEAREST_PRUNE 1
-#endif
 #ifndef SHM_TIER_LOOKAHEAD
 #define SHM_TIER_LOOKAHEAD 1
 #endif
@@ -284,17 +281,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
         const float cx = uniform_f32((float)((i0 + kHalfX) * P.cell + P.bbox_min[0])), cy = uniform_f32((float)((j0 + kHalfY) * P.cell + P.bbox_min[1]));
         const float cz = uniform_f32((float)((P.k0 + kk0 - 1 + kHalfZ) * P.cell + P.bbox_min[2]));
         float dmin = 3.0e38f, wnear = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;   // nearest source: squared distance, squared weight, offset from the centre
-        // (minimum over the wave by ds_swizzle butterflies within the halves + two v_readlane: no per-step lane index held in a register -- the __shfl_xor form kept six of
-        // them live through the whole kernel -- and a sixth of the instructions of a five-value butterfly)
-        auto wave_min_u = [&](unsigned v) {
-            v = min(v, (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1f | (1 << 10)));    // bit-mask mode: lane ^ 1, 2, 4, 8, 16 within each half
-            v = min(v, (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1f | (2 << 10)));
-            v = min(v, (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1f | (4 << 10)));
-            v = min(v, (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1f | (8 << 10)));
-            v = min(v, (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1f | (16 << 10)));
-            return min((unsigned)__builtin_amdgcn_readlane((int)v, 0), (unsigned)__builtin_amdgcn_readlane((int)v, 32));
-        };
-        auto visit = [&](int s) {   // source s against the lane's best so far
+        for (int s = lane; s < P.S; s += kWave) {
             const double* q = src + (size_t)s * 6;
             const float dx = cx - (float)q[0], dy = cy - (float)q[1], dz = cz - (float)q[2];
             const float w0 = (float)(q[3] * P.wscale), w1 = (float)(q[4] * P.wscale), w2c = (float)(q[5] * P.wscale);   // (scaled: see the staging below)
@@ -306,43 +293,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                 ny = dy;
                 nz = dz;
             }
-        };
-#if SHM_TIER_NEAREST_PRUNE
-        if (P.n_clusters >= 8) {
-            // Round 5 (late): the search goes through the clusters' bounding spheres first.  Every block used to read EVERY source (48 bytes each) to find its nearest one:
-            // 2.3 MB per block on SprayBottle.pc (48 893 points) -- 9.8 TB of L2 reads over the 4.2 million blocks of 1024^3 and a seventh of Step 1 there.  Now: the smallest
-            // upper bound (distance to a cluster's centre + its radius) over all clusters, one cluster per lane; then only the clusters whose lower bound (distance - radius)
-            // does not exceed it are searched, a lane per source as before -- a handful of clusters.  Same winner, same ties: a lane meets its sources in the same order
-            // as before, and the nearest source (and every source tied with it) lies in a cluster that is searched.
-            float ub = 3.0e38f;
-            for (int c = lane; c < P.n_clusters; c += kWave) {
-                const float* rec = clusters + (size_t)c * kConvClusterRec;
-                const float gx = cx - rec[0], gy = cy - rec[1], gz = cz - rec[2];
-                ub = fminf(ub, sqrtf(gx * gx + gy * gy + gz * gz) * 1.00001f + rec[3]);
-            }
-            ub = __uint_as_float(wave_min_u(__float_as_uint(ub))) * 1.0001f + 1e-30f;   // (non-negative floats order like their bit patterns)
-            for (int c0 = 0; c0 < P.n_clusters; c0 += kWave) {
-                const int c = c0 + lane;
-                bool cand = false;
-                if (c < P.n_clusters) {
-                    const float* rec = clusters + (size_t)c * kConvClusterRec;
-                    const float gx = cx - rec[0], gy = cy - rec[1], gz = cz - rec[2];
-                    cand = sqrtf(gx * gx + gy * gy + gz * gz) * 0.9999f - rec[3] <= ub;
-                }
-                unsigned long long mask = __ballot(cand);
-                while (mask) {
-                    const int b = (int)__builtin_ctzll(mask);
-                    mask &= mask - 1ull;
-                    visit((c0 + b) * kTierCluster + lane);
-                }
-            }
-        } else
-#endif
-        {
-            for (int s = lane; s < P.S; s += kWave) visit(s);
         }
-        {   // the lane that holds the nearest source (ties: the larger weight, then the lower lane), then its five values by v_readlane
-
+        {   // the lane that holds the nearest source (ties: the larger weight, then the lower lane), then its five values by v_readlane.  Minimum / maximum over the wave
+            // by ds_swizzle butterflies within the halves + two v_readlane: no per-step lane index held in a register (the __shfl_xor form kept six of them live
+            // through the whole kernel), a sixth of the instructions of a five-value butterfly
+            auto wave_min_u = [&](unsigned v) {
+                v = min(v, (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1f | (1 << 10)));    // bit-mask mode: lane ^ 1, 2, 4, 8, 16 within each half
+                v = min(v, (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1f | (2 << 10)));
+                v = min(v, (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1f | (4 << 10)));
+                v = min(v, (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1f | (8 << 10)));
+                v = min(v, (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1f | (16 << 10)));
+                return min((unsigned)__builtin_amdgcn_readlane((int)v, 0), (unsigned)__builtin_amdgcn_readlane((int)v, 32));
+            };
             // (squared distances and squared weights are >= 0: their bit patterns order like the values)
             const unsigned dbits = wave_min_u(__float_as_uint(dmin));
             const unsigned wkey = __float_as_uint(dmin) == dbits ? ~__float_as_uint(wnear) : 0xffffffffu;
