@@ -627,6 +627,8 @@ def test_phi_of_the_default_solve_against_c_oracle_at_full_size(shm, oracle_c, h
     s.set_problem(pre["pos"], pre["wnormal"], pre["area"], pre["lam"], n, pre["bbox_min"], pre["cell"])
     st = s.solve(scrub=True)
     phi, _ = s.get_phi()
+    ste = s.solve(scrub=True, step1="exact_f64")        # the reference's arithmetic in every pair of Step 1 (round 5: through the tiered kernel's fp64 body)
+    phi_exact, _ = s.get_phi()
     s.close()
     ref = np.zeros(n ** 3)
     sto = np.zeros(5)
@@ -644,6 +646,9 @@ def test_phi_of_the_default_solve_against_c_oracle_at_full_size(shm, oracle_c, h
     print("\nphi bunny_small.obj n=%d: default solve (solver %d, %d iterations, rel %.1e) against the C oracle (%d CG iterations, rel %.1e, %.1f s on %d threads): L_inf %.3e, phi in [%.4f, %.4f]"
           % (n, st.solver, st.iters, st.rel_residual, int(sto[1]), sto[2], t_or, threads, err, phi.min(), phi.max()))
     assert err < 1e-7, err
+    err_exact = float(np.abs(phi_exact - ref).max())
+    print("phi bunny_small.obj n=%d: step1_arith = EXACT_F64 (pairs fp64 %.3e, fp32 %.0f) against the C oracle: L_inf %.3e" % (n, ste.pairs_fp64, ste.pairs_fp32, err_exact))
+    assert err_exact < 1e-7 and ste.pairs_fp32 == 0, err_exact
 
 
 ALL_DATA = ["bunny_small.obj", "polygon-bear.obj", "rocker.obj", "chair.obj", "knot.obj", "bunny.pc", "rocker.pc", "chair.pc", "knot.pc", "SprayBottle.pc"]
