@@ -231,6 +231,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
     const float hx = uniform_f32((float)(kHalfX * P.cell) * 1.000001f), hy = uniform_f32((float)(kHalfY * P.cell) * 1.000001f),
                 hz = uniform_f32((float)(kHalfZ * P.cell) * 1.000001f);   // half extents of a block
     unsigned long long cnt_near = 0, cnt_far = 0, cnt_redo = 0;
+    int decided = -1;   // the sample's verdict, once this wave has needed it
     // Eight queue heads, one per XCD (workgroup b runs on XCD b % 8): the units -- x fastest, then y, then z -- are cut into eight contiguous ranges, so
     // that the two 64-byte halves of a 128-byte line of Y (x-adjacent blocks) are written through the same L2 and leave it as one line; an XCD
     // whose range is exhausted takes units from the others' (work stealing keeps the end of the kernel balanced).
@@ -255,6 +256,29 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
         if (unit == 0xffffffffu) break;
         const int tzq = (int)(unit / (unsigned)(P.tiles_x * P.tiles_y)), trem = (int)unit - tzq * (P.tiles_x * P.tiles_y);
         const int tz = P.layer_order ? P.layer_order[tzq] : tzq;   // (the queues run from the layers at the grid's centre to the ones at its faces: launch_conv)
+        // Which far rule this block classifies with (see Solver::far_rule_plan): P.far_rule for every block, or per layer of the queue order -- 1: the SAMPLE (differential
+        // rule; its counters decide), 0: box rule whatever the sample says (the layers every queue works through while the sample finishes), 2: what the sample earned.
+        bool use_diff = false;
+        int rule_sel = -1;
+        if constexpr (CHECK) {
+            use_diff = P.far_rule != 0;
+            if (P.unit_rule) {
+                rule_sel = (int)P.unit_rule[tzq];
+                if (rule_sel == 2) {
+                    if (decided < 0) {   // (once per wave; every wave reads the same three numbers once all sample blocks have reported)
+                        volatile unsigned long long* sc = P.sample_ctr;
+                        while (__builtin_amdgcn_readfirstlane((int)(sc[2] >= (unsigned long long)P.sample_blocks)) == 0) __builtin_amdgcn_s_sleep(32);
+                        __threadfence();
+                        const unsigned long long farp = sc[0], redo = sc[1];
+                        decided = __builtin_amdgcn_readfirstlane((int)(farp > 0 && redo * 25ull <= farp));   // at most 4 % of the sample's far pairs evaluated again
+                    }
+                    use_diff = decided != 0;
+                } else {
+                    use_diff = rule_sel == 1;
+                }
+            }
+        }
+        const unsigned long long far_before = cnt_far, redo_before = cnt_redo;
         const int ty = trem / P.tiles_x, tx = trem - ty * P.tiles_x;
         const int i0 = tx * kTierTX, j0 = ty * kTierTY, kk0 = P.kk_begin + tz * NPT;
 
@@ -342,6 +366,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
         for (int e = 0; e < NPT / 2; e++) fl[e] = float2v{0.f, 0.f};
         // constant of the exponent-range test of a far source: lambda' (dist + 2 rt_w) - coff - log2(w_s / w_max) <= 113  (see the header)
         const float range_c = uniform_f32(2.f * rt_w * lam_l2 - 113.f - coff);
+        // the differential far rule's block constants: unit vector from the nearest source s* to the centre, its distance from the centre (rounded up) and the reciprocal of
+        // its distance from the block's box (inf when the block holds it: the rule then never fires)
+        float star_ux = 0.f, star_uy = 0.f, star_uz = 0.f, star_dc = 0.f, star_inv_d = 0.f;
+        if constexpr (CHECK) {
+            if (use_diff) {
+                const float inv = dmin > 0.f ? 1.f / dmin : 0.f;
+                star_ux = uniform_f32(nx * inv);
+                star_uy = uniform_f32(ny * inv);
+                star_uz = uniform_f32(nz * inv);
+                star_dc = uniform_f32(dmin * 1.000001f);
+                const float bx = fmaxf(fabsf(nx) - hx, 0.f), by = fmaxf(fabsf(ny) - hy, 0.f), bz = fmaxf(fabsf(nz) - hz, 0.f);
+                const float db = sqrtf(bx * bx + by * by + bz * bz);
+                star_inv_d = uniform_f32(dmin > 0.f && db > 0.f ? 1.f / db : __builtin_huge_valf());
+            }
+        }
         // pass 0: near sources in fp64, far ones in packed fp32.  pass 1 (only when the a-posteriori test failed): the far sources again, in fp64.
 #pragma unroll 1
         for (int pass = 0; pass < 2; pass++) {
@@ -426,7 +465,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                 const float lhs = (dist * 0.999999f - r_hi_w) * lam_l2;                    // lower bound of lambda (r(x, s) - r_near(x)) / ln 2
                 const bool valid = w2 > 0.f;                                              // the zero-weight padding is never evaluated
                 const bool in_range = fmaf(dist, lam_l2, range_c) <= lw;                   // every term of the source stays a normal fp32 number over the block
-                const bool far = lhs > g_l2 + rel && in_range;
+                float lhs_far = lhs;
+                if constexpr (CHECK) {
+                    if (use_diff) {
+                        // Differential rule (round 5, late; chosen per problem, see Solver::choose_far_rule): with s* the source nearest to the block's centre c,
+                        //   r_s(x) - r_near(x) >= f(x) := r_s(x) - r_s*(x) >= f(c) - rt (|u_s(c) - u_s*(c)| + rt (1 / d_s + 1 / d_s*))      for every x of the block
+                        // (u: unit vectors towards c; d: distances to the block's box -- the gradient of f is u_s - u_s*, a unit vector turns by at most |x - c| / d).  Two
+                        // sources in similar directions keep their DIFFERENCE of distances over the block although each distance varies by the block's diameter: the
+                        // box rule loses 2 rt lambda e-folds there.  More sources go to the packed-fp32 tier (bunny 256^3: 0.50 -> 0.60 of the pairs); the a-posteriori
+                        // test below is what keeps the budget, whatever rule filled the tier.
+                        const float ex = cx - q32[0], ey = cy - q32[1], ez = cz - q32[2];
+                        const float dc2 = ex * ex + ey * ey + ez * ez, rdc = __builtin_amdgcn_rsqf(dc2), dc = dc2 * rdc;
+                        const float dot = (ex * star_ux + ey * star_uy + ez * star_uz) * rdc;
+                        const float du = sqrtf(fmaxf(0.f, 2.f - 2.f * dot));
+                        const float lip = du + rt_w * (__builtin_amdgcn_rcpf(dist) + star_inv_d);
+                        const float lhs2 = (dc * 0.999999f - star_dc - rt_w * lip * 1.00001f) * lam_l2;
+                        lhs_far = fmaxf(lhs, lhs2);   // (NaN -- the source at the centre -- leaves the box rule)
+                    }
+                }
+                const bool far = lhs_far > g_l2 + rel && in_range;
                 const bool drop = lhs > skip_l2 + rel;
                 const bool to64 = valid && !drop && (pass == 0 ? !far : far);   // (drop first: a source outside the fp32 exponent range is not "far", but it may well be dropped)
                 const bool to32 = valid && pass == 0 && far && !drop;
@@ -565,6 +622,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
             Y0[vi] = (TY)(x0 / nrm);
             Y1[vi] = (TY)(x1 / nrm);
             Y2[vi] = (TY)(x2 / nrm);
+        }
+        if constexpr (CHECK) {
+            if (rule_sel == 1 && lane == 0) {   // a sample block reports: far pairs, pairs evaluated again, then -- behind a fence -- that it is done
+                atomicAdd(P.sample_ctr + 0, (cnt_far - far_before) * (unsigned long long)(64 * NPT));
+                atomicAdd(P.sample_ctr + 1, (cnt_redo - redo_before) * (unsigned long long)(64 * NPT));
+                __threadfence();
+                atomicAdd(P.sample_ctr + 2, 1ull);
+            }
         }
     }  // unit loop
     if (counters && lane == 0) {

@@ -462,6 +462,10 @@ struct Slab {
     DevArray<ShiftItem> shift_items;
     DevArray<double> dv;  // dual solver m-vectors: mu, r, p, z, t1, t2, g (7 x mp)
     DevArray<int> layer_order;   // tiered Step 1: z-layers of blocks in queue order (layer_order_for)
+    DevArray<int> sample_order;               // ... when the far rule is decided from a sample (far_rule_plan)
+    DevArray<unsigned char> sample_rule;      // rule per layer of that order: 1 sample, 0 box, 2 decided
+    DevArray<unsigned long long> sample_ctr;  // the sample's counters (see ConvParams)
+    long long sample_key = -1;
     long long layer_order_key = -1;
     DevArray<double> div_partials;   // per-workgroup sums of b written by the divergence kernel (div_sum_blocks of them; 0: not available, sum b with sum_kernel)
     int div_sum_blocks = 0;
@@ -502,6 +506,7 @@ struct Solver final : SolverBase {
     DevArray<float> d_clusters_t;
     int n_clusters_t = 0;
     bool conv_tiered = false;                                  // fp64 only; SHM_CONV_EXACT=1 selects the all-fp64 kernel
+    int far_rule = 0;                                          // tiered fp64 Step 1 without a sample launch: 0 = box rule (see far_rule_sampled)
     bool conv_tier_exact = false;                              // ... with every pair in its fp64 body (SHM_STEP1_EXACT_F64 where the exponent span allows)
     bool conv_tiered32 = false;                                // fp32 handles: Step 1 through the tiered kernel's packed-fp32 body
     bool fold_pq = false;                                      // fused stencil CG on one GPU: the RES sweep sums the DIR sweep's partials of p'.Kp' itself
@@ -1008,6 +1013,64 @@ struct Solver final : SolverBase {
         sl.layer_order_key = key;
         return sl.layer_order.p;
     }
+    // Which far rule the tiered fp64 Step 1 classifies with (ConvParams::far_rule).  SHM_TIER_FAR_RULE=0/1: A/B knob.
+    int far_rule_now() const {
+        const char* e = knob("SHM_TIER_FAR_RULE");
+        if (e) return atoi(e) != 0;
+        return far_rule > 0;
+    }
+    // The differential far rule moves a tenth of the pairs from the fp64 body to the packed-fp32 one -- and on some inputs fills the tier so far that the a-posteriori test
+    // sends a fifth of the blocks through the second pass (measured, Step 1 alone: bunny_small 256^3 -5.5 %, rocker 128^3 -17 %, SprayBottle.pc 256^3 -12.5 %; rocker 256^3
+    // +4.5 %, rocker 512^3 +29 %; profiles/r05_far_rule.txt).  Which it is depends on how much of |X| cancels where, i.e. on the input.  So the kernel finds out on a SAMPLE:
+    // eight layers of blocks spread over the planes run under the rule (real work: their Y stands) and report their far pairs and the pairs evaluated again; every queue then
+    // works through one layer under the box rule -- work that needs no verdict, long enough for the sample to finish -- and the rest of the grid runs under the rule iff at
+    // most 4 % of the sample's far pairs were evaluated again (every wave reads the same counters: far_rule_plan, conv_tiered_kernel).  One launch, no host round trip, nothing
+    // tuned outside the solve; deterministic (same sample, counters and verdict in every solve of a problem).  Where one process holds the whole grid, the grid has >= 64 layers
+    // of blocks (256^3 upwards) and the budget is the default one; everything else keeps the box rule.  A first version that read the sample's counters on the host between two
+    // launches lost the gain to the sample launch's tail.
+    int far_rule_last = 0;   // what the last Step 1 ran with: 0 box, 1 differential, -1 decided on the device from the sample
+    // Does this Step 1 decide its far rule from a sample?  Builds (once per problem) the queue order of the layers and the rule of every position: each of the eight queues
+    // starts with ONE sample layer (differential rule; spread over the planes), goes on with one of the eight most central remaining layers under the box rule -- work that
+    // needs no verdict, long enough for every sample block to finish meanwhile --, and then runs its share of the rest, centre to faces, under the rule the sample earned.
+    bool far_rule_plan(Slab<T>& sl, int planes, int npt) {
+        far_rule_last = far_rule_now();
+        if (sizeof(T) != 8 || !conv_tiered || conv_tier_exact || slabs.size() != 1 || total_slabs != 1 || knob("SHM_TIER_FAR_RULE") != nullptr || knob("SHM_TIER_NO_SAMPLE") != nullptr) return false;
+        if (step1_budget > 0. && step1_budget != kTierBudget) return false;
+        const int layers = (planes + npt - 1) / npt;
+        if (layers < 64 || layers % 8 != 0 || planes % npt != 0) return false;
+        const long long key = ((long long)layers << 32) ^ ((long long)npt << 16);
+        if (sl.sample_key != key) {
+            std::vector<char> role((size_t)layers, 2);
+            std::vector<int> A, B1;
+            for (int a = 0; a < 8; a++) {
+                const int l = (int)(((long long)(2 * a + 1) * layers) / 16);
+                A.push_back(l);
+                role[(size_t)l] = 1;
+            }
+            std::vector<std::pair<double, int>> byc;
+            for (int l = 0; l < layers; l++)
+                if (role[(size_t)l] != 1) byc.push_back({std::fabs((double)(sl.k0 + l * npt) + 0.5 * (npt - 1) - 0.5 * (n - 1)), l});
+            std::stable_sort(byc.begin(), byc.end());
+            for (int a = 0; a < 8; a++) B1.push_back(byc[(size_t)a].second);
+            std::vector<int> order;
+            std::vector<unsigned char> rule;
+            for (int q = 0; q < 8; q++) {
+                order.push_back(A[(size_t)q]);
+                rule.push_back(1);
+                order.push_back(B1[(size_t)q]);
+                rule.push_back(0);
+                for (size_t r = 8 + (size_t)q; r < byc.size(); r += 8) {
+                    order.push_back(byc[r].second);
+                    rule.push_back(2);
+                }
+            }
+            sl.sample_order.upload(order, stream);
+            sl.sample_rule.upload(rule, stream);
+            sl.sample_ctr.alloc(4);
+            sl.sample_key = key;
+        }
+        return true;
+    }
     void launch_conv() {
         const bool slab_log = knob("SHM_CONV_SLAB_LOG") != nullptr;
         Event slab_ev[2];
@@ -1019,6 +1082,10 @@ struct Solver final : SolverBase {
             }
             ConvParams P;
             P.layer_order = nullptr;
+            P.unit_rule = nullptr;
+            P.sample_ctr = nullptr;
+            P.sample_blocks = 0;
+            P.far_rule = conv_tiered && !conv_tier_exact && sizeof(T) == 8 ? far_rule_now() : 0;
             P.n = n;
             P.kk_begin = 1;  // owned planes only: the ghost planes of Y are exchanged (exchange_Y_halos), not recomputed -- a ghost plane
             P.kk_end = sl.nzl + 1;  // would cost a whole 16-plane tile layer of Step 1 (41 % extra on 8 GPUs at 256^3)
@@ -1106,7 +1173,7 @@ struct Solver final : SolverBase {
             }
             unsigned long long* const cnt = d_pair_counters.p;
             // one launch over the local planes [1 + b0, 1 + b1) with the kernel shape `sel` (nodes per lane: 8 / 4 / 2; the tiered kernel ignores it)
-            auto launch_range = [&](int b0, int b1, int sel) {
+            auto launch_range = [&](int b0, int b1, int sel, int rule = -1, const int* order = nullptr, int order_layers = 0) {
                 if (b1 <= b0) return;
                 conv_launches_last++;
                 const int tz_sel = 4 * sel;
@@ -1122,9 +1189,10 @@ struct Solver final : SolverBase {
                     const int npt = npt4 ? 4 : 2;
                     Pc.tiles_x = (n + kTierTX - 1) / kTierTX;
                     Pc.tiles_y = (n + kTierTY - 1) / kTierTY;
-                    const int layers = (Pc.kk_end - Pc.kk_begin + npt - 1) / npt;
+                    const int layers = order ? order_layers : (Pc.kk_end - Pc.kk_begin + npt - 1) / npt;
                     Pc.n_tiles = Pc.tiles_x * Pc.tiles_y * layers;
-                    Pc.layer_order = layer_order_for(sl, Pc.kk_begin, layers, npt);
+                    Pc.layer_order = order ? order : layer_order_for(sl, Pc.kk_begin, layers, npt);
+                    if (rule >= 0) Pc.far_rule = rule;
                     const dim3 gt((unsigned)std::min<long long>((Pc.n_tiles + 3) / 4, grid));
                     if constexpr (sizeof(T) == 8) {
                         if (npt4)
@@ -1168,6 +1236,16 @@ struct Solver final : SolverBase {
                     launch_range(b, b + take, sel);
                     b += take;
                 }
+            } else if (far_rule_plan(sl, planes, npt4 ? 4 : 2)) {
+                // one launch: sample layers, box layers, then the layers that run under the sample's verdict (far_rule_plan; the waves decide from the sample's counters themselves)
+                const int npt = npt4 ? 4 : 2, layers = planes / npt;
+                HIPCHK(hipMemsetAsync(sl.sample_ctr.p, 0, 4 * sizeof(unsigned long long), stream));
+                P.unit_rule = sl.sample_rule.p;
+                P.sample_ctr = sl.sample_ctr.p;
+                P.sample_blocks = 8 * ((n + kTierTX - 1) / kTierTX) * ((n + kTierTY - 1) / kTierTY);
+                launch_range(0, planes, sel0, 0, sl.sample_order.p, layers);
+                P.unit_rule = nullptr;
+                far_rule_last = -1;   // (decided on the device: shm_grid_last_far_rule reads the counters)
             } else {
                 for (int b0 = 0; b0 < planes; b0 += chunk_planes) launch_range(b0, std::min(planes, b0 + chunk_planes), sel0);
             }

@@ -152,6 +152,10 @@ struct ConvParams {
     double pad_pos[3];     // tiered fp64 path: where the zero-weight padding entries of a compacted source list sit (bbox_min - n cell: a grid side from every node)
     float far_redo_ratio;  // tiered fp64 path: a block whose packed-fp32 sums exceed this fraction of |X| at any node evaluates its far sources again in fp64
                            // (= budget on Y / calibrated relative error of a packed-fp32 term; 3e38: never)
+    int far_rule;             // tiered fp64 path: 1 = the differential far rule beside the box rule (shm_conv_tiered.hip.h; chosen per problem by Solver::choose_far_rule)
+    const unsigned char* unit_rule;        // tiered fp64 path: far rule per layer of the queue order (nullptr: far_rule everywhere) -- 1 sample, 0 box, 2 as the sample decides
+    unsigned long long* sample_ctr;        // ... [0] far pairs, [1] pairs evaluated again, [2] blocks done of the sample (zeroed before the launch)
+    int sample_blocks;                     // ... blocks of the sample
     const int* layer_order;   // tiered path: z-layer of blocks that stands at position p of the work queues' order (nullptr: p itself) -- see launch_conv
 };
 
