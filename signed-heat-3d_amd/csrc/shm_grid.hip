@@ -466,6 +466,7 @@ struct Slab {
     DevArray<unsigned char> sample_rule;      // rule per layer of that order: 1 sample, 0 box, 2 decided
     DevArray<unsigned long long> sample_ctr;  // the sample's counters (see ConvParams)
     long long sample_key = -1;
+    int sample_blocks = 0;
     long long layer_order_key = -1;
     DevArray<double> div_partials;   // per-workgroup sums of b written by the divergence kernel (div_sum_blocks of them; 0: not available, sum b with sum_kernel)
     int div_sum_blocks = 0;
@@ -1042,8 +1043,10 @@ struct Solver final : SolverBase {
         if (sl.sample_key != key) {
             std::vector<char> role((size_t)layers, 2);
             std::vector<int> A, B1;
-            for (int a = 0; a < 8; a++) {
-                const int l = (int)(((long long)(2 * a + 1) * layers) / 16);
+            const int nA = 8;   // sample layers: one per queue.  (Four -- every second queue -- where a layer holds 4096 blocks and more was measured at 512^3: rocker no cheaper, 584.9 against
+                                // 585.3 ms, and the bunny's verdict flipped to the box rule, 190.2 against 188.6 ms: the smaller sample sits on other planes.)
+            for (int a = 0; a < nA; a++) {
+                const int l = (int)(((long long)(2 * a + 1) * layers) / (2 * nA));
                 A.push_back(l);
                 role[(size_t)l] = 1;
             }
@@ -1054,16 +1057,35 @@ struct Solver final : SolverBase {
             for (int a = 0; a < 8; a++) B1.push_back(byc[(size_t)a].second);
             std::vector<int> order;
             std::vector<unsigned char> rule;
-            for (int q = 0; q < 8; q++) {
-                order.push_back(A[(size_t)q]);
-                rule.push_back(1);
+            size_t next_rest = 8;   // byc[0 .. 7] are the box layers; the rest is handed out centre to faces, a layer per queue in turn
+            std::vector<std::vector<int>> rest(8);
+            {
+                std::vector<int> want(8);
+                for (int q = 0; q < 8; q++) want[(size_t)q] = layers / 8 - 1 - ((nA == 8 || q % 2 == 0) ? 1 : 0);
+                bool any = true;
+                while (any && next_rest < byc.size()) {
+                    any = false;
+                    for (int q = 0; q < 8 && next_rest < byc.size(); q++)
+                        if ((int)rest[(size_t)q].size() < want[(size_t)q]) {
+                            rest[(size_t)q].push_back(byc[next_rest++].second);
+                            any = true;
+                        }
+                }
+            }
+            for (int q = 0, a = 0; q < 8; q++) {
+                if (nA == 8 || q % 2 == 0) {
+                    order.push_back(A[(size_t)a++]);
+                    rule.push_back(1);
+                }
                 order.push_back(B1[(size_t)q]);
                 rule.push_back(0);
-                for (size_t r = 8 + (size_t)q; r < byc.size(); r += 8) {
-                    order.push_back(byc[r].second);
+                for (int l : rest[(size_t)q]) {
+                    order.push_back(l);
                     rule.push_back(2);
                 }
             }
+            if ((int)order.size() != layers) throw Error(SHM_ERR_INVALID, "far_rule_plan: internal count mismatch");
+            sl.sample_blocks = nA * ((n + kTierTX - 1) / kTierTX) * ((n + kTierTY - 1) / kTierTY);
             sl.sample_order.upload(order, stream);
             sl.sample_rule.upload(rule, stream);
             sl.sample_ctr.alloc(4);
@@ -1242,7 +1264,7 @@ struct Solver final : SolverBase {
                 HIPCHK(hipMemsetAsync(sl.sample_ctr.p, 0, 4 * sizeof(unsigned long long), stream));
                 P.unit_rule = sl.sample_rule.p;
                 P.sample_ctr = sl.sample_ctr.p;
-                P.sample_blocks = 8 * ((n + kTierTX - 1) / kTierTX) * ((n + kTierTY - 1) / kTierTY);
+                P.sample_blocks = sl.sample_blocks;
                 launch_range(0, planes, sel0, 0, sl.sample_order.p, layers);
                 P.unit_rule = nullptr;
                 far_rule_last = -1;   // (decided on the device: shm_grid_last_far_rule reads the counters)
