@@ -272,44 +272,14 @@ def also_legs(shm, HostSolver, device, tol, pre256, scrub256):
 
 
 def multi_gpu_legs(shm, HostSolver, dist, torch, args, pre, precision, scrub, rank, world, local_rank, barrier):
-    """N > 1 only.  The timed default above is the gathered dual solve (Steps 1-2 on z-slabs, D^T Y gathered, whole-grid solve replicated).  The split the
+    """N > 1 only.  The timed default above is the library's AUTO: since round 6 the slab-distributed explicit-S dual solve where it applies (256^3 ... 512^3, S <= 16384:
+    S and S^-1 replicated beside every rank's Step 1, K^+ on the z-slabs), the gathered dual solve elsewhere (Steps 1-2 on z-slabs, D^T Y gathered, whole-grid solve
+    replicated) -- which also runs here as the leg "gathered_dual" for the comparison.  BASELINE.json's own multi-GPU configurations come first.  The split the
     north star names -- z-slab stencil PCG with a one-plane halo exchange per sweep and an all-reduce per dot product -- is SHM_SOLVER_PRIMAL; it is
     run here as further legs on the SAME ranks so that whichever multi-GPU run the driver gets covers both: the DCT-preconditioned stencil PCG to the
     tolerance (z-slab transforms: two all-to-alls per application) and the plain stencil CG for a fixed 200 iterations (halo + two all-reduces per
     iteration, nothing else).  Collective: every rank calls this with the same arguments."""
-    box = [shm.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0)
-    s = shm.GridSolver(device=local_rank, precision=precision, rank=rank, world=world, rccl_unique_id=box[0], slab_plan=0)   # equal planes: what the z-slab transforms need
-    n = pre["n"]
-    N = n ** 3
-    s.set_problem(pre["pos"], pre["wnormal"], pre["area"], pre["lam"], n, pre["bbox_min"], pre["cell"])
     out = {}
-    legs = [("primal_pcg", dict(solver="primal", precond="auto", tol=args.tol), max(1, min(3, args.steps))),
-            ("primal_plain_cg_200", dict(solver="primal", precond="none", tol=1e-30, max_iters=200, allow_noconv=True), 1)]
-    for name, kw, reps in legs:
-        try:
-            s.solve(scrub=scrub, **kw)
-            barrier()
-            t0 = time.perf_counter()
-            sts = [s.solve(scrub=scrub, **kw).as_dict() for _ in range(reps)]
-            barrier()
-            dt = time.perf_counter() - t0
-            tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item()) / reps
-            a = {k: float(np.mean([x[k] for x in sts])) for k in sts[0]}
-            _, kinfo = kernel_table(a, N / world, precision // 8, world, False)
-            per_iter = a["ms_pcg"] / max(1.0, a["iters"])
-            out[name] = {"value": N / dt, "unit": "grid-nodes/s", "ms_per_step": 1e3 * dt, "steps": reps, "cg_iters": int(a["iters"]), "rel_residual": a["rel_residual"],
-                         "preconditioner": "dct (z-slab transforms, two all-to-alls per application)" if int(a["preconditioner"]) == 2 else "none",
-                         "per_iteration": "one-plane halo of the direction to each slab neighbour before the DIR sweep, all-reduce of p.Kp, all-reduce of [||r||^2, A r]",
-                         "phases_ms": {k: a[k] for k in ("ms_conv", "ms_div", "ms_wait_setup", "ms_pcg", "ms_shift", "ms_total")},
-                         "ms_per_iter": per_iter, "algorithmic_bytes_per_iter_per_rank": a["bytes_per_iter"] / world,
-                         "loop_frac_of_hbm_peak_per_rank": a["bytes_per_iter"] / world / (per_iter * 1e-3) / 1e9 / HBM_PEAK_GBS if per_iter > 0 else None,
-                         "kernels": kinfo}
-        except Exception as e:   # never lose the headline over an extra leg (every rank fails alike: the library's checks are rank-independent)
-            out[name] = {"failed": repr(e)}
-    s.close()
     # BASELINE.json's own multi-GPU configurations, end to end with the library defaults on the SAME ranks: configs[3] (bunny.pc 512^3 fp64) and configs[4]
     # (SprayBottle.pc 1024^3 fp32, z-slabs weighted by the Step-1 work the source culling leaves in them) -- so that whichever multi-GPU record the driver
     # gets carries them whatever --workload it timed.  SHM_BENCH_MULTI_HCOEF: stand-in grid size for the flow test on a one-GPU box.
@@ -319,7 +289,14 @@ def multi_gpu_legs(shm, HostSolver, dist, torch, args, pre, precision, scrub, ra
         try:
             path2, hc2, prec2 = WORKLOADS[wl]
             hc2 = float(os.environ.get("SHM_BENCH_MULTI_HCOEF", hc2))
-            pre2 = HostSolver(os.path.join(ROOT, path2)).preprocess(hCoef=hc2)
+            try:
+                pre2 = HostSolver(os.path.join(ROOT, path2)).preprocess(hCoef=hc2)
+            except Exception as e:   #  a rank that fails BEFORE the collectives below must not leave the others waiting in them: everyone learns of it first
+                pre2, pre_err = None, repr(e)
+            oks = [None] * world
+            dist.all_gather_object(oks, pre2 is not None)
+            if not all(oks):
+                raise RuntimeError("host pre-processing failed on rank(s) %s%s" % ([r for r, ok in enumerate(oks) if not ok], "" if pre2 is not None else ": " + pre_err))
             box = [shm.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             plan = 1 if prec2 == 32 else 0
@@ -344,12 +321,49 @@ def multi_gpu_legs(shm, HostSolver, dist, torch, args, pre, precision, scrub, ra
             out[wl + "_end_to_end"] = {"value": n2 ** 3 / dt, "unit": "grid-nodes/s", "ms_per_step": 1e3 * dt, "steps": reps, "grid": "%d^3" % n2, "sources": int(pre2["S"]),
                                        "constraint_rows": int(a["m"]), "dtype": "f64 (Step 1: f64 / packed-f32 tiers)" if prec2 == 64 else "f32",
                                        "partition": "z-slabs x%d%s" % (world, " (planes weighted by Step-1 work)" if plan else ""),
-                                       "solver": int(a["solver"]), "cg_iters": int(a["iters"]), "rel_residual": a["rel_residual"],
+                                       "solver": int(a["solver"]), "cg_form": int(a["cg_form"]), "cg_iters": int(a["iters"]), "rel_residual": a["rel_residual"],
                                        "phases_ms": {k: a[k] for k in ("ms_conv", "ms_div", "ms_wait_setup", "ms_pcg", "ms_shift", "ms_total")},
                                        "per_rank": per_rank}
             s2.close()
         except Exception as e:
             out[wl + "_end_to_end"] = {"failed": repr(e)}
+    box = [shm.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    s = shm.GridSolver(device=local_rank, precision=precision, rank=rank, world=world, rccl_unique_id=box[0], slab_plan=0)   # equal planes: what the z-slab transforms need
+    n = pre["n"]
+    N = n ** 3
+    s.set_problem(pre["pos"], pre["wnormal"], pre["area"], pre["lam"], n, pre["bbox_min"], pre["cell"])
+    # (round 6: the timed default is the slab-distributed explicit-S dual solve where it applies; "gathered_dual" is the default of rounds 1-5 -- D^T Y gathered, the whole-grid
+    # solve replicated on every rank -- on the same ranks, for the comparison)
+    legs = [("gathered_dual", dict(solver="dual", tol=args.tol), max(1, min(3, args.steps))),
+            ("primal_pcg", dict(solver="primal", precond="auto", tol=args.tol), max(1, min(3, args.steps))),
+            ("primal_plain_cg_200", dict(solver="primal", precond="none", tol=1e-30, max_iters=200, allow_noconv=True), 1)]
+    for name, kw, reps in legs:
+        try:
+            s.solve(scrub=scrub, **kw)
+            barrier()
+            t0 = time.perf_counter()
+            sts = [s.solve(scrub=scrub, **kw).as_dict() for _ in range(reps)]
+            barrier()
+            dt = time.perf_counter() - t0
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item()) / reps
+            a = {k: float(np.mean([x[k] for x in sts])) for k in sts[0]}
+            _, kinfo = kernel_table(a, N / world, precision // 8, world, False)
+            per_iter = a["ms_pcg"] / max(1.0, a["iters"])
+            out[name] = {"value": N / dt, "unit": "grid-nodes/s", "ms_per_step": 1e3 * dt, "steps": reps, "cg_iters": int(a["iters"]), "rel_residual": a["rel_residual"],
+                         "solver": int(a["solver"]), "cg_form": int(a["cg_form"]),
+                         "preconditioner": "dct (z-slab transforms, two all-to-alls per application)" if int(a["preconditioner"]) == 2 else "none",
+                         "per_iteration": "gather of D^T Y, whole-grid dual solve on every rank" if name == "gathered_dual" else
+                                          "one-plane halo of the direction to each slab neighbour before the DIR sweep, all-reduce of p.Kp, all-reduce of [||r||^2, A r]",
+                         "phases_ms": {k: a[k] for k in ("ms_conv", "ms_div", "ms_wait_setup", "ms_pcg", "ms_shift", "ms_total")},
+                         "ms_per_iter": per_iter, "algorithmic_bytes_per_iter_per_rank": a["bytes_per_iter"] / world,
+                         "loop_frac_of_hbm_peak_per_rank": a["bytes_per_iter"] / world / (per_iter * 1e-3) / 1e9 / HBM_PEAK_GBS if per_iter > 0 else None,
+                         "kernels": kinfo}
+        except Exception as e:   # never lose the headline over an extra leg (every rank fails alike: the library's checks are rank-independent)
+            out[name] = {"failed": repr(e)}
+    s.close()
     return out
 
 
@@ -556,7 +570,10 @@ def main():
         line_printed = [False]
 
         def watchdog():
-            if not legs_done.wait(float(os.environ.get("SHM_BENCH_LEGS_TIMEOUT", "300"))):
+            #  budgeted per leg: 120 s for each leg on the timed workload's grid (scaled with the grid beyond 256^3), 150 s for configs[3], 420 s for configs[4]
+            # (host pre-processing of 52 290 points, a 1024^3 set-up and two solves per rank); SHM_BENCH_LEGS_TIMEOUT overrides the sum
+            budget = 3 * 120.0 * max(1.0, (pre["n"] / 256.0) ** 3) + 150.0 + 420.0
+            if not legs_done.wait(float(os.environ.get("SHM_BENCH_LEGS_TIMEOUT", budget))):
                 with line_lock:
                     if line_printed[0]:
                         return

@@ -107,17 +107,22 @@ typedef struct {
 /* Form of the dual solver (SHM_SOLVER_DUAL / AUTO on one process; the same operator in every form, so the same phi up to the tolerance).
  * AUTO:          chosen per problem (DESIGN.md section 4b'): the direct solve where the inverse of S hides behind Step 1, else CG on the explicit S or through the grid.
  * DIRECT:        S = A K^+ A^T assembled from the image-sum Green's table and INVERTED beside Step 1; the solve is two dense mat-vecs + refinement passes.
- *                Applies for m <= 16384 rows, n <= 512, one z-slab; elsewhere the request falls back to AUTO's choice.
+ *                Applies for m <= 16384 rows and n <= 512, on one z-slab or -- round 6 -- on a power-of-two number of equal z-slabs with n a power of two (S and S^-1 are
+ *                then replicated on every rank and K^+ runs on the slabs: SHM_SOLVER_DUAL_SLABS, and what AUTO picks for 256 <= n <= 512 with S <= 16384 sources);
+ *                elsewhere the request falls back to AUTO's choice.
  * EXPLICIT_S_CG: S assembled, CG on it (one dense mat-vec per iteration), preconditioned by (A A^T)^-1 (A K A^T) (A A^T)^-1.
  * THROUGH_GRID:  CG with S applied through the grid (scatter, five transform sweeps, gather per iteration); no m x m matrix is formed.
- * stats.cg_form reports what ran (2 / 3 / 0). */
+ * stats.cg_form reports what ran (2 / 3 / 0).
+ * shm_opts is 48 bytes in ABI 5 (40 in ABI 4): shm_grid_solve reads sizeof(shm_opts) bytes from the caller, so a caller MUST check shm_grid_abi_version() == 5 before
+ * passing one -- a struct of an older ABI would be over-read and its trailing fields (dual_form, step1_budget) taken from whatever follows it. */
 enum { SHM_DUAL_AUTO = 0, SHM_DUAL_DIRECT = 1, SHM_DUAL_EXPLICIT_S_CG = 2, SHM_DUAL_THROUGH_GRID = 3 };
 
 /* Arithmetic of Step 1 (the N*S direct summation, signed_heat_grid_solver.cpp:48-65 / :157-174; yukawaPotential, signed_heat_3d.cpp:45-49) in an SHM_F64 handle.
  * AUTO:      error-budgeted precision tiers (csrc/shm_conv_tiered.hip.h): per block of 8 x 8 x 4 nodes, sources whose terms are below e^-8 of the block's
- *            dominant terms are summed in packed fp32, sources whose terms all together stay below 2e-9 of it are dropped; everything else in fp64.  The
- *            kernel checks the packed-fp32 sums against |X| at every node and re-evaluates a block's far sources in fp64 where they could move Y by more than
- *            the budget (cancellation regions; shm_stats.pairs_redone).  max|Y - Y_exact| < 1e-8 (asserted against the C oracle at the full sizes of
+ *            dominant terms are summed in packed fp32, sources whose terms all together stay below 2e-9 of it are dropped (round 6: by the accumulated sum of their
+ *            bounds, not S times the worst case); everything else in fp64.  The kernel checks the packed-fp32 sums AND the dropped sources' bound against |X| at
+ *            every node and re-evaluates a block's far and dropped sources in fp64 where they could move Y by more than the budget (cancellation regions;
+ *            shm_stats.pairs_redone).  max|Y - Y_exact| < 1e-8 (asserted against the C oracle at the full sizes of
  *            BASELINE.json), phi inherits < 1e-9.
  * EXACT_F64: every (node, source) pair in fp64 like the reference (~1.4x the Step-1 time); Y agrees with the serial loops to 1e-11.  (Round 5: the tiered kernel with nothing far
  * and nothing dropped where every pair of the grid stays inside a block's exponent span -- lambda * grid diagonal below ~600 --, the all-fp64 kernel of rounds 1-4 otherwise.)

@@ -139,6 +139,45 @@ __device__ __forceinline__ double exp2_tab(double u, const uint2v* __restrict__ 
 // a wave-uniform float as a scalar register (the builtin is integer-typed: pass the bits, not the value)
 __device__ __forceinline__ float uniform_f32(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
+// ---- The sample's verdict (far rule of the fp64 solve, Solver::far_rule_plan), handed from the sample blocks to every wave of the SAME launch (round 6: hardened) ----
+// ctr[0] far pairs, ctr[1] pairs evaluated again, ctr[2] sample blocks that have reported, ctr[3] the verdict: 0 undecided, 1 differential rule, 2 box rule.
+// All four words are only ever touched by agent-scope atomics (served by the L2 / fabric: no CU's L1 can hold a stale copy; MI355X_MICROARCH.md, inter-workgroup
+// visibility).  A sample block adds its two counts (relaxed) and then arrives with a RELEASE add on ctr[2] -- its counts are visible before its arrival is --;
+// the block whose arrival completes the sample reads the totals behind an ACQUIRE fence and publishes the verdict with ONE compare-and-swap on ctr[3].  A reader
+// polls ctr[3] with relaxed loads and s_sleep; there is no payload behind the flag, so the value it reads IS the verdict.  The spin is bounded: a reader that
+// gives up (~1 s: it means the sample's blocks are not being worked on -- a launch smaller than the resident set its queues assume) tries to publish "box rule"
+// itself, and whoever's compare-and-swap lands first decides for the WHOLE launch: no wave ever decides on its own, Y stays one function of the verdict word.
+__device__ __forceinline__ int sample_verdict(unsigned long long* ctr) {
+    int v = 0;   // (wave-uniform: lane 0's reading)
+    for (unsigned spins = 0; spins < (1u << 20); spins++) {
+        v = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ctr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (v != 0) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
+    if (v == 0) {   // timed out: the whole launch falls back to the box rule, unless a verdict lands first
+        int r = 0;
+        if ((threadIdx.x & 63u) == 0u) {
+            unsigned long long expected = 0ull;
+            const bool won = __hip_atomic_compare_exchange_strong(ctr + 3, &expected, 2ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            r = won ? 2 : (int)expected;
+        }
+        v = __builtin_amdgcn_readfirstlane(r);
+    }
+    return v == 1;
+}
+__device__ __forceinline__ void sample_report(unsigned long long* ctr, unsigned long long far_pairs, unsigned long long redo_pairs, int sample_blocks) {
+    __hip_atomic_fetch_add(ctr + 0, far_pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(ctr + 1, redo_pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long before = __hip_atomic_fetch_add(ctr + 2, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (before + 1ull == (unsigned long long)sample_blocks) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const unsigned long long farp = __hip_atomic_load(ctr + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long redo = __hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long expected = 0ull;   // at most 4 % of the sample's far pairs evaluated again -> the differential rule
+        __hip_atomic_compare_exchange_strong(ctr + 3, &expected, (farp > 0ull && redo * 25ull <= farp) ? 1ull : 2ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 #ifndef SHM_TIER_TX
 #define SHM_TIER_TX 8
 #endif
@@ -151,6 +190,12 @@ constexpr int kTierTX = SHM_TIER_TX, kTierTY = 64 / kTierTX;   // a wave's block
 // (A threshold that grows with the block's exponent offset -- eps_far proportional to lambda' r, as the 1-ulp error of v_rsq_f32 suggests -- was measured
 // too: SprayBottle.pc 1024^3 8.3e-9 -> 7.7e-9 for +9 % of its Step 1, knot 1024^3 +6.5 %; profiles/r04_eps_sweep.txt.  Not adopted.)
 constexpr double kTierBudget = 1.0e-8, kTierEpsFar = 3.0e-6;
+// Round 6: the calibration point of kTierEpsFar is lambda r = 28, i.e. a scaled exponent u = lambda' r = 40; a packed-fp32 term's error grows with its exponent (the rounding of
+// u, ~6e-8 u, goes straight into 2^-u), so the a-posteriori test prices a term at kTierEpsFar * max(1, u_block / kTierEpsFarU0), u_block the largest exponent of a nearest term in
+// the block (lambda' (d0 + 2 rt)): 7.5e-8 per unit of exponent, five times the observed slope like the constant it extends.  Found by the seeded adversarial inputs of
+// tests/test_gpu_parity.py::test_tier_budget_on_adversarial_inputs (a small dense cloud in a grid with lambda r up to ~1e3: 4.2e-8 against the 1e-8 budget under the constant).
+// The sample that decides the far rule (Solver::far_rule_plan) keeps counting with the constant: its verdict is about the rule's cost where the rule applies (u <= 72).
+constexpr float kTierEpsFarU0 = 40.0f;
 constexpr int kTierCluster = 64;                    // sources per cluster = lanes per wave: one source per lane in the classification
 constexpr int kTierChunk = 4;                       // clusters per LDS fill
 constexpr int kTierFill = kTierCluster * kTierChunk;
@@ -208,6 +253,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
     __shared__ double2 raw[kWaves][3][kTierCluster];
 #endif
     __shared__ uint2v exp_tab[2048];   // bits of 2^(j/2048) with (j << 9) taken off the high word (see yukawa_near)
+    __shared__ float4 star_stash[kWaves];   // the block's reference source (scaled position, squared weight), parked here between the block's set-up and its a-posteriori test
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
     double* const tile = stage64[wave];
     float* const tA = farA[wave];
@@ -222,9 +268,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
     const int n = P.n;
     const size_t plane = (size_t)n * n;
     const float lam_l2 = (float)(P.lambda * 1.4426950408889634);     // lambda in powers of two per unit length
-    const float g_l2 = P.tier_log * 1.4426950408889634f, skip_l2 = P.skip_base * 1.4426950408889634f;
+    const float g_l2 = P.tier_log * 1.4426950408889634f;
+    const bool drop_on = P.drop_eps_soft > 0.f;   // (wave-uniform: kernel argument)
     const float cellq = (float)(P.cell * (P.lambda * 1.4426950408889634));   // the cell size in the far tier's scaled units
-    const float lws = (float)log2(P.wscale);                                   // log2 of the weights' scale factor (a power of two)
+    const float lws = uniform_f32((float)log2(P.wscale));                      // log2 of the weights' scale factor (a power of two)
     constexpr double kHalfZ = 0.5 * (NPT - 1);
     constexpr double kHalfX = 0.5 * (kTierTX - 1), kHalfY = 0.5 * (kTierTY - 1);
     const float rt_w = (float)(sqrt(kHalfX * kHalfX + kHalfY * kHalfY + kHalfZ * kHalfZ) * P.cell) * 1.000001f;
@@ -265,13 +312,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
             if (P.unit_rule) {
                 rule_sel = (int)P.unit_rule[tzq];
                 if (rule_sel == 2) {
-                    if (decided < 0) {   // (once per wave; every wave reads the same three numbers once all sample blocks have reported)
-                        volatile unsigned long long* sc = P.sample_ctr;
-                        while (__builtin_amdgcn_readfirstlane((int)(sc[2] >= (unsigned long long)P.sample_blocks)) == 0) __builtin_amdgcn_s_sleep(32);
-                        __threadfence();
-                        const unsigned long long farp = sc[0], redo = sc[1];
-                        decided = __builtin_amdgcn_readfirstlane((int)(farp > 0 && redo * 25ull <= farp));   // at most 4 % of the sample's far pairs evaluated again
-                    }
+                    if (decided < 0) decided = sample_verdict(P.sample_ctr);   // (once per wave; one word, written once per launch: every wave reads the same verdict)
                     use_diff = decided != 0;
                 } else {
                     use_diff = rule_sel == 1;
@@ -279,6 +320,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
             }
         }
         const unsigned long long far_before = cnt_far, redo_before = cnt_redo;
+        bool sample_counts_redo = false;   // (a sample block: its second pass counts towards the verdict only where the test at the calibration point fails)
         const int ty = trem / P.tiles_x, tx = trem - ty * P.tiles_x;
         const int i0 = tx * kTierTX, j0 = ty * kTierTY, kk0 = P.kk_begin + tz * NPT;
 
@@ -298,7 +340,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
         // the wave's nodes form a compact kTierTX x kTierTY x NPT block: a lane keeps the z of its first node, the others follow by the cell size (planes past the
         // end of the launch are evaluated like the others and not stored)
         pz0 = (P.k0 + kk0 - 1) * P.cell + P.bbox_min[2];
-        qz0 = (float)(pz0 * (P.lambda * 1.4426950408889634));
+        {   // (the same for every lane of the wave: a scalar register pair, not two vector registers held through the loops)
+            const long long b = __double_as_longlong(pz0);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+            pz0 = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        }
+        qz0 = uniform_f32((float)(pz0 * (P.lambda * 1.4426950408889634)));
         const bool live_xy = li < n && lj < n;
         // nearest source of the block's centre (and its weight): one source per lane and step, butterfly minimum
         // (wave-uniform values computed by vector instructions are moved to scalar registers by hand: the compiler would keep a copy per lane)
@@ -379,17 +426,37 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
             // else the box rule and its measured margin stand.  (A test that tightens with u instead was measured: it fails so many sample blocks that the bunny's verdict turns to the
             // box rule and SprayBottle / rocker 256^3 pay 8 % for the sample.)
             use_diff = use_diff && coff + 2.f * rt_w * lam_l2 <= 72.f;
-            if (use_diff) {
-                const float inv = dmin > 0.f ? 1.f / dmin : 0.f;
-                star_ux = uniform_f32(nx * inv);
-                star_uy = uniform_f32(ny * inv);
-                star_uz = uniform_f32(nz * inv);
-                star_dc = uniform_f32(dmin * 1.000001f);
-                const float bx = fmaxf(fabsf(nx) - hx, 0.f), by = fmaxf(fabsf(ny) - hy, 0.f), bz = fmaxf(fabsf(nz) - hz, 0.f);
-                const float db = sqrtf(bx * bx + by * by + bz * bz);
-                star_inv_d = uniform_f32(dmin > 0.f && db > 0.f ? 1.f / db : __builtin_huge_valf());
-            }
         }
+        // (round 6: the drop rule reads the same differential bound in every block -- it decides what is evaluated at all, not in which arithmetic)
+        if (use_diff || drop_on) {
+            const float inv = dmin > 0.f ? 1.f / dmin : 0.f;
+            star_ux = uniform_f32(nx * inv);
+            star_uy = uniform_f32(ny * inv);
+            star_uz = uniform_f32(nz * inv);
+            star_dc = uniform_f32(dmin * 1.000001f);
+            const float bx = fmaxf(fabsf(nx) - hx, 0.f), by = fmaxf(fabsf(ny) - hy, 0.f), bz = fmaxf(fabsf(nz) - hz, 0.f);
+            const float db = sqrtf(bx * bx + by * by + bz * bz);
+            star_inv_d = uniform_f32(dmin > 0.f && db > 0.f ? 1.f / db : __builtin_huge_valf());
+        }
+        // ---- The drop rule by ACCUMULATED bound (round 6) ----
+        // For a source s and the block's reference source s* (the one nearest to the block's centre), at every node x of the block
+        //     |term_s(x)| / |term_s*(x)| = (|w_s| / |w_s*|) e^{-lambda (r_s(x) - r_s*(x))} r_s*(x) / r_s(x)  <=  b_s := (|w_s| / |w_s*|) e^{-lambda gap_s} r_hi / d_s
+        // with gap_s the larger of the two lower bounds of r_s - r_s* over the block -- the box rule's d_s - r_hi (d_s: distance from s to the block's box, r_hi: farthest corner
+        // from s*) and the differential rule's (see the classification below) -- and r_s* <= r_hi, r_s >= d_s.  Rounds 3-5 dropped s when b_s <= eps / S: all S sources together then
+        // stay below eps of |term_s*(x)| <= the node's dominant term.  That is the same inequality with a factor S that is loose by 4-10 e-folds (most sources are orders of magnitude
+        // below the threshold; what sits near it is a ring of a few hundred).  Now: the block keeps the running sum R of the bounds of what it has dropped, in the fixed order of the
+        // scan (clusters in storage order, a cluster's candidates together -- Y stays bit-identical from run to run), and a candidate (b_s <= tau = eps_soft / K, K a per-problem
+        // estimate of the ring's population: Solver::drop_rule_plan) is dropped while R + (the cluster's candidates) <= eps_soft = 7/8 eps.  K only decides how well the budget is
+        // used; the sum is what makes the rule sound.  A source with b_s <= tau_hard = (eps / 8) / S is dropped whatever R (the old rule on an eighth of the budget: it bounds how
+        // far an evaluated source can lie from the block -- the exponent span of yukawa_near -- and keeps the new rule from ever doing much worse than the old one).
+        // Whole clusters go the same way with their bounding sphere, largest weight (candidate test) and weight sum (bound).
+        // fp64 solve: R enters the a-posteriori test (R |term_s*(x)| against budget |X(x)|, beside the packed-fp32 tier's L1 sums), and the second pass evaluates the dropped
+        // sources too: where the sheets of the geometry cancel (|X| << dominant term) the rule of rounds 3-5 had no such guard.
+        float R_soft = 0.f, R_hard = 0.f;   // wave-uniform
+        if constexpr (CHECK) {   // (four registers less through the loops; a wave's LDS accesses execute in order)
+            if (drop_on && lane == 0) star_stash[wave] = float4{(cx - nx) * lam_l2, (cy - ny) * lam_l2, (cz - nz) * lam_l2, wnear};
+        }
+        const float span_c = uniform_f32(2.f * rt_w * lam_l2 - coff - 960.f);   // pass 1: a dropped source is evaluated only where its exponent stays inside the block's span
         // pass 0: near sources in fp64, far ones in packed fp32.  pass 1 (only when the a-posteriori test failed): the far sources again, in fp64.
 #pragma unroll 1
         for (int pass = 0; pass < 2; pass++) {
@@ -412,37 +479,77 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
             for (int a = 0; a < 6; a++) nq[a] = qn[a];
         };
 #endif
-        // the whole cluster against the block (bounding sphere, scalar loads): dropped before anything is fetched or staged
-        auto cluster_kept = [&](int c) {
-            const float* rec = clusters + (size_t)c * kConvClusterRec;
-            const float gdx = cx - rec[0], gdy = cy - rec[1], gdz = cz - rec[2];
-            const float gap = sqrtf(gdx * gdx + gdy * gdy + gdz * gdz) * 0.999999f - rt_w - rec[3] - r_hi_w;
-            return !(gap * lam_l2 > skip_l2 + (rec[4] * 1.4426950408889634f + lws) - lnear_w);   // (rec[4]: ln of the cluster's largest UNscaled weight)
+        // ---- whole clusters against the block (bounding spheres), SIXTY-FOUR AT A TIME (round 6) ----
+        // Rounds 3-5 tested one cluster per trip of a scalar loop -- six scalar loads, a dozen vector instructions on wave-uniform values, a branch: a dependent chain per
+        // cluster, 216 of them per block on rocker, 817 on SprayBottle.pc, most of them for clusters that are dropped.  Now a lane tests ONE cluster of a batch of 64 (its
+        // record by three 8-byte loads), ballots turn the 64 answers into scalar masks, and the walk below steps from set bit to set bit.  The accumulated drop rule takes a
+        // batch's candidates together -- all of them while the running sum allows, else only the ones below the hard threshold --, in the fixed order of the batches; pass 1
+        // repeats the masks and walks what pass 0 dropped as well (`cdrop_mask` tells the classification that every source of such a cluster was dropped).
+        int cur_batch = -1;
+        unsigned long long kept_mask = 0ull, cdrop_mask = 0ull;
+        auto load_batch = [&](int b) {
+            cur_batch = b;
+            const int ci = b * kWave + lane;
+            const bool in = ci < P.n_clusters;
+            const unsigned long long validm = __ballot(in);
+            cdrop_mask = 0ull;
+            if (drop_on) {
+                const float2* rec = reinterpret_cast<const float2*>(clusters + (size_t)min(ci, P.n_clusters - 1) * kConvClusterRec);
+                const float2 r0 = rec[0], r1 = rec[1], r2 = rec[2];   // centre xy | centre z, radius | ln of the largest weight, ln of the sum of the weights (UNscaled, rounded up)
+                const float gdx = cx - r0.x, gdy = cy - r0.y, gdz = cz - r1.x;
+                const float gap = sqrtf(gdx * gdx + gdy * gdy + gdz * gdz) * 0.999999f - rt_w - r1.y - r_hi_w;
+                const float lrel = lws - lnear_w - gap * lam_l2;
+                const float lbmax = fmaf(r2.x, 1.4426950408889634f, lrel) + 2e-5f;   // log2 of the largest bound of any of its sources
+                const bool cand = in && gap > 0.f && lbmax <= P.drop_ltau;
+                const unsigned long long candm = __ballot(cand);
+                if (candm != 0ull) {
+                    // a candidate cluster's sources together: (sum of weights / |w_*|) e^{-lambda gap} r_hi / (r_hi + gap)
+                    float bc = cand ? __builtin_amdgcn_exp2f(fmaf(r2.y, 1.4426950408889634f, lrel)) * (r_hi_w * __builtin_amdgcn_rcpf(r_hi_w + gap)) * 1.0001f : 0.f;
+                    bc += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(bc), 0x1f | (1 << 10)));
+                    bc += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(bc), 0x1f | (2 << 10)));
+                    bc += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(bc), 0x1f | (4 << 10)));
+                    bc += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(bc), 0x1f | (8 << 10)));
+                    bc += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(bc), 0x1f | (16 << 10)));
+                    const float sum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bc), 0)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bc), 32));
+                    const float r_new = uniform_f32(R_soft + sum);
+                    if (__builtin_amdgcn_readfirstlane((int)(r_new <= P.drop_eps_soft))) {
+                        R_soft = r_new;
+                        cdrop_mask = candm;
+                    } else {
+                        cdrop_mask = __ballot(cand && lbmax <= P.drop_ltau_hard);
+                        R_hard = uniform_f32(R_hard + (float)(__builtin_popcountll(cdrop_mask) * kTierCluster) * P.drop_tau_hard);
+                    }
+                }
+            }
+            kept_mask = pass == 1 ? validm : validm & ~cdrop_mask;
         };
-        // Round 5 (late): in the fp64 solve the fetch runs one KEPT cluster ahead.  Rounds 3-5 fetched cluster c + 1 whatever became of it: a kept cluster behind a dropped one
-        // waited out the whole memory latency of a fetch issued a few dozen cycles earlier (-3 ... 4 % of Step 1 at 128^3 and on rocker 128^3, nothing at 256^3 where few
-        // clusters are dropped; profiles/r05_setup_interference.txt).  The fp32 solve keeps the plain order: there it measured 7-8 % SLOWER (rocker / SprayBottle 256^3 fp32 --
-        // its kept clusters are all-far and short, and the scan for the next one then sits between a cluster's fetch and its use instead of beside the evaluation).
-        constexpr bool kLookahead = SHM_TIER_LOOKAHEAD != 0 && sizeof(TY) == 8;
-        auto next_kept = [&](int c) {
-            while (c < P.n_clusters && !cluster_kept(c)) c++;
-            return c;
+        // the next cluster >= `from` this pass walks (P.n_clusters: none); cdrop: pass 0 dropped it as a whole
+        auto next_kept = [&](int from, bool& cdrop) {
+            cdrop = false;
+#pragma unroll 1
+            while (from < P.n_clusters) {
+                const int b = from >> 6;
+                if (b != cur_batch) load_batch(b);
+                const unsigned long long m = kept_mask & (~0ull << (from & 63));
+                if (m != 0ull) {
+                    const int bit = (int)__builtin_ctzll(m);
+                    cdrop = ((cdrop_mask >> bit) & 1ull) != 0ull;
+                    return (b << 6) + bit;
+                }
+                from = (b + 1) << 6;
+            }
+            return P.n_clusters;
         };
-        int c = kLookahead ? next_kept(0) : 0;
+        // The fetch runs one KEPT cluster ahead (round 5 in the fp64 solve; the fp32 solve kept the plain order then because the scalar scan for the next kept cluster sat between
+        // a cluster's fetch and its use -- with the scan a few scalar instructions on a mask, round 6, both solves look ahead).
+        R_soft = 0.f;   // (the second pass repeats the first one's scan and with it its sums and decisions)
+        R_hard = 0.f;
+        bool cdrop_cur = false, cdrop_next = false;
+        int c = next_kept(0, cdrop_cur);
         if (c < P.n_clusters) fetch_cluster(c);
 #pragma unroll 1
         while (c < P.n_clusters) {
-            int c_next;
-            if constexpr (kLookahead) {
-                c_next = next_kept(c + 1);   // (the scan overlaps the fetch in flight)
-            } else {
-                c_next = c + 1;
-                if (!cluster_kept(c)) {
-                    if (c_next < P.n_clusters) fetch_cluster(c_next);
-                    c = c_next;
-                    continue;
-                }
-            }
+            const int c_next = next_kept(c + 1, cdrop_next);   // (the scan overlaps the fetch in flight)
             const int c_fetch = c_next;
             double q[6];
 #if SHM_TIER_LDS_FETCH
@@ -474,10 +581,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                 const float lhs = (dist * 0.999999f - r_hi_w) * lam_l2;                    // lower bound of lambda (r(x, s) - r_near(x)) / ln 2
                 const bool valid = w2 > 0.f;                                              // the zero-weight padding is never evaluated
                 const bool in_range = fmaf(dist, lam_l2, range_c) <= lw;                   // every term of the source stays a normal fp32 number over the block
-                float lhs_far = lhs;
-                if constexpr (CHECK) {
-                    if (use_diff) {
-                        // Differential rule (round 5, late; chosen per problem, see Solver::choose_far_rule): with s* the source nearest to the block's centre c,
+                float lhs_far = lhs, lhs_drop = lhs;
+                {
+                    if (use_diff || (drop_on && !cdrop_cur)) {
+                        // Differential rule (round 5, late; chosen per problem: Solver::far_rule_plan / far_rule_now): with s* the source nearest to the block's centre c,
                         //   r_s(x) - r_near(x) >= f(x) := r_s(x) - r_s*(x) >= f(c) - rt (|u_s(c) - u_s*(c)| + rt (1 / d_s + 1 / d_s*))      for every x of the block
                         // (u: unit vectors towards c; d: distances to the block's box -- the gradient of f is u_s - u_s*, a unit vector turns by at most |x - c| / d).  Two
                         // sources in similar directions keep their DIFFERENCE of distances over the block although each distance varies by the block's diameter: the
@@ -489,12 +596,37 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                         const float du = sqrtf(fmaxf(0.f, 2.f - 2.f * dot));
                         const float lip = du + rt_w * (__builtin_amdgcn_rcpf(dist) + star_inv_d);
                         const float lhs2 = (dc * 0.999999f - star_dc - rt_w * lip * 1.00001f) * lam_l2;
-                        lhs_far = fmaxf(lhs, lhs2);   // (NaN -- the source at the centre -- leaves the box rule)
+                        lhs_drop = fmaxf(lhs, lhs2);   // (NaN -- the source at the centre -- leaves the box rule)
+                        if (use_diff) lhs_far = lhs_drop;
                     }
                 }
                 const bool far = lhs_far > g_l2 + rel && in_range;
-                const bool drop = lhs > skip_l2 + rel;
-                const bool to64 = valid && !drop && (pass == 0 ? !far : far);   // (drop first: a source outside the fp32 exponent range is not "far", but it may well be dropped)
+                // the drop rule by accumulated bound (see the block's header above): candidates of this cluster together, or only the ones below the hard threshold
+                bool drop = valid && cdrop_cur;   // (pass 1 walks a cluster that pass 0 dropped as a whole)
+                if (drop_on && !cdrop_cur) {
+                    const float lb = rel - lhs_drop + 2e-5f;   // log2 of b_s without its geometric factor, rounded up
+                    const bool cand = valid && lb <= P.drop_ltau;
+                    if (__ballot(cand) != 0ull) {
+                        float bs = cand ? __builtin_amdgcn_exp2f(lb) * (r_hi_w * __builtin_amdgcn_rcpf(dist)) * 1.0001f : 0.f;   // (a source inside the block: inf -- never dropped by the sum)
+                        bs += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(bs), 0x1f | (1 << 10)));   // butterfly sum within the halves of the wave: fixed order
+                        bs += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(bs), 0x1f | (2 << 10)));
+                        bs += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(bs), 0x1f | (4 << 10)));
+                        bs += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(bs), 0x1f | (8 << 10)));
+                        bs += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(bs), 0x1f | (16 << 10)));
+                        const float sum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bs), 0)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bs), 32));
+                        const float r_new = uniform_f32(R_soft + sum);
+                        if (__builtin_amdgcn_readfirstlane((int)(r_new <= P.drop_eps_soft))) {   // (inf / NaN: false)
+                            R_soft = r_new;
+                            drop = cand;
+                        } else {
+                            drop = cand && lb <= P.drop_ltau_hard;
+                            R_hard = uniform_f32(R_hard + (float)__builtin_popcountll(__ballot(drop)) * P.drop_tau_hard);
+                        }
+                    }
+                }
+                // pass 1 evaluates what pass 0 dropped as well, where the term's exponent stays inside the span of the block's scale (beyond it the term is < 2^-900 of the scale)
+                const bool span_ok = fmaf(dist, lam_l2, span_c) < 0.f;
+                const bool to64 = valid && (pass == 0 ? (!drop && !far) : (drop ? span_ok : far));   // (drop first: a source outside the fp32 exponent range is not "far", but it may well be dropped)
                 const bool to32 = valid && pass == 0 && far && !drop;
                 nearmask = __ballot(to64);
                 farmask = __ballot(to32);
@@ -565,10 +697,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                 near_source(rec);
             }
             // ---- far tier: packed fp32 (two nodes per instruction), kFarUnroll sources in flight (the transcendentals' results arrive late) ----
-            for (int i0 = 0; i0 < nfar; i0 += kFarUnroll) {
+            for (int i0f = 0; i0f < nfar; i0f += kFarUnroll) {
 #pragma unroll
                 for (int u = 0; u < kFarUnroll; u++) {
-                    const int s = i0 + u;
+                    const int s = i0f + u;
                     const float4 pa = *reinterpret_cast<const float4*>(&tA[4 * s]);
                     const float2v pc = *reinterpret_cast<const float2v*>(&tC[2 * s]);
                     const float2v wxy = {pa.z, pa.w};
@@ -597,6 +729,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                 }
             }
             c = c_next;
+            cdrop_cur = cdrop_next;
         }
         if (!CHECK) break;
         if (pass == 0) {
@@ -604,17 +737,45 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
             // are evaluated again in fp64 (pass 1) and the packed-fp32 sums discarded
             bool fail = false;
             const double e0 = far_scale();
+            // what the block dropped, against |X| as well (round 6): its accumulated bound R is relative to the reference source's term at the node, evaluated here once per node
+            // (in the block's scale, like the sums); R / eps_far puts it on the scale of the packed-fp32 tier's L1 sums
+            // (fp32 is plenty for a bound that carries a 1 % margin, and it keeps the test out of the kernel's register peak)
+            const float r_drop = R_soft + R_hard;
+            float coff_here = coff, ratio_here = P.far_redo_ratio;
+            asm volatile("" : "+v"(coff_here), "+v"(ratio_here));   // (invariant in the pass loop: keep it behind the loops, see below)
+            const double ratio_base = (double)ratio_here;
+            const double ratio = (double)(ratio_here / fmaxf(1.f, (coff_here + 2.f * rt_w * lam_l2) * (1.f / kTierEpsFarU0)));   // (wave-uniform)
+            bool fail_base = false;
+            // (everything here is invariant in the pass loop; the reference source comes back from LDS, the rest is pinned behind the loops by the empty asm -- computed ahead of
+            // them it held 16 registers through them)
+            const float4 st = star_stash[wave];
+            float chk = P.drop_check, k0_here = (float)k0;
+            asm volatile("" : "+v"(chk), "+v"(k0_here));
+            const float rs = r_drop * chk * 1.01f * sqrtf(st.w) * __builtin_amdgcn_exp2f(-lws) * lam_l2;   // (lambda': the reciprocal below is of the SCALED distance)
+            const float sdx = qx - st.x, sdy = qy - st.y, sdz0 = qz0 - st.z;   // scaled coordinates, like the far tier's
+            const float sxy2 = sdx * sdx + sdy * sdy;
 #pragma unroll
             for (int e = 0; e < NPT; e++) {
                 const double x0 = ax[e] + (double)fx[e / 2][e & 1] * e0, x1 = ay[e] + (double)fy[e / 2][e & 1] * e0, x2 = az[e] + (double)fz[e / 2][e & 1] * e0;
-                fail = fail || (live_xy && kk0 + e < P.kk_end && (double)fl[e / 2][e & 1] * e0 > (double)P.far_redo_ratio * sqrt(x0 * x0 + x1 * x1 + x2 * x2));
+                // |w_*| e^{-lambda r} / r in the block's scale 2^-k0:  2^(-lambda' r - k0) lambda' / (lambda' r)      (the node on s*: inf * 0 = NaN -- compares false, X is NaN there itself)
+                const float dz = e * cellq + sdz0, d2 = fmaf(dz, dz, sxy2), rinv = __builtin_amdgcn_rsqf(d2);
+                const float tstar = r_drop > 0.f ? rs * __builtin_amdgcn_exp2f(-d2 * rinv - k0_here) * rinv : 0.f;
+                const double lhs_t = fma((double)fl[e / 2][e & 1], e0, (double)tstar), xn = sqrt(x0 * x0 + x1 * x1 + x2 * x2);
+                const bool live = live_xy && kk0 + e < P.kk_end;
+                fail = fail || (live && lhs_t > ratio * xn);
+                fail_base = fail_base || (live && lhs_t > ratio_base * xn);
             }
+            sample_counts_redo = __ballot(fail_base) != 0ull;
             if (__ballot(fail) == 0ull) break;
 #pragma unroll
             for (int e = 0; e < NPT / 2; e++) fx[e] = fy[e] = fz[e] = float2v{0.f, 0.f};
         }
         }  // pass loop
         const double e0 = far_scale();
+        // (the lane's node indices are formed again here rather than held through the loops: two registers)
+        int lane_here = lane;
+        asm volatile("" : "+v"(lane_here));
+        const int si = min(i0 + (lane_here % kTierTX), n - 1), sj = min(j0 + (lane_here / kTierTX), n - 1);
 #pragma unroll
         for (int e = 0; e < NPT; e++) {
             if (!(live_xy && kk0 + e < P.kk_end)) continue;
@@ -624,7 +785,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
             const double x0 = __builtin_amdgcn_ldexp(ax[e] + (double)fx[e / 2][e & 1] * e0, kback), x1 = __builtin_amdgcn_ldexp(ay[e] + (double)fy[e / 2][e & 1] * e0, kback),
                          x2 = __builtin_amdgcn_ldexp(az[e] + (double)fz[e / 2][e & 1] * e0, kback);
             const double nrm = sqrt(x0 * x0 + x1 * x1 + x2 * x2);
-            const size_t vi = (size_t)(kk0 + e) * plane + (size_t)cj * n + ci;   // (live: kk0 + e is a plane of the launch)
+            const size_t vi = (size_t)(kk0 + e) * plane + (size_t)sj * n + si;   // (live: kk0 + e is a plane of the launch)
             // 0/0 -> NaN exactly like X /= X.norm() (:61).  A wave writes 64-byte row segments (8 nodes: half lines); the x-adjacent block is a neighbouring
             // unit of the same XCD's queue, so the two halves meet in that XCD's L2: PMC, kernel alone (tools/conv_pmc.sh): 412 MB written for 384 MB of
             // output (non-temporal stores: 497 MB; 16 x 4 x NPT blocks: 387 MB but 7 % slower -- the wider block classifies fewer sources as far)
@@ -633,12 +794,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
             Y2[vi] = (TY)(x2 / nrm);
         }
         if constexpr (CHECK) {
-            if (rule_sel == 1 && lane == 0) {   // a sample block reports: far pairs, pairs evaluated again, then -- behind a fence -- that it is done
-                atomicAdd(P.sample_ctr + 0, (cnt_far - far_before) * (unsigned long long)(64 * NPT));
-                atomicAdd(P.sample_ctr + 1, (cnt_redo - redo_before) * (unsigned long long)(64 * NPT));
-                __threadfence();
-                atomicAdd(P.sample_ctr + 2, 1ull);
-            }
+            if (rule_sel == 1 && lane == 0)   // a sample block reports: far pairs, pairs evaluated again, then that it is done; the last one to report publishes the verdict
+                sample_report(P.sample_ctr, (cnt_far - far_before) * (unsigned long long)(64 * NPT), sample_counts_redo ? (cnt_redo - redo_before) * (unsigned long long)(64 * NPT) : 0ull, P.sample_blocks);
         }
     }  // unit loop
     if (counters && lane == 0) {

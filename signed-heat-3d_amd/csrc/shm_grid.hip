@@ -279,6 +279,22 @@ struct Row {
 //   fp32 (conv_normalize_kernel<float>, SHM_CONV32_CLASSIC=1): block = 8 x 8 x 16 nodes (its culled unit), classified per CLUSTER of 32 Morton-sorted sources with the cluster's
 //   bounding sphere and largest weight, like the kernel: kept clusters cost 32 pairs per node, skipped ones 0.  (A per-source rule predicts a 20 % imbalance
 //   of equal slabs on rocker 512^3 where 3 % is measured: the spheres' radii, not the sources' distances, decide what that kernel skips.)
+// K of the tiered kernels' drop rule (round 6): the number of sources a block is expected to find within an e-fold of the drop threshold (see Solver::set_problem)
+static double drop_rule_K(int64_t S, const double* wn, double lambda) {
+    double wsum = 0.;
+    int64_t nz = 0;
+    for (int64_t t = 0; t < S; t++) {
+        const double w = std::sqrt(wn[3 * t] * wn[3 * t] + wn[3 * t + 1] * wn[3 * t + 1] + wn[3 * t + 2] * wn[3 * t + 2]);
+        if (w > 0. && std::isfinite(w)) {
+            wsum += w;
+            nz++;
+        }
+    }
+    const double abar = nz ? wsum / (double)nz : 0.;
+    const double k_est = abar > 0. ? 3.0 * 157.0 / (abar * lambda * lambda) : 64.;
+    return std::min(std::max(64.0, (double)S), std::max(64.0, k_est));
+}
+
 static void step1_plane_weights_host(int64_t S, const double* pos, const double* wn, double lambda, int n, const double* bbox_min, double cell, int precision,
                                      double tier_log, double* weights, bool tiered32 = false) {
     const bool per_source = precision == SHM_F64 || tiered32;   // the tiered kernel's classification: per (8 x 8 x 4 block, source)
@@ -287,7 +303,10 @@ static void step1_plane_weights_host(int64_t S, const double* pos, const double*
     const int bz = f64 ? 4 : 16;
     const double half_z = 0.5 * (bz - 1);
     const double rt = std::sqrt(3.5 * 3.5 * 2 + half_z * half_z) * cell * 1.000001;
-    const double skip_base = std::log((double)S / (precision == SHM_F64 ? 2e-9 : 6.0e-8));   // (the kernels' drop thresholds: Solver::set_sources)
+    const double drop_eps = precision == SHM_F64 ? 2e-9 : 6.0e-8;
+    const double skip_base = std::log((double)S / drop_eps);   // (the classic kernels' drop threshold: Solver::set_problem)
+    // tiered kernels (round 6): dropped by accumulated bound -- candidates below tau in groups of 64 while their bounds sum to <= eps_soft, below tau_hard always
+    const double eps_soft = 0.875 * drop_eps, ln_tau = std::log(eps_soft / drop_rule_K(S, wn, lambda)), ln_tau_hard = std::log(0.125 * drop_eps / (double)S);
     const double far_cost = 0.43;
     std::vector<double> wmag((size_t)S);
     double wlo = 1e300, whi = 0.;
@@ -353,7 +372,8 @@ static void step1_plane_weights_host(int64_t S, const double* pos, const double*
             for (int b = 0; b < K; b++) {
                 const int tx = (int)(((2 * a + 1) * (long long)tiles) / (2 * K)), ty = (int)(((2 * b + 1) * (long long)tiles) / (2 * K));
                 const double cx = (tx * 8 + 3.5) * cell + bbox_min[0], cy = (ty * 8 + 3.5) * cell + bbox_min[1];
-                double dmin = 1e300, wnear = 0.;
+                double dmin = 1e300, wnear = 0., bnd[64], lbs[64];
+                int64_t s_star = 0;
                 for (int64_t s = 0; s < S; s++) {
                     const double dx = cx - pos[3 * s], dy = cy - pos[3 * s + 1], dz = cz - pos[3 * s + 2];
                     const double d = std::sqrt(dx * dx + dy * dy + dz * dz);
@@ -361,19 +381,44 @@ static void step1_plane_weights_host(int64_t S, const double* pos, const double*
                     if (wmag[(size_t)s] > 0. && (d < dmin || (d == dmin && wmag[(size_t)s] > wnear))) {
                         dmin = d;
                         wnear = wmag[(size_t)s];
+                        s_star = s;
                     }
                 }
                 if (!(wnear > 0.)) continue;
                 const double r_hi = dmin + rt, ln_near = std::log(wnear);
                 double cost = 0.;
                 if (f64) {
-                    for (int64_t s = 0; s < S; s++) {
-                        if (!(wmag[(size_t)s] > 0.)) continue;
-                        const double lhs = lambda * (dist[(size_t)s] - rt - r_hi), rel = std::log(wmag[(size_t)s]) - ln_near;
-                        if (lhs > skip_base + rel) continue;
-                        const double d_box = std::max(0., dist[(size_t)s] - rt), d0 = std::max(0., dmin - rt);
-                        const bool in_range = 1.4426950408889634 * lambda * (d_box - d0) + range_c <= std::log2(wmag[(size_t)s]) - lwhi;
-                        cost += lhs > tier_log + rel && in_range ? far_cost : 1.0;
+                    // (the kernel's bounds with the block's bounding sphere in place of its box; its differential bound of r_s - r_s* beside the box rule's: shm_conv_tiered.hip.h)
+                    const double sx = cx - pos[3 * s_star], sy = cy - pos[3 * s_star + 1], sz = cz - pos[3 * s_star + 2];
+                    const double inv_dstar_box = dmin - rt > 0. ? 1.0 / (dmin - rt) : 1e300;
+                    double R = 0.;
+                    for (int64_t g0 = 0; g0 < S; g0 += 64) {
+                        const int64_t g1 = std::min<int64_t>(S, g0 + 64);
+                        double gsum = 0.;
+                        for (int64_t s = g0; s < g1; s++) {
+                            bnd[(size_t)(s - g0)] = -1.;
+                            if (!(wmag[(size_t)s] > 0.)) continue;
+                            const double d = dist[(size_t)s], d_box = std::max(1e-300, d - rt);
+                            const double ex = cx - pos[3 * s], ey = cy - pos[3 * s + 1], ez = cz - pos[3 * s + 2];
+                            const double dot = d > 0. && dmin > 0. ? (ex * sx + ey * sy + ez * sz) / (d * dmin) : 1.0;
+                            const double lip = std::sqrt(std::max(0., 2.0 - 2.0 * dot)) + rt * (1.0 / d_box + inv_dstar_box);
+                            const double lhs_drop = lambda * std::max(d - rt - r_hi, d - dmin - rt * lip), rel = std::log(wmag[(size_t)s]) - ln_near;
+                            lbs[(size_t)(s - g0)] = rel - lhs_drop;
+                            if (lbs[(size_t)(s - g0)] <= ln_tau) {
+                                bnd[(size_t)(s - g0)] = std::exp(lbs[(size_t)(s - g0)]) * r_hi / d_box;
+                                gsum += bnd[(size_t)(s - g0)];
+                            }
+                        }
+                        const bool soft_ok = R + gsum <= eps_soft;
+                        if (soft_ok) R += gsum;
+                        for (int64_t s = g0; s < g1; s++) {
+                            if (!(wmag[(size_t)s] > 0.)) continue;
+                            if (bnd[(size_t)(s - g0)] >= 0. && (soft_ok || lbs[(size_t)(s - g0)] <= ln_tau_hard)) continue;   // dropped
+                            const double lhs = lambda * (dist[(size_t)s] - rt - r_hi), rel = std::log(wmag[(size_t)s]) - ln_near;
+                            const double d_box = std::max(0., dist[(size_t)s] - rt), d0 = std::max(0., dmin - rt);
+                            const bool in_range = 1.4426950408889634 * lambda * (d_box - d0) + range_c <= std::log2(wmag[(size_t)s]) - lwhi;
+                            cost += lhs > tier_log + rel && in_range ? far_cost : 1.0;
+                        }
                     }
                 } else {
                     for (size_t c = 0; c < crad.size(); c++) {
@@ -500,14 +545,14 @@ struct Solver final : SolverBase {
     int64_t S = 0;
     std::vector<double> h_pos, h_wn, h_area;
     double area_sum = 0., conv_far_gap = 0., conv_skip_base = 3.0e38, last_host_setup_ms = 0., last_setup_wall_ms = 0.;
-    double conv_tier_log = 0., conv_tier_skip_base = 3.0e38;   // tiered fp64 Step 1: far threshold G (nats) and its drop threshold
+    double conv_tier_log = 0., conv_tier_skip_base = 3.0e38;   // tiered fp64 Step 1: far threshold G (nats) and the drop threshold of rounds 3-5, ln(S / eps)
+    double conv_drop_K = 64., conv_drop_eps64 = 2e-9, conv_drop_eps32 = 6.0e-8;   // tiered kernels, round 6: the accumulated drop rule (drop_rule_plan)
     double conv_w_span = 0.;                                   // ln(largest / smallest non-zero source weight)
     // fp32 handles: the tiered kernel's view of the sources (fp64 records in clusters of 64, the reference's own weights) beside the fp32 kernel's
     DevArray<double> d_src_t;
     DevArray<float> d_clusters_t;
     int n_clusters_t = 0;
     bool conv_tiered = false;                                  // fp64 only; SHM_CONV_EXACT=1 selects the all-fp64 kernel
-    int far_rule = 0;                                          // tiered fp64 Step 1 without a sample launch: 0 = box rule (see far_rule_sampled)
     bool conv_tier_exact = false;                              // ... with every pair in its fp64 body (SHM_STEP1_EXACT_F64 where the exponent span allows)
     bool conv_tiered32 = false;                                // fp32 handles: Step 1 through the tiered kernel's packed-fp32 body
     bool fold_pq = false;                                      // fused stencil CG on one GPU: the RES sweep sums the DIR sweep's partials of p'.Kp' itself
@@ -597,6 +642,7 @@ struct Solver final : SolverBase {
     // world > 1: the whole-grid solver every rank runs after the right-hand side has been gathered (see solve_gathered)
     std::unique_ptr<Solver<T>> full;
     bool solve_only = false;  // this instance is such a whole-grid solver: it never runs Steps 1-2, so it owns no Y arrays
+    bool full_problem_set = false;   // `full` holds the current problem (ensure_full)
     bool pool_held = false;   // this solver holds a reference on its device's pinned staging chunks (PinnedPool)
 
     explicit Solver(const shm_config& c, bool solve_only_ = false) : cfg(c), solve_only(solve_only_) {
@@ -771,7 +817,7 @@ struct Solver final : SolverBase {
                 }
                 for (int a = 0; a < 3; a++) cl[kConvClusterRec * (size_t)c + a] = (float)cc[a];
                 cl[kConvClusterRec * (size_t)c + 3] = (float)(rad * 1.00001 + 1e-30);
-                double wmax2 = 0.;  // largest source weight |A N| of the cluster (skip test: ln of it, rounded up)
+                double wmax2 = 0., wsum = 0.;  // largest source weight |A N| of the cluster and the sum of its weights (drop rule: ln of them, rounded up)
                 for (int e = 0; e < kConvCluster; e++) {
                     double w2 = 0.;
                     for (int a = 0; a < 3; a++) {
@@ -779,8 +825,10 @@ struct Solver final : SolverBase {
                         w2 += w * w;
                     }
                     wmax2 = std::max(wmax2, w2);
+                    wsum += std::sqrt(w2);
                 }
                 cl[kConvClusterRec * (size_t)c + 4] = wmax2 > 0. ? (float)(0.5 * std::log(wmax2) + 1e-5) : -1.0e30f;
+                cl[kConvClusterRec * (size_t)c + 5] = wsum > 0. ? (float)(std::log(wsum) + 1e-5) : -1.0e30f;
             }
             // far when lambda * (d_lo - r_hi) > 25 + ln(Amax/Amin): the cluster's terms are below e^-25 ~ 1.4e-11 of the
             // tile's dominant term, so their fp32 rounding (~1e-5 incl. the exponent) stays below 2e-16 of it
@@ -809,6 +857,28 @@ struct Solver final : SolverBase {
                 conv_tier_log = tl ? atof(tl) : 8.0;
                 const char* db = knob("SHM_CONV_DROP_BUDGET");
                 conv_tier_skip_base = sk ? 3.0e38 : std::log((double)S / (db ? atof(db) : 2e-9));
+                // Round 6 -- the tiered kernels drop by ACCUMULATED bound (shm_conv_tiered.hip.h): budgets eps (same values as above: 2e-9 of the dominant term in the fp64
+                // solve, one fp32 rounding unit in the fp32 solve; 0: nothing is dropped), and K, the number of sources a block is expected to find near the threshold -- the
+                // candidate threshold is eps_soft / K, the running sum keeps the rule sound whatever K is.  Sources near the threshold lie in a ring of radius D ~ 25 / lambda
+                // around the block on a surface with one source per mean source area a: ~ 2 pi D / (a lambda) of them within one e-fold, i.e. 157 / (a lambda^2); three times
+                // that leaves the sum room (tools/r06_drop_sim.py: rocker 512^3 keeps 0.52-0.53 of its pairs for K = 512 ... 1024, 0.62 for K = 256, where the sum binds).
+                conv_drop_eps64 = sk ? 0. : (db ? atof(db) : 2e-9);
+                conv_drop_eps32 = sk ? 0. : (db32 ? atof(db32) : 6.0e-8);
+                {
+                    double wsum = 0.;
+                    int64_t nz = 0;
+                    for (int64_t t = 0; t < S; t++) {
+                        const double w = std::sqrt(h_wn[3 * t] * h_wn[3 * t] + h_wn[3 * t + 1] * h_wn[3 * t + 1] + h_wn[3 * t + 2] * h_wn[3 * t + 2]);
+                        if (w > 0. && std::isfinite(w)) {
+                            wsum += w;
+                            nz++;
+                        }
+                    }
+                    const double abar = nz ? wsum / (double)nz : 0.;
+                    const char* dk = knob("SHM_CONV_DROP_K");   // experiment knob
+                    const double k_est = abar > 0. ? 3.0 * 157.0 / (abar * lambda * lambda) : 64.;
+                    conv_drop_K = dk ? atof(dk) : std::min(std::max(64.0, (double)S), std::max(64.0, k_est));
+                }
                 select_step1_arith(SHM_STEP1_AUTO);
             }
             d_src.upload(packed, stream);
@@ -836,6 +906,7 @@ struct Solver final : SolverBase {
                     for (int t = 0; t < 3; t++) cl.push_back((float)cc[t]);
                     cl.push_back((float)(rad * 1.00001 + 1e-30));
                     cl.push_back((float)lnw);
+                    cl.push_back(0.f);   // (record stride; the fill-level records carry no weight sum)
                 }
             }
             d_clusters.upload(cl, stream);
@@ -854,7 +925,7 @@ struct Solver final : SolverBase {
                 std::vector<float> clt((size_t)n_clusters_t * kConvClusterRec, 0.f);
                 for (int c = 0; c < n_clusters_t; c++) {
                     const double* q = pk.data() + 6 * (size_t)c * kTierCluster;
-                    double cc[3] = {0, 0, 0}, rad = 0., wmax2 = 0.;
+                    double cc[3] = {0, 0, 0}, rad = 0., wmax2 = 0., wsum = 0.;
                     for (int e = 0; e < kTierCluster; e++)
                         for (int a = 0; a < 3; a++) cc[a] += q[6 * e + a] / kTierCluster;
                     for (int e = 0; e < kTierCluster; e++) {
@@ -865,10 +936,12 @@ struct Solver final : SolverBase {
                         }
                         rad = std::max(rad, std::sqrt(d2));
                         wmax2 = std::max(wmax2, w2);
+                        wsum += std::sqrt(w2);
                     }
                     for (int a = 0; a < 3; a++) clt[kConvClusterRec * (size_t)c + a] = (float)cc[a];
                     clt[kConvClusterRec * (size_t)c + 3] = (float)(rad * 1.00001 + 1e-30);
                     clt[kConvClusterRec * (size_t)c + 4] = wmax2 > 0. ? (float)(0.5 * std::log(wmax2) + 1e-5) : -1.0e30f;
+                    clt[kConvClusterRec * (size_t)c + 5] = wsum > 0. ? (float)(std::log(wsum) + 1e-5) : -1.0e30f;
                 }
                 d_src_t.upload(pk, stream);
                 d_clusters_t.upload(clt, stream);
@@ -945,23 +1018,41 @@ struct Solver final : SolverBase {
         precond_ready = false;
         have_problem = true;
         have_conv = have_div = have_phi = have_constraints = false;
-        if (cfg.world > 1 && !solve_only && n >= 4 && n <= 1024) {   // (a single slab has a fast Poisson solve for every n: fft_available() / gemm_dct())
-            if (!full) {
-                shm_config c = cfg;
-                c.world = 1;
-                c.rank = 0;
-                c.local_slabs = 1;
-                c.rccl_unique_id = nullptr;
-                full.reset(new Solver<T>(c, true));
-            }
-            full->set_problem(src, g);
-        } else {
-            full.reset();
-        }
+        // (round 6: the whole-grid solver of the gathered multi-rank solve is created when a solve first takes that path -- ensure_full() -- so that a run whose solves
+        // all take the slab-distributed forms never allocates whole-grid arrays on every rank)
+        full_problem_set = false;
+        if (!(cfg.world > 1 && !solve_only && n >= 4 && n <= 1024)) full.reset();   // (a single slab has a fast Poisson solve for every n: fft_available() / gemm_dct())
         log("[shm] problem set: n=%d N=%zu S=%lld slabs=%d(local %d) vec=%d", n, N, (long long)S, total_slabs, cfg.local_slabs, vec);
     }
 
     // shm_opts.step1_arith: the tiered kernel unless the caller (or SHM_CONV_EXACT=1, read per call: tests flip it inside one process) asks for the reference's arithmetic
+    // the whole-grid solver behind solve_gathered(): created and given the current problem on first use
+    bool full_wanted() const { return cfg.world > 1 && !solve_only && n >= 4 && n <= 1024; }
+    void ensure_full() {
+        if (!full_wanted()) return;
+        if (!full) {
+            shm_config c = cfg;
+            c.world = 1;
+            c.rank = 0;
+            c.local_slabs = 1;
+            c.rccl_unique_id = nullptr;
+            full.reset(new Solver<T>(c, true));
+        }
+        if (!full_problem_set) {
+            shm_sources src{};
+            src.S = S;
+            src.pos = h_pos.data();
+            src.wnormal = h_wn.data();
+            src.area = h_area.data();
+            src.lambda = lambda;
+            shm_grid g{};
+            g.n = n;
+            for (int a = 0; a < 3; a++) g.bbox_min[a] = bbox_min[a];
+            g.cell = cell;
+            full->set_problem(src, g);
+            full_problem_set = true;
+        }
+    }
     void select_step1_arith(int arith) {
         if (arith != SHM_STEP1_AUTO && arith != SHM_STEP1_EXACT_F64) throw Error(SHM_ERR_INVALID, "unknown step1_arith");
         conv_tiered = sizeof(T) == 8 && arith == SHM_STEP1_AUTO && knob("SHM_CONV_EXACT") == nullptr && tier_exponent_span_ok();
@@ -982,7 +1073,8 @@ struct Solver final : SolverBase {
     bool tier_exponent_span_ok(bool every_pair = false) const {
         const double rt = std::sqrt(2 * 3.5 * 3.5 + 1.5 * 1.5) * cell;
         // (every_pair: nothing is dropped -- a block's evaluated sources lie up to the grid's diagonal further away than its nearest one; sources sit inside the grid's box)
-        const double reach = every_pair ? lambda * std::sqrt(3.0) * (double)(n - 1) * cell : std::min(sizeof(T) == 8 ? conv_tier_skip_base : conv_skip_base, 1.0e6);
+        // (round 6: what is evaluated for certain lies inside the HARD drop threshold, the old rule on an eighth of the budget: ln 8 further out)
+        const double reach = every_pair ? lambda * std::sqrt(3.0) * (double)(n - 1) * cell : std::min((sizeof(T) == 8 ? conv_tier_skip_base : conv_skip_base) + 2.0794415416798357, 1.0e6);
         const double bits = (4.0 * rt * lambda + reach + std::max(conv_w_span, 43.0)) * 1.4426950408889634 + 16.0;
         return bits < 990.0;
     }
@@ -1018,7 +1110,7 @@ struct Solver final : SolverBase {
     int far_rule_now() const {
         const char* e = knob("SHM_TIER_FAR_RULE");
         if (e) return atoi(e) != 0;
-        return far_rule > 0;
+        return 0;   // (without a sample: the box rule; far_rule_plan decides where a sample runs)
     }
     // The differential far rule moves a tenth of the pairs from the fp64 body to the packed-fp32 one -- and on some inputs fills the tier so far that the a-posteriori test
     // sends a fifth of the blocks through the second pass (measured, Step 1 alone: bunny_small 256^3 -5.5 %, rocker 128^3 -17 %, SprayBottle.pc 256^3 -12.5 %; rocker 256^3
@@ -1029,12 +1121,10 @@ struct Solver final : SolverBase {
     // tuned outside the solve; deterministic (same sample, counters and verdict in every solve of a problem).  Where one process holds the whole grid, the grid has >= 64 layers
     // of blocks (256^3 upwards) and the budget is the default one; everything else keeps the box rule.  A first version that read the sample's counters on the host between two
     // launches lost the gain to the sample launch's tail.
-    int far_rule_last = 0;   // what the last Step 1 ran with: 0 box, 1 differential, -1 decided on the device from the sample
     // Does this Step 1 decide its far rule from a sample?  Builds (once per problem) the queue order of the layers and the rule of every position: each of the eight queues
     // starts with ONE sample layer (differential rule; spread over the planes), goes on with one of the eight most central remaining layers under the box rule -- work that
     // needs no verdict, long enough for every sample block to finish meanwhile --, and then runs its share of the rest, centre to faces, under the rule the sample earned.
     bool far_rule_plan(Slab<T>& sl, int planes, int npt) {
-        far_rule_last = far_rule_now();
         if (sizeof(T) != 8 || !conv_tiered || conv_tier_exact || slabs.size() != 1 || total_slabs != 1 || knob("SHM_TIER_FAR_RULE") != nullptr || knob("SHM_TIER_NO_SAMPLE") != nullptr) return false;
         if (step1_budget > 0. && step1_budget != kTierBudget) return false;
         const int layers = (planes + npt - 1) / npt;
@@ -1132,6 +1222,15 @@ struct Solver final : SolverBase {
                 P.far_redo_ratio = ratio > 0. ? (float)ratio : 3.0e38f;
             }
             P.skip_base = conv_tier_exact ? 3.0e38f : (float)std::min(conv_tiered ? conv_tier_skip_base - g_shift : conv_skip_base, 3.0e38);
+            {   // the tiered kernels' drop rule (round 6; shm_conv_tiered.hip.h): eps follows the budget in the fp64 solve (a fifth of it, as before)
+                const double eps = conv_tier_exact ? 0. : sizeof(T) == 8 ? conv_drop_eps64 * (budget / kTierBudget) : conv_drop_eps32;
+                const double eps_soft = 0.875 * eps, tau = eps_soft / conv_drop_K, tau_hard = 0.125 * eps / (double)std::max<int64_t>(1, S);
+                P.drop_eps_soft = (float)eps_soft;
+                P.drop_ltau = eps > 0. ? (float)std::log2(tau) : -3.0e38f;
+                P.drop_ltau_hard = eps > 0. ? (float)std::log2(tau_hard) : -3.0e38f;
+                P.drop_tau_hard = (float)(tau_hard * 1.0001);
+                P.drop_check = (float)(1.0 / kTierEpsFar);
+            }
             P.inv_lambda = (float)(1.0 / lambda);
             P.tiles_x = (n + kConvTile - 1) / kConvTile;
             P.tiles_y = P.tiles_x;
@@ -1267,7 +1366,6 @@ struct Solver final : SolverBase {
                 P.sample_blocks = sl.sample_blocks;
                 launch_range(0, planes, sel0, 0, sl.sample_order.p, layers);
                 P.unit_rule = nullptr;
-                far_rule_last = -1;   // (decided on the device: shm_grid_last_far_rule reads the counters)
             } else {
                 for (int b0 = 0; b0 < planes; b0 += chunk_planes) launch_range(b0, std::min(planes, b0 + chunk_planes), sel0);
             }
@@ -1325,6 +1423,8 @@ struct Solver final : SolverBase {
     void run_conv(int step1_arith) override {
         need_problem();
         HIPCHK(hipSetDevice(cfg.device));
+        step1_budget = 0.;   // (the stage entry points run with the library's defaults, whatever the last solve's shm_opts asked for)
+        dual_form_req = SHM_DUAL_AUTO;
         select_step1_arith(step1_arith);
         launch_conv();
         HIPCHK(hipStreamSynchronize(stream));
@@ -1447,7 +1547,9 @@ struct Solver final : SolverBase {
             return (double)(st >> 11) * (1.0 / 9007199254740992.0);
         };
         const double ext = (double)(n - 1) * cell, rt2 = 2.0 * 5.17 * cell;
-        const double r_near_gap = rt2 + conv_tier_log / lambda, r_keep_gap = rt2 + std::log((double)S / 2e-9) / lambda;
+        // (round 6: kept = inside the accumulated drop rule's candidate threshold, ln(K / eps_soft) -- was ln(S / eps); the 2e-9 stands for either precision as it did when the
+        // constants below were fitted)
+        const double r_near_gap = rt2 + conv_tier_log / lambda, r_keep_gap = rt2 + std::log(std::min((double)S, conv_drop_K) / (0.875 * 2e-9)) / lambda;
         std::vector<float> d2((size_t)S);
         size_t c_near = 0, c_keep = 0;
         for (int k = 0; k < K; k++) {
@@ -1507,7 +1609,7 @@ struct Solver final : SolverBase {
         // line is drawn per problem from an estimate of Step 1 that knows what the tiers drop (estimate_step1_ms_tiered: +-25 % over the data files) and of the
         // set-up on an idle device (assembly 1.4e-7 m^2, inversion 5.5e-11 m^3, the Green's table); beside Step 1 the set-up runs at ~0.4 of that speed.
         static const bool direct_est_off = knob("SHM_DUAL_DIRECT_EST_OFF") != nullptr;   // A/B knob: the fixed limit alone
-        if (!dual_direct && dual_direct_requested && !no_direct && !direct_est_off && (conv_tiered || conv_tiered32) && total_slabs == 1 && precond_available() && !gemm_dct() && n <= 512 &&
+        if (!dual_direct && dual_direct_requested && !no_direct && !direct_est_off && (conv_tiered || conv_tiered32) && precond_available() && !gemm_dct() && n <= 512 &&
             m > direct_max_m && m <= 16384 && conv_est_total_ms < 1e29) {
             const double md = (double)m;
             const double table_ms = 10.0 * std::pow((double)n / 512.0, 4.0);
@@ -2148,10 +2250,16 @@ struct Solver final : SolverBase {
         // (beside the tiered fp64 Step 1 -- where the assembly is co-resident and hidden -- up to 16384 rows since round 4: rocker 512^3 fp64, m = 12 612: solve phase
         // 71.5 -> 35.9 ms, 631 -> 609 ms per solve; after the fp32 Step 1, which leaves the set-up's kernels no room, the same choice costs 401 -> 423 ms)
         static const int max_m_env = knob("SHM_DENSE_S_MAX_M") ? atoi(knob("SHM_DENSE_S_MAX_M")) : 0;
-        const int max_m = max_m_env > 0 ? max_m_env : ((conv_tiered || conv_tiered32) ? 16384 : 8192);
+        // (an explicit shm_opts.dual_form request gets the documented 16384 rows whatever Step-1 kernel runs)
+        const bool asked = dual_form_req == SHM_DUAL_DIRECT || dual_form_req == SHM_DUAL_EXPLICIT_S_CG;
+        const int max_m = max_m_env > 0 ? max_m_env : ((conv_tiered || conv_tiered32 || asked) ? 16384 : 8192);
         // n not a power of two: applying S through the grid costs six dense products per CG iteration (shm_dct_gemm.hip.h: 5 ms at n = 362), so the explicit S
         // is worth its assembly up to the sizes its memory allows, whatever Step 1 hides
         if (gemm_dct()) return !off && m > 0 && m <= std::max(max_m, 16384);
+        // Round 6 -- several z-slabs (ranks): S and its inverse are REPLICATED (assembled from the grid's Green's table and the global rows on every rank, beside that
+        // rank's Step 1 like the rest of the set-up), and the solve touches the grid twice -- K^+ b and K^+ (A^T mu - b) on the slabs, two all-to-alls each --
+        // with the whole dual system solved on m-vectors that every rank holds: no gather of D^T Y, no whole-grid solve per rank (solve_dual).  Wherever it fits.
+        if (total_slabs > 1) return !off && fft_available() && m > 0 && m <= 16384 && n <= 512;
         if (off || total_slabs != 1 || !precond_available() || m <= 0 || m > max_m || n > 512) return false;
         // the assembly (216 table entries per matrix entry: ~2.2e-7 ms per m^2 on an idle device until round 4 -- 1.8 ms at m = 2842, 29 ms at m = 12 612; 1.1 ms at m = 2842 since the
         // windows along the last axis are fetched by two loads instead of three; the estimate below keeps the conservative constant) has to hide behind
@@ -2180,7 +2288,7 @@ struct Solver final : SolverBase {
         static const bool off = knob("SHM_GREEN_LATE") != nullptr;   // A/B knob
         static const int direct_max_m = knob("SHM_DUAL_DIRECT_MAX_M") ? atoi(knob("SHM_DUAL_DIRECT_MAX_M")) : 4096;
         if (dual_form_req == SHM_DUAL_EXPLICIT_S_CG || dual_form_req == SHM_DUAL_THROUGH_GRID) return false;
-        return !off && dual_direct_requested && knob("SHM_DUAL_NO_DIRECT") == nullptr && knob("SHM_DUAL_NO_DENSE_S") == nullptr && total_slabs == 1 && precond_available() &&
+        return !off && dual_direct_requested && knob("SHM_DUAL_NO_DIRECT") == nullptr && knob("SHM_DUAL_NO_DENSE_S") == nullptr && (total_slabs == 1 || fft_available()) && precond_available() &&
                !gemm_dct() && n <= 512 && S > 0 && S <= direct_max_m && (sizeof(T) == 8 || conv_tiered32 || n < 512 || knob("SHM_DUAL_DIRECT_ALWAYS") != nullptr || dual_form_req == SHM_DUAL_DIRECT);
     }
     void enqueue_green_table(hipStream_t st) {
@@ -3081,12 +3189,13 @@ struct Solver final : SolverBase {
         }
         // ---- r = Pm(g - S mu), z, p
         const bool sparse_ok = total_slabs == 1 && slabs[0].n_act_x > 0 && !knob("SHM_DENSE_DCT");
-        const bool dense_S = have_S && total_slabs == 1 && !comm;   // explicit S (shm_schur.hip.h): one dense mat-vec instead of scatter, five sweeps, gather
+        // explicit S (shm_schur.hip.h): one dense mat-vec instead of scatter, five sweeps, gather.  Several slabs / ranks (round 6): S (and S^-1, G^-1, B) are replicated and
+        // every slab applies them to its own copy of the m-vectors -- the same numbers everywhere, no communication inside the dual iteration
+        const bool dense_S = have_S;
         if (!dense_S)
             for (Slab<T>& sl : slabs) HIPCHK(hipMemsetAsync(sl.p.p, 0, sl.ntot * sizeof(T), stream));  // w = A^T nu lives in p: zero outside the touched nodes
         auto apply_S = [&](int vec) {   // red[1..m] = S v
-            Slab<T>& sl = slabs[0];
-            hipLaunchKernelGGL(ginv_matvec_kernel<double>, dim3(m), dim3(kBlock), 0, stream, m, mp, Sdense.p, mv(sl, vec), sl.red.p + 1);
+            for (Slab<T>& sl : slabs) hipLaunchKernelGGL(ginv_matvec_kernel<double>, dim3(m), dim3(kBlock), 0, stream, m, mp, Sdense.p, mv(sl, vec), sl.red.p + 1);
         };
         if (dense_S) apply_S(V_MU);
         else {
@@ -3138,7 +3247,6 @@ struct Solver final : SolverBase {
             // u = S^-1 r, v = S^-1 1 (formed behind the inversion, in the set-up), delta = u - (1^T u / 1^T v) v;  then r = Pm(g - S mu) again with the explicit S.
             // The first pass IS the solution (cond(S) ~ 5e2 ... 7e4 on the bunny grids: 1e-12 and better); further passes are iterative refinement, taken only
             // while the residual test of the CG path -- the same one -- is not met.
-            Slab<T>& sl = slabs[0];
             auto apply_Sinv = [&](const double* w, double* u) { hipLaunchKernelGGL(ginv_matvec_kernel<double>, dim3(m), dim3(kBlock), 0, stream, m, mp, Sinv.p, w, u); };
             // At most six passes, and never more than max_iters.  A tolerance below what the arithmetic can deliver (about eps * cond(S): cond is 5e2 ... 7e4
             // here) would otherwise end in SHM_ERR_NOCONV although mu is at rounding accuracy: when a pass no longer reduces the residual by at least a
@@ -3148,11 +3256,14 @@ struct Solver final : SolverBase {
             while (it < max_passes && !converged && !breakdown) {
                 const bool sample = st && nsamples < kMaxSamples;
                 if (sample) ev[3 * nsamples]->record(stream);
-                apply_Sinv(mv(sl, V_R), mv(sl, V_T1));
-                hipLaunchKernelGGL(dual_bordered_kernel, dim3(1), dim3(kDualBlock), 0, stream, m, mv(sl, V_T1), Sinv_ones.p, (const double*)nullptr, 1, mv(sl, V_MU));
+                for (Slab<T>& sl : slabs) {
+                    apply_Sinv(mv(sl, V_R), mv(sl, V_T1));
+                    hipLaunchKernelGGL(dual_bordered_kernel, dim3(1), dim3(kDualBlock), 0, stream, m, mv(sl, V_T1), Sinv_ones.p, (const double*)nullptr, 1, mv(sl, V_MU));
+                }
                 if (sample) ev[3 * nsamples + 1]->record(stream);
                 apply_S(V_MU);
-                hipLaunchKernelGGL(dual_init_residual_kernel, dim3(1), dim3(kDualBlock), 0, stream, m, mv(sl, V_G), sl.red.p + 1, mv(sl, V_R), sl.sc.p, 0);
+                for (Slab<T>& sl : slabs)
+                    hipLaunchKernelGGL(dual_init_residual_kernel, dim3(1), dim3(kDualBlock), 0, stream, m, mv(sl, V_G), sl.red.p + 1, mv(sl, V_R), sl.sc.p, 0);
                 if (sample) {
                     ev[3 * nsamples + 2]->record(stream);
                     nsamples++;
@@ -3593,14 +3704,20 @@ struct Solver final : SolverBase {
             solve_fast(o, st, e_start, e_conv, e_div, wall0);
             return;
         }
-        if (full && (o.solver == SHM_SOLVER_AUTO || o.solver == SHM_SOLVER_DUAL) && o.preconditioner != SHM_PRECOND_NONE) {
+        // Several ranks.  Round 6: where S fits (S <= 16384 sources bound the rows) and the grid is one of the sizes BASELINE.json names (256^3 ... 512^3, equal power-of-two
+        // slabs), AUTO takes the slab-distributed explicit-S forms of solve_dual -- S and its inverse replicated beside every rank's Step 1, K^+ on the slabs: no gather of
+        // D^T Y, no whole-grid solve per rank.  Everything else (larger constraint sets, 1024^3, odd sizes, weighted plans; SHM_SOLVER_DUAL) keeps the gathered solve.
+        const bool slab_forms_auto = full_wanted() && o.solver == SHM_SOLVER_AUTO && o.preconditioner != SHM_PRECOND_NONE && fft_available() && n >= 256 && n <= 512 && S <= 16384 &&
+                                     o.dual_form != SHM_DUAL_THROUGH_GRID && knob("SHM_MULTI_GATHERED") == nullptr;
+        if (full_wanted() && !slab_forms_auto && (o.solver == SHM_SOLVER_AUTO || o.solver == SHM_SOLVER_DUAL) && o.preconditioner != SHM_PRECOND_NONE) {
+            ensure_full();
             solve_gathered(o, st, e_start, e_conv, e_div, wall0);
             return;
         }
         static const bool setup_alone = knob("SHM_SETUP_ALONE") != nullptr;  // measurement knob: wait for Step 1 first, so that shm_stats.ms_setup is
         if (setup_alone) HIPCHK(hipStreamSynchronize(stream));                  // the set-up's time on an otherwise idle GPU (tools/scaling_model.py)
         e_s2a.record(stream2);
-        dual_direct_requested = (o.solver == SHM_SOLVER_DUAL || (o.solver == SHM_SOLVER_AUTO && o.preconditioner != SHM_PRECOND_NONE)) && precond_available() && !comm;
+        dual_direct_requested = (o.solver == SHM_SOLVER_DUAL || o.solver == SHM_SOLVER_DUAL_SLABS || (o.solver == SHM_SOLVER_AUTO && o.preconditioner != SHM_PRECOND_NONE)) && precond_available();
         build_constraints();  // on stream2: overlaps the Step-1 kernel; returns once (A A^T)^-1 (or S^-1, for the direct dual solve) is ready
         dual_direct_requested = false;
         e_s2b.record(stream2);

@@ -152,11 +152,17 @@ struct ConvParams {
     double pad_pos[3];     // tiered fp64 path: where the zero-weight padding entries of a compacted source list sit (bbox_min - n cell: a grid side from every node)
     float far_redo_ratio;  // tiered fp64 path: a block whose packed-fp32 sums exceed this fraction of |X| at any node evaluates its far sources again in fp64
                            // (= budget on Y / calibrated relative error of a packed-fp32 term; 3e38: never)
-    int far_rule;             // tiered fp64 path: 1 = the differential far rule beside the box rule (shm_conv_tiered.hip.h; chosen per problem by Solver::choose_far_rule)
+    int far_rule;             // tiered fp64 path: 1 = the differential far rule beside the box rule (shm_conv_tiered.hip.h; per launch from Solver::far_rule_now, per layer of the queue order from Solver::far_rule_plan)
     const unsigned char* unit_rule;        // tiered fp64 path: far rule per layer of the queue order (nullptr: far_rule everywhere) -- 1 sample, 0 box, 2 as the sample decides
     unsigned long long* sample_ctr;        // ... [0] far pairs, [1] pairs evaluated again, [2] blocks done of the sample (zeroed before the launch)
     int sample_blocks;                     // ... blocks of the sample
     const int* layer_order;   // tiered path: z-layer of blocks that stands at position p of the work queues' order (nullptr: p itself) -- see launch_conv
+    // tiered path, round 6: the drop rule by ACCUMULATED bound (shm_conv_tiered.hip.h).  b_s = (|w_s| / |w_*|) e^{-lambda gap_s} r_hi / d_s bounds a source's terms against the
+    // terms of the block's reference source s* at every node of the block.  A source is a candidate when b_s <= 2^drop_ltau and is dropped while the running sum of the
+    // block's dropped bounds stays <= drop_eps_soft; one with b_s <= 2^drop_ltau_hard = drop_tau_hard (the S-times-worst-case rule of rounds 3-5 on an eighth of the
+    // budget) is dropped whatever the sum.  drop_eps_soft = 0: nothing is dropped.
+    float drop_eps_soft, drop_ltau, drop_ltau_hard, drop_tau_hard;
+    float drop_check;         // fp64 solve: 1 / eps_far -- what a unit of dropped bound weighs against the packed-fp32 tier's L1 sums in the a-posteriori test
 };
 
 typedef float float2v __attribute__((ext_vector_type(2)));
@@ -166,7 +172,7 @@ constexpr int kConvTile = 8;      // 8x8x8 nodes per workgroup, 2 per lane
 // bunny (nothing to cull) pays with +1.2 % (42.0 -> 42.5 ms); the culled configurations are the fp32 ones
 template <typename T> constexpr int conv_cluster() { return sizeof(T) == 8 ? 64 : 32; }
 template <typename T> constexpr int conv_chunk() { return (sizeof(T) == 8 ? kSrcTile : 4 * kSrcTile) / conv_cluster<T>(); }  // clusters per LDS fill (256 / 1024 sources)
-constexpr int kConvClusterRec = 5;  // floats per cluster record: bounding sphere (centre, radius), ln of its largest source weight
+constexpr int kConvClusterRec = 6;  // floats per cluster record: bounding sphere (centre, radius), ln of its largest source weight, ln of the sum of its source weights (round 6)
 
 // Workgroup = one compact 8x8x8 tile of nodes (2 per lane); sources arrive as Morton-sorted clusters of 64 with bounding
 // spheres, staged through LDS 8 clusters at a time and broadcast-read by every lane.

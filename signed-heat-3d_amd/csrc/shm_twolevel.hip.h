@@ -13,8 +13,9 @@
 // Set-up: batched blocked Gauss-Jordan of the D_a (all boxes at once), T_a for all boxes in one launch, the Schur update per colour (boxes of one colour -- box
 // coordinates of equal parity -- touch disjoint separator rows, so eight passes need no atomics and the sums have a fixed order),
 // then the existing blocked Gauss-Jordan on the |Sigma| x |Sigma| Schur complement: (3/b)^3 of the flops of the full inversion.
-// Application (round 5: 3 launches; 5 until round 4): [row-parallel mat-vecs with D_a^-1 | column-parallel ones with T_a^T], the dense S^-1 mat-vec whose workgroups
-// gather w_S - T^T w_I first, row-parallel mat-vecs with T_a.  Exact up to rounding, so the projector and the dual preconditioner are the same operators as with the dense
+// Application, five launches (tl_rows_kernel: row-parallel mat-vecs with D_a^-1; tl_cols_kernel: column-parallel ones with E_a^T; tl_gather_sep_kernel; the dense S_Sigma^-1
+// mat-vec; tl_finish_kernel: row-parallel mat-vecs with T_a).  A three-launch form ([t | y = T^T w] in one launch, the S^-1 mat-vec's workgroups gathering w_S - T^T w_I
+// first) was built in round 5 behind SHM_TL_MERGED3 and measured slower (profiles/r05_projection.txt): five it stays.  Exact up to rounding, so the projector and the dual preconditioner are the same operators as with the dense
 // inverse (same iteration counts); matrices in double for the projector, an fp32 copy for the dual preconditioner.
 #pragma once
 #include "shm_kernels.hip.h"

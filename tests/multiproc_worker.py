@@ -46,7 +46,10 @@ def main():
                        slab_plan=int(os.environ.get("SHM_WORKER_SLAB_PLAN", "0")))
     s.set_problem(d["pos"], d["wnormal"], d["area"], float(d["lam"]), int(d["n"]), d["bbox_min"], float(d["cell"]))
     kw = {"primal-plain": dict(solver="primal", precond="none"), "primal-dct": dict(solver="primal", precond="dct"),
-          "dual": dict(solver="dual"), "dual-slabs": dict(solver="dual_slabs"), "fast": dict(fast=True)}[mode]
+          "dual": dict(solver="dual"), "dual-slabs": dict(solver="dual_slabs", dual_form="through_grid"), "fast": dict(fast=True),
+          # round 6: the slab-distributed explicit-S forms (S and its inverse replicated, K^+ on the slabs): the direct solve and CG on the explicit S
+          "dual-direct-slabs": dict(solver="dual_slabs", dual_form="direct"), "dual-scg-slabs": dict(solver="dual_slabs", dual_form="explicit_s_cg"),
+          "auto": dict()}[mode]
     if os.environ.get("SHM_WORKER_MAX_ITERS"):
         # did-not-converge hand-over (include/shm_grid.h: SHM_ERR_NOCONV still leaves phi): the gathered multi-rank solve must copy phi to the
         # rank's slabs and fill the statistics before it reports the status
@@ -54,7 +57,11 @@ def main():
         assert st.iters == int(os.environ["SHM_WORKER_MAX_ITERS"]) and (int(d["m"]) < 0 or st.m == int(d["m"])) and st.ms_pcg > 0
     else:
         st = s.solve(tol=1e-10 if precision == 64 else 0.0, scrub=scrub, **kw)
-    assert st.solver == {"dual": 2, "dual-slabs": 3}.get(mode, st.solver)
+    assert st.solver == {"dual": 2, "dual-slabs": 3, "dual-direct-slabs": 3, "dual-scg-slabs": 3}.get(mode, st.solver)
+    assert st.cg_form == {"dual-direct-slabs": 2, "dual-scg-slabs": 3, "dual-slabs": 0}.get(mode, st.cg_form), st.cg_form
+    if os.environ.get("SHM_WORKER_EXPECT_SOLVER"):   # what AUTO picked on this rank
+        want_solver, want_form = (int(v) for v in os.environ["SHM_WORKER_EXPECT_SOLVER"].split(":"))
+        assert st.solver == want_solver and (want_form < 0 and st.cg_form in (2, 3) or st.cg_form == want_form), (st.solver, st.cg_form)
     phi, (k0, k1) = s.get_phi()
     np.save(os.path.join(out_dir, "phi_%d.npy" % rank), phi)
     np.save(os.path.join(out_dir, "meta_%d.npy" % rank), np.array([k0, k1, st.iters, st.shift]))

@@ -319,6 +319,82 @@ def test_far_rule_is_decided_by_the_sample_per_problem(shm, monkeypatch):
         assert np.abs(Y["default"][ok] - Y["exact"][ok]).max() < Y_BUDGET
 
 
+def _adversarial_sources(kind, n, seed):
+    """Seeded inputs built to break the precision tiers of Step 1 (round 6) -- not meshes anyone would draw, but valid inputs of the C ABI:
+      sheets:  two parallel sheets of sources `sep` cells apart with opposite normals -- between and around them the two sheets' terms cancel in X, and
+               Y = X / |X| amplifies every error of the packed-fp32 tier and of the drop rule by (sum of |terms|) / |X|;
+      cloud:   a small dense point cloud in a large grid, lambda r up to ~1e3 at the far corners -- exponents in the hundreds, where a packed-fp32 term's relative
+               error (~1e-7 per unit of exponent) is at its largest and most sources are dropped;
+      areas:   a closed surface whose source weights span 1e4 : 1 -- the weight ratios enter every threshold (far, drop, exponent range of the fp32 tier).
+    Returns the arguments of set_problem."""
+    rng = np.random.default_rng(seed)
+    cell = 2.0 / (n - 1)
+    bbox_min = np.array([-1.0, -1.0, -1.0])
+    if kind.startswith("sheets"):
+        sep = float(kind.split(":")[1])             # separation in cells
+        hs = 2.0 * cell                            # source spacing: two cells
+        g = np.arange(-0.5, 0.5, hs) + 0.37 * cell
+        X, Yg = np.meshgrid(g, g, indexing="ij")
+        jit = lambda: (rng.random(X.shape) - 0.5) * 0.3 * hs   # noqa: E731
+        z0 = 0.123 * cell
+        lo = np.stack([X + jit(), Yg + jit(), np.full(X.shape, z0)], -1).reshape(-1, 3)
+        hi = np.stack([X + jit(), Yg + jit(), np.full(X.shape, z0 + sep * cell)], -1).reshape(-1, 3)
+        pos = np.vstack([lo, hi])
+        nrm = np.vstack([np.tile([0.0, 0.0, -1.0], (len(lo), 1)), np.tile([0.0, 0.0, 1.0], (len(hi), 1))])
+        area = np.full(len(pos), hs * hs) * (0.8 + 0.4 * rng.random(len(pos)))
+        lam = 1.0 / hs
+    elif kind == "cloud":
+        S = 4000
+        v = rng.normal(size=(S, 3))
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        R = 0.12
+        pos = R * v * (1.0 + 0.02 * rng.normal(size=(S, 1))) + np.array([0.05, -0.03, 0.02])
+        nrm = v
+        area = np.full(S, 4 * np.pi * R * R / S)
+        lam = 1.0e3 / (np.sqrt(3.0) * 1.0)          # lambda r ~ 1e3 at the corners of the grid
+        lam = min(lam, 4.0 / cell)                 # (keep lambda * cell <= 4: beyond it the tiered kernel hands over to the all-fp64 one by design)
+    elif kind == "areas":
+        S = 6000
+        v = rng.normal(size=(S, 3))
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        R = 0.45
+        pos = R * v * np.array([1.0, 0.7, 0.5])
+        nrm = v / np.array([1.0, 0.7, 0.5])
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        base = 4 * np.pi * R * R * 0.7 / S
+        area = base * 10.0 ** (-4.0 * rng.random(S))     # 1e4 : 1
+        lam = 1.0 / np.sqrt(base)
+    else:
+        raise ValueError(kind)
+    return dict(pos=pos, wnormal=nrm * area[:, None], area=area, lam=float(lam), n=n, bbox_min=bbox_min, cell=cell)
+
+
+@pytest.mark.parametrize("kind,n", [("sheets:0.5", 128), ("sheets:1", 128), ("sheets:2", 256), ("sheets:4", 128), ("cloud", 256), ("cloud", 128), ("areas", 128), ("areas", 256)])
+def test_tier_budget_on_adversarial_inputs(shm, kind, n):
+    """The tiered Step 1 against the all-fp64 arithmetic (shm_opts.step1_arith = EXACT_F64) on seeded inputs built to break the tiers: cancelling sheets, exponents in the
+    hundreds, weights over four decades.  The budget on Y holds where the all-fp64 field is finite, the non-finite sets agree, two default runs agree bit for bit; the margin
+    is printed (profiles/r06_gpu_tests.txt)."""
+    worst = 0.0
+    for seed in (1, 2):
+        d = _adversarial_sources(kind, n, seed)
+        s = make_solver(shm, d)
+        s.run_conv()
+        Yt = np.stack([s.get_field(k) for k in (0, 1, 2)], axis=1)
+        s.run_conv()
+        Yt2 = np.stack([s.get_field(k) for k in (0, 1, 2)], axis=1)
+        assert np.array_equal(Yt, Yt2, equal_nan=True)
+        s.run_conv(step1="exact_f64")
+        Ye = np.stack([s.get_field(k) for k in (0, 1, 2)], axis=1)
+        s.close()
+        ok = np.isfinite(Ye).all(axis=1)
+        assert ok.mean() > 0.2, ok.mean()
+        assert (np.isfinite(Yt).all(axis=1) == ok).all()
+        err = float(np.abs(Yt[ok] - Ye[ok]).max())
+        worst = max(worst, err)
+    print("\nadversarial %-10s n=%3d: max|dY| tiered vs all-fp64 = %.2e (budget %.0e, margin %.1fx)" % (kind, n, worst, Y_BUDGET, Y_BUDGET / max(worst, 1e-300)))
+    assert worst < Y_BUDGET, worst
+
+
 @pytest.mark.parametrize("precision", [64, 32])
 def test_step1_block_order_does_not_change_Y(shm, precision, monkeypatch):
     """The tiered kernel's work queues hand the z-layers of blocks out from the grid's centre to its faces (round 5; SHM_TIER_LAYER_ORDER=0: bottom to top).  A block's
@@ -575,10 +651,17 @@ def test_local_slabs_with_preconditioner(shm, slabs, mode):
     assert np.abs(phi - d["phi"]).max() < 1e-7
     s1 = make_solver(shm, d)
     st1 = s1.solve(tol=1e-10, **MODES[mode])
-    if st1.cg_form == 2:   # one slab, dual: the direct solve (explicit S^-1) -- one or two passes instead of a CG; the slabs iterate
-        assert st1.iters <= 2 and st.iters > 4, (st.iters, st1.iters)
+    if st1.cg_form == 2:   # one slab, dual: the direct solve (explicit S^-1) -- one or two passes instead of a CG
+        # round 6: several slabs take the same direct solve (S and S^-1 shared, K^+ on the slabs); with S applied through the grid (dual_form) they iterate
+        assert st1.iters <= 2 and st.cg_form == 2 and st.iters <= 2, (st.iters, st1.iters, st.cg_form)
         phi1, _ = s1.get_phi()
         assert np.abs(phi1 - phi).max() < 1e-8
+        st_it = s.solve(tol=1e-10, dual_form="through_grid", **MODES[mode])
+        phi_it, _ = s.get_phi()
+        assert st_it.cg_form == 0 and st_it.iters > 4 and np.abs(phi_it - d["phi"]).max() < 1e-7, (st_it.cg_form, st_it.iters)
+        st_cg = s.solve(tol=1e-10, dual_form="explicit_s_cg", **MODES[mode])
+        phi_cg, _ = s.get_phi()
+        assert st_cg.cg_form == 3 and abs(st_cg.iters - st_it.iters) <= 4 and np.abs(phi_cg - d["phi"]).max() < 1e-7, (st_cg.cg_form, st_cg.iters)
     else:
         assert abs(st.iters - st1.iters) <= 4
 
@@ -1428,6 +1511,11 @@ def _run_ranks(tmp_path, so, world, case, mode, tag, extra_env=None):
 # ---- several PROCESSES (ranks) on one GPU through a shared-memory double of librccl --------------------------------------
 @pytest.mark.parametrize("world,mode,case", [(2, "dual", "bunny_small_n32"), (4, "dual", "bunny_small_n32"), (8, "dual", "bunny_small_n32"),
                                              (2, "dual-slabs", "bunny_small_n32"), (4, "dual-slabs", "bunny_small_n32"),
+                                             # round 6: the slab-distributed explicit-S forms -- S and S^-1 replicated beside every rank's Step 1, K^+ on the slabs (two all-to-alls
+                                             # per application), the dual system on m-vectors every rank holds: the direct solve, and CG on the explicit S
+                                             (2, "dual-direct-slabs", "bunny_small_n32"), (4, "dual-direct-slabs", "bunny_small_n32"), (8, "dual-direct-slabs", "bunny_small_n32"),
+                                             (2, "dual-direct-slabs", "bunny_pc_n32"), (8, "dual-direct-slabs", "bunny_pc_n32"),
+                                             (2, "dual-scg-slabs", "bunny_small_n32"), (4, "dual-scg-slabs", "bunny_pc_n32"),
                                              (2, "primal-plain", "bunny_small_n32"), (8, "primal-plain", "bunny_small_n32"),
                                              (2, "primal-dct", "bunny_small_n32"), (8, "primal-dct", "bunny_small_n32"),
                                              (4, "fast", "bunny_small_fast_n32"), (8, "fast", "bunny_small_fast_n32"),
@@ -1462,6 +1550,25 @@ def test_multiprocess_ranks_on_one_gpu(shm, tmp_path, world, mode, case):
         s1.solve(tol=1e-10, scrub="_pc_" not in case, **MODES[mode])
         ref, _ = s1.get_phi()
         assert np.abs(phi - ref).max() < 1e-9
+
+
+@pytest.mark.parametrize("world,fname,precision", [(4, "bunny_small.obj", 64), (4, "bunny.pc", 64), (4, "rocker.obj", 32)])   # (four ranks: the all-to-all blocks of two would not fit the mock's 8 MB mailboxes)
+def test_multiprocess_auto_takes_the_slab_distributed_forms(shm, tmp_path, world, fname, precision):
+    """Round 6: at the sizes BASELINE.json names (256^3 here) the DEFAULT multi-rank solve no longer gathers D^T Y and solves the whole grid on every rank: S and
+    its inverse are replicated beside every rank's Step 1, K^+ runs on the z-slabs (two all-to-alls per application) and the dual system is solved on m-vectors
+    every rank holds -- directly (bunny: cg_form 2) or by CG on the explicit S (rocker.obj, m = 9110: cg_form 2 or 3, whichever the rank's Step 1 hides).  Every
+    rank must report that path and produce its planes of the single-rank answer."""
+    so = _build_rccl_mock(tmp_path)
+    case = "file:%s:4" % fname
+    phi, metas, covered = _run_ranks(tmp_path, so, world, case, "auto", "auto%d%s" % (precision, fname[:4]),
+                                     {"SHM_WORKER_PRECISION": str(precision), "SHM_WORKER_EXPECT_SOLVER": "3:2" if fname != "rocker.obj" else "3:-1"})
+    pre = _preprocess(fname, 4.0)
+    assert covered == pre["n"] == 256 and np.isfinite(phi).all()
+    _, st1, phi1 = _gpu_phi(shm, pre, shm.SHM_F64 if precision == 64 else shm.SHM_F32, not fname.endswith(".pc"), tol=1e-10 if precision == 64 else 0.0)
+    span = np.abs(phi1).max()
+    err = np.abs(phi - phi1).max()
+    print("\n%s 256^3 fp%d, %d ranks, AUTO: slab-distributed explicit-S solve against one rank: L_inf %.3e (max|phi| %.2f)" % (fname, precision, world, err, span))
+    assert err < (1e-8 if precision == 64 else 3e-5) * max(1.0, span), (err, span)
 
 
 @pytest.mark.parametrize("mode,plan", [("dual", 0), ("primal-dct", 0), ("dual", 1), ("primal-plain", 1)])
@@ -1586,6 +1693,7 @@ def test_bench_py_multi_rank_flow_on_one_gpu(tmp_path):
     m = d["also_multi"]
     assert m["primal_pcg"]["value"] > 0 and m["primal_pcg"]["rel_residual"] < 1e-7 and m["primal_pcg"]["preconditioner"].startswith("dct")
     assert m["primal_plain_cg_200"]["cg_iters"] == 200 and "cg_fused_kernel<DIR>" in m["primal_plain_cg_200"]["kernels"]
+    assert m["gathered_dual"]["value"] > 0 and m["gathered_dual"]["solver"] == 2     # the default of rounds 1-5 beside the round-6 one, on the same ranks
     # BASELINE.json configs[3] / configs[4] end to end on the same ranks (here at 32^3): value, phases and every rank's Step-1 pairs
     for wl, dtype in (("bunny_pc_512_f64_end_to_end", "f64"), ("spraybottle_pc_1024_f32_end_to_end", "f32")):
         leg = m[wl]

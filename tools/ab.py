@@ -18,8 +18,10 @@ if sys.argv[1] == "--child":
     alone = []
     for _ in range(4):   # Step 1 with nothing beside it (shm_grid_run_conv synchronises): wall clock, minimum of four
         t0 = time.perf_counter(); s.run_conv(); alone.append((time.perf_counter() - t0) * 1e3)
-    print("%-15s fp%d n=%d m=%5d %-24s total %.2f conv %.2f wait %.2f pcg %.2f iters %d solver %d cg_form %d rel %.1e conv_alone %.2f" % (
-        f, prec, pre["n"], st.m, name, st.ms_total, st.ms_conv, st.ms_wait_setup, st.ms_pcg, st.iters, st.solver, st.cg_form, st.rel_residual, min(alone)), flush=True)
+    nom = float(pre["n"]) ** 3 * pre["S"]
+    print("%-15s fp%d n=%d m=%5d %-24s total %.2f conv %.2f wait %.2f pcg %.2f iters %d solver %d cg_form %d rel %.1e conv_alone %.2f pairs64 %.3f pairs32 %.3f" % (
+        f, prec, pre["n"], st.m, name, st.ms_total, st.ms_conv, st.ms_wait_setup, st.ms_pcg, st.iters, st.solver, st.cg_form, st.rel_residual, min(alone),
+        st.pairs_fp64 / nom, st.pairs_fp32 / nom), flush=True)
     sys.exit(0)
 cases = [c.split(":") for c in sys.argv[1].split(",")]
 settings = []

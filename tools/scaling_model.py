@@ -11,6 +11,11 @@ Model, per solve on P ranks (z-slabs; constants at the top of the file, each mar
         beside Step 1 -- co-resident with the tiered fp64 kernel, where it takes `beside` ms, time-sliced to Step 1's end against the fp32 one -- and what is
         left of it when Step 1 ends runs at its idle-GPU rate: exposed = max(0, 1 - (conv/P)/beside) * alone; the right-hand side is all-gathered (every rank
         receives (P-1)/P of one N-vector over its xGMI links); the m-dimensional dual solve is replicated (latency-bound: slicing it buys nothing).
+  slab-distributed explicit-S dual (round 6; AUTO for 256^3 ... 512^3 with S <= 16384):
+                         t = imb(P) conv/P + div/P + exposed_setup + [replicated m-sized part + n_sized/P + 4 all-to-alls + 3 small all-reduces] + shift
+        S and S^-1 are replicated beside every rank's Step 1 (the same exposed_setup as above); the solve applies K^+ twice on the slabs -- the transform sweeps shard, every
+        application pays two all-to-alls in which a rank sends (P-1)/P of its slab -- and solves the dual system on m-vectors that every rank holds (direct: two dense
+        mat-vecs; CG on the explicit S: the iterations, replicated).  No gather of D^T Y, no whole-grid K^+ per rank.
   primal stencil CG:     t = (conv + div)/P + max(0, setup - conv/P) + iters * (sweeps/P + halo + 2 allreduce + project) + shift
         the N-sized sweeps shard, the m-sized projection is replicated, one ghost plane of z per neighbour and two all-reduces per iteration.
 """
@@ -72,6 +77,27 @@ def main():
         rows["nodes_per_s"].append(N / (t * 1e-3))
     for k, v in rows.items():
         print("%-28s " % k + " ".join("%10.3g" % x for x in v))
+    # ---- slab-distributed explicit-S dual (round 6)
+    if m <= 16384 and n <= 512:
+        # N-sized part of the one-GPU solve phase: two dense K^+ applications (10 N T bytes each at the measured transform rate: 3.7 TB/s at 512^3, 5.1 TB/s at 256^3,
+        # profiles/r03_bench_{512,256}_primal_dct.json); what is left of the measured phase is m-sized (mat-vecs, CG iterations on S) and stays replicated
+        app_ms = 10.0 * N * T / ((3.7e12 if n >= 512 else 5.1e12)) * 1e3
+        n_sized = min(ph["ms_pcg"], 2.0 * app_ms)
+        replicated = ph["ms_pcg"] - n_sized
+        print("%-28s %10s %10s %10s %10s   (solve phase on one GPU %.2f ms = %.2f N-sized + %.2f m-sized)" % ("slab-distributed explicit S", "P=1", "P=2", "P=4", "P=8", ph["ms_pcg"], n_sized, replicated))
+        rows = {"ms_per_solve": [], "speedup": []}
+        t1 = None
+        for P in (1, 2, 4, 8):
+            conv_p = ph["ms_conv"] / P * (imb.get(P, 1.0) if P > 1 else 1.0)
+            exposed = (max(0.0, 1.0 - conv_p / beside) * alone) if beside else max(ph["ms_wait_setup"], alone - conv_p)
+            a2a = 0.0 if P == 1 else (N * T * (P - 1) / (P * P)) / (min(P - 1, LINKS) * XGMI_LINK_GBS * 1e9) * 1e3 + P2P_LAT_US * 1e-3
+            small = 0.0 if P == 1 else 3 * ALLREDUCE_LAT_US * 1e-3
+            t = conv_p + ph["ms_div"] / P + exposed + replicated + n_sized / P + 4 * a2a + small + ph["ms_shift"]
+            t1 = t1 or t
+            rows["ms_per_solve"].append(t)
+            rows["speedup"].append(t1 / t)
+        for k, v in rows.items():
+            print("%-28s " % k + " ".join("%10.3g" % x for x in v))
     if len(sys.argv) > 2:
         p = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
         pp, it = p["phases_ms"], p["config"]["cg_iters"]
