@@ -227,6 +227,41 @@ def also_legs(shm, HostSolver, device, tol, pre256, scrub256):
         "phases_ms": {k: a[k] for k in ("ms_conv", "ms_div", "ms_wait_setup", "ms_pcg", "ms_shift", "ms_total")},
         # (round 5: EXACT_F64 runs the tiered kernel with nothing far and nothing dropped where the grid fits a block's exponent span -- it does at 256^3)
         "step1": step1_roofline(a, float(N256) * float(pre256["S"]), 64, tiered=True)}
+    # (0b) round 6 -- what the budget knob of Step 1 spans (shm_opts.step1_budget; the default stays 1e-8): ms per solve and L_inf of phi against the solve whose Step 1
+    # is all fp64 (itself held to the C oracle at this size by tests/test_gpu_parity.py::test_phi_of_the_default_solve_against_c_oracle_at_full_size: 3.6e-10, where
+    # the same curve is asserted against the oracle directly -- 126 s of host time that do not belong in a bench run)
+    s = shm.GridSolver(device=device, precision=64)
+    s.set_problem(pre256["pos"], pre256["wnormal"], pre256["area"], pre256["lam"], pre256["n"], pre256["bbox_min"], pre256["cell"])
+    s.solve(tol=tol, scrub=scrub256, step1="exact_f64")
+    phi_exact = s.get_phi()[0]
+    curve = []
+    for budget in (1e-8, 1e-7, 1e-6):
+        s.solve(tol=tol, scrub=scrub256, step1_budget=budget)
+        t0 = time.perf_counter()
+        stb = [s.solve(tol=tol, scrub=scrub256, step1_budget=budget).as_dict() for _ in range(reps)]
+        dtb = (time.perf_counter() - t0) / reps
+        ab = {k: float(np.mean([x[k] for x in stb])) for k in stb[0]}
+        curve.append({"step1_budget": budget, "ms_per_step": 1e3 * dtb, "ms_conv": ab["ms_conv"], "value": N256 / dtb,
+                      "packed_fp32_share_of_evaluated_pairs": ab["pairs_fp32"] / max(1.0, ab["pairs_fp32"] + ab["pairs_fp64"]),
+                      "linf_phi_vs_exact_f64_step1": float(np.abs(s.get_phi()[0] - phi_exact).max())})
+    s.close()
+    out["step1_budget_curve"] = {"workload": "bunny_small.obj 256^3 fp64, %d timed solves per point" % reps, "unit": "grid-nodes/s", "points": curve,
+                                 "note": "a reported curve, not a new default: the library default is 1e-8 (tests hold Y to it against the C oracle at full size)"}
+    # (0c) configs[0] -- the only size the reference itself can run (64^3, CPU Eigen path) -- as a first-class number of this record
+    pre64 = HostSolver(os.path.join(ROOT, "data/bunny_small.obj")).preprocess(hCoef=2.0)
+    s = shm.GridSolver(device=device, precision=64)
+    s.set_problem(pre64["pos"], pre64["wnormal"], pre64["area"], pre64["lam"], pre64["n"], pre64["bbox_min"], pre64["cell"])
+    for _ in range(3):
+        s.solve(tol=tol)
+    reps64 = 50
+    t0 = time.perf_counter()
+    sts = [s.solve(tol=tol).as_dict() for _ in range(reps64)]
+    dt = (time.perf_counter() - t0) / reps64
+    s.close()
+    a = {k: float(np.mean([x[k] for x in sts])) for k in sts[0]}
+    out["bunny_small_64_f64"] = {"workload": "BASELINE.json configs[0]: bunny_small.obj at 64^3 (hCoef 2) fp64, library defaults; %d timed solves" % reps64,
+                                 "value": pre64["n"] ** 3 / dt, "unit": "grid-nodes/s", "ms_per_step": 1e3 * dt, "constraint_rows": int(a["m"]), "cg_iters": int(a["iters"]),
+                                 "phases_ms": {k: a[k] for k in ("ms_conv", "ms_div", "ms_setup", "ms_wait_setup", "ms_pcg", "ms_shift", "ms_total")}}
     pre = HostSolver(os.path.join(ROOT, "data/bunny_small.obj")).preprocess(hCoef=5.0)
     n = pre["n"]
     N = n ** 3

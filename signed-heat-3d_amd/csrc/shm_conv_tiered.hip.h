@@ -190,12 +190,6 @@ constexpr int kTierTX = SHM_TIER_TX, kTierTY = 64 / kTierTX;   // a wave's block
 // (A threshold that grows with the block's exponent offset -- eps_far proportional to lambda' r, as the 1-ulp error of v_rsq_f32 suggests -- was measured
 // too: SprayBottle.pc 1024^3 8.3e-9 -> 7.7e-9 for +9 % of its Step 1, knot 1024^3 +6.5 %; profiles/r04_eps_sweep.txt.  Not adopted.)
 constexpr double kTierBudget = 1.0e-8, kTierEpsFar = 3.0e-6;
-// Round 6: the calibration point of kTierEpsFar is lambda r = 28, i.e. a scaled exponent u = lambda' r = 40; a packed-fp32 term's error grows with its exponent (the rounding of
-// u, ~6e-8 u, goes straight into 2^-u), so the a-posteriori test prices a term at kTierEpsFar * max(1, u_block / kTierEpsFarU0), u_block the largest exponent of a nearest term in
-// the block (lambda' (d0 + 2 rt)): 7.5e-8 per unit of exponent, five times the observed slope like the constant it extends.  Found by the seeded adversarial inputs of
-// tests/test_gpu_parity.py::test_tier_budget_on_adversarial_inputs (a small dense cloud in a grid with lambda r up to ~1e3: 4.2e-8 against the 1e-8 budget under the constant).
-// The sample that decides the far rule (Solver::far_rule_plan) keeps counting with the constant: its verdict is about the rule's cost where the rule applies (u <= 72).
-constexpr float kTierEpsFarU0 = 40.0f;
 constexpr int kTierCluster = 64;                    // sources per cluster = lanes per wave: one source per lane in the classification
 constexpr int kTierChunk = 4;                       // clusters per LDS fill
 constexpr int kTierFill = kTierCluster * kTierChunk;
@@ -320,7 +314,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
             }
         }
         const unsigned long long far_before = cnt_far, redo_before = cnt_redo;
-        bool sample_counts_redo = false;   // (a sample block: its second pass counts towards the verdict only where the test at the calibration point fails)
         const int ty = trem / P.tiles_x, tx = trem - ty * P.tiles_x;
         const int i0 = tx * kTierTX, j0 = ty * kTierTY, kk0 = P.kk_begin + tz * NPT;
 
@@ -603,6 +596,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                 const bool far = lhs_far > g_l2 + rel && in_range;
                 // the drop rule by accumulated bound (see the block's header above): candidates of this cluster together, or only the ones below the hard threshold
                 bool drop = valid && cdrop_cur;   // (pass 1 walks a cluster that pass 0 dropped as a whole)
+#ifndef SHM_X_NO_SRCDROP
                 if (drop_on && !cdrop_cur) {
                     const float lb = rel - lhs_drop + 2e-5f;   // log2 of b_s without its geometric factor, rounded up
                     const bool cand = valid && lb <= P.drop_ltau;
@@ -624,6 +618,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                         }
                     }
                 }
+#endif
                 // pass 1 evaluates what pass 0 dropped as well, where the term's exponent stays inside the span of the block's scale (beyond it the term is < 2^-900 of the scale)
                 const bool span_ok = fmaf(dist, lam_l2, span_c) < 0.f;
                 const bool to64 = valid && (pass == 0 ? (!drop && !far) : (drop ? span_ok : far));   // (drop first: a source outside the fp32 exponent range is not "far", but it may well be dropped)
@@ -740,12 +735,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
             // what the block dropped, against |X| as well (round 6): its accumulated bound R is relative to the reference source's term at the node, evaluated here once per node
             // (in the block's scale, like the sums); R / eps_far puts it on the scale of the packed-fp32 tier's L1 sums
             // (fp32 is plenty for a bound that carries a 1 % margin, and it keeps the test out of the kernel's register peak)
+#ifdef SHM_X_NO_CHECKTERM
+            const float r_drop = 0.f;
+#else
             const float r_drop = R_soft + R_hard;
-            float coff_here = coff, ratio_here = P.far_redo_ratio;
-            asm volatile("" : "+v"(coff_here), "+v"(ratio_here));   // (invariant in the pass loop: keep it behind the loops, see below)
-            const double ratio_base = (double)ratio_here;
-            const double ratio = (double)(ratio_here / fmaxf(1.f, (coff_here + 2.f * rt_w * lam_l2) * (1.f / kTierEpsFarU0)));   // (wave-uniform)
-            bool fail_base = false;
+#endif
             // (everything here is invariant in the pass loop; the reference source comes back from LDS, the rest is pinned behind the loops by the empty asm -- computed ahead of
             // them it held 16 registers through them)
             const float4 st = star_stash[wave];
@@ -760,12 +754,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                 // |w_*| e^{-lambda r} / r in the block's scale 2^-k0:  2^(-lambda' r - k0) lambda' / (lambda' r)      (the node on s*: inf * 0 = NaN -- compares false, X is NaN there itself)
                 const float dz = e * cellq + sdz0, d2 = fmaf(dz, dz, sxy2), rinv = __builtin_amdgcn_rsqf(d2);
                 const float tstar = r_drop > 0.f ? rs * __builtin_amdgcn_exp2f(-d2 * rinv - k0_here) * rinv : 0.f;
-                const double lhs_t = fma((double)fl[e / 2][e & 1], e0, (double)tstar), xn = sqrt(x0 * x0 + x1 * x1 + x2 * x2);
-                const bool live = live_xy && kk0 + e < P.kk_end;
-                fail = fail || (live && lhs_t > ratio * xn);
-                fail_base = fail_base || (live && lhs_t > ratio_base * xn);
+                fail = fail || (live_xy && kk0 + e < P.kk_end && fma((double)fl[e / 2][e & 1], e0, (double)tstar) > (double)P.far_redo_ratio * sqrt(x0 * x0 + x1 * x1 + x2 * x2));
             }
-            sample_counts_redo = __ballot(fail_base) != 0ull;
             if (__ballot(fail) == 0ull) break;
 #pragma unroll
             for (int e = 0; e < NPT / 2; e++) fx[e] = fy[e] = fz[e] = float2v{0.f, 0.f};
@@ -795,7 +785,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
         }
         if constexpr (CHECK) {
             if (rule_sel == 1 && lane == 0)   // a sample block reports: far pairs, pairs evaluated again, then that it is done; the last one to report publishes the verdict
-                sample_report(P.sample_ctr, (cnt_far - far_before) * (unsigned long long)(64 * NPT), sample_counts_redo ? (cnt_redo - redo_before) * (unsigned long long)(64 * NPT) : 0ull, P.sample_blocks);
+                sample_report(P.sample_ctr, (cnt_far - far_before) * (unsigned long long)(64 * NPT), (cnt_redo - redo_before) * (unsigned long long)(64 * NPT), P.sample_blocks);
         }
     }  // unit loop
     if (counters && lane == 0) {

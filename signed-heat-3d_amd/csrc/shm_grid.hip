@@ -2588,8 +2588,14 @@ struct Solver final : SolverBase {
         static const int nw_env = knob("SHM_FUSED_WAVES") ? atoi(knob("SHM_FUSED_WAVES")) : 0;  // A/B knob: 4, 8 or 16 waves per workgroup
         static const int ry_env = knob("SHM_FUSED_RY") ? atoi(knob("SHM_FUSED_RY")) : 0;
         c.ry = (vec == 1) ? 4 : 2;
+#ifdef SHM_AB_SHAPES
         if (ry_env == 4 || (ry_env == 2 && vec != 1)) c.ry = ry_env;   // (1 row per lane measured no better than 2)
-        c.nw = (nw_env == 4 && c.wx <= 4) ? 4 : (c.ry <= 2 && (nw_env == 16 || (nw_env == 0 && c.wx >= 4))) ? 16 : 8;   // (16-wave kernels exist for <= 2 rows per lane)
+        const bool four_waves = nw_env == 4 && c.wx <= 4;
+#else
+        (void)ry_env;
+        const bool four_waves = false;
+#endif
+        c.nw = four_waves ? 4 : (c.ry <= 2 && (nw_env == 16 || (nw_env == 0 && c.wx >= 4))) ? 16 : 8;   // (16-wave kernels exist for <= 2 rows per lane)
         const int wy = c.nw / c.wx;
         static const int zc_env = knob("SHM_FUSED_ZC") ? atoi(knob("SHM_FUSED_ZC")) : 0;
         // rows per workgroup wy * ry: 8 rows per lane unless that leaves too few workgroups along y to fill the chip with deep z chunks
@@ -2626,6 +2632,8 @@ struct Solver final : SolverBase {
         if (fold_pq && !sl.pq_partials.p) sl.pq_partials.alloc(sl.partials.count);
         if (c.part == FUSED_INTERIOR) { F.zc_first = 1; c.zchunks -= 2; }
         else if (c.part == FUSED_BOUNDARY) { F.zc_stride = c.zchunks - 1; c.zchunks = 2; }
+#ifdef SHM_AB_SHAPES   // (round 6: the 4-wave shapes and, for vector widths > 1, the 4-rows-per-lane shapes exist for A/B runs only -- 52 of the ~120 instantiations of
+                       // cg_fused_kernel, compiled in with -DSHM_AB_SHAPES; the launcher below never selects them otherwise)
         if constexpr (WX <= 4) {
             if (c.nw == 4) {
                 hipLaunchKernelGGL((cg_fused_kernel<T, VEC, RY, WX, 4 / WX, MODE>), dim3((unsigned)(c.yblocks * c.zchunks)), dim3(256), 0, stream, F, sl.sc.p, slot_old,
@@ -2633,6 +2641,7 @@ struct Solver final : SolverBase {
                 return;
             }
         }
+#endif
         if constexpr (RY <= 2) {
             if (c.nw == 16) {   // 16-wave workgroups: twice the rows per workgroup, half the re-read border rows (see fused_cfg)
                 hipLaunchKernelGGL((cg_fused_kernel<T, VEC, RY, WX, 16 / WX, MODE>), dim3((unsigned)(c.yblocks * c.zchunks)), dim3(1024), 0, stream, F, sl.sc.p, slot_old,
@@ -2658,7 +2667,9 @@ struct Solver final : SolverBase {
         FusedCfg c = fused_cfg(sl);
         c.part = part;
         if (vec == 1) launch_fused_w<MODE, 1, 4>(sl, c, slot_old, slot_new, init, use_uw, alpha_slot, zsrc, pin, pout);
+#ifdef SHM_AB_SHAPES
         else if (c.ry == 4) launch_fused_w<MODE, vec_width<T>(), 4>(sl, c, slot_old, slot_new, init, use_uw, alpha_slot, zsrc, pin, pout);
+#endif
         else launch_fused_w<MODE, vec_width<T>(), 2>(sl, c, slot_old, slot_new, init, use_uw, alpha_slot, zsrc, pin, pout);
         return c.yblocks * c.zchunks;
     }

@@ -310,7 +310,7 @@ def test_far_rule_is_decided_by_the_sample_per_problem(shm, monkeypatch):
                 Y[mode] = np.stack([s.get_field_planes(f, 96, 160) for f in (0, 1, 2)], axis=1)
             s.close()
         print("\nfar rule %s 256^3: packed-fp32 share of the evaluated pairs: default %.3f, box rule %.3f, rule forced %.3f" % (path, share["default"], share["box"], share["rule"]))
-        assert share["rule"] > share["box"] + 0.02
+        assert share["rule"] > share["box"] + (0.02 if expect_rule else 0.005)   # (rocker: the rule's far pairs that fail the a-posteriori test come back as fp64 pairs)
         assert share["box"] - 1e-3 <= share["default"] <= share["rule"] + 1e-3       # the sample's verdict lies between the two forced runs
         if expect_rule:
             assert share["default"] > share["box"] + 0.6 * (share["rule"] - share["box"])
@@ -337,10 +337,17 @@ def _adversarial_sources(kind, n, seed):
         X, Yg = np.meshgrid(g, g, indexing="ij")
         jit = lambda: (rng.random(X.shape) - 0.5) * 0.3 * hs   # noqa: E731
         z0 = 0.123 * cell
-        lo = np.stack([X + jit(), Yg + jit(), np.full(X.shape, z0)], -1).reshape(-1, 3)
-        hi = np.stack([X + jit(), Yg + jit(), np.full(X.shape, z0 + sep * cell)], -1).reshape(-1, 3)
+        # (gently undulating sheets: with flat ones every normal is +-z, X is parallel to z everywhere and Y = (0, 0, +-1) whatever the arithmetic)
+        hgt = lambda x, y: 0.03 * np.sin(5.0 * x) * np.cos(4.0 * y)   # noqa: E731
+        def sheet(dz, sign):
+            x, y = X + jit(), Yg + jit()
+            nv = np.stack([-0.15 * np.cos(5.0 * x) * np.cos(4.0 * y), 0.12 * np.sin(5.0 * x) * np.sin(4.0 * y), np.ones(x.shape)], -1)
+            nv /= np.linalg.norm(nv, axis=-1, keepdims=True)
+            return np.stack([x, y, hgt(x, y) + z0 + dz], -1).reshape(-1, 3), (sign * nv).reshape(-1, 3)
+        lo, nlo = sheet(0.0, -1.0)
+        hi, nhi = sheet(sep * cell, 1.0)
         pos = np.vstack([lo, hi])
-        nrm = np.vstack([np.tile([0.0, 0.0, -1.0], (len(lo), 1)), np.tile([0.0, 0.0, 1.0], (len(hi), 1))])
+        nrm = np.vstack([nlo, nhi])
         area = np.full(len(pos), hs * hs) * (0.8 + 0.4 * rng.random(len(pos)))
         lam = 1.0 / hs
     elif kind == "cloud":
@@ -389,6 +396,16 @@ def test_tier_budget_on_adversarial_inputs(shm, kind, n):
         ok = np.isfinite(Ye).all(axis=1)
         assert ok.mean() > 0.2, ok.mean()
         assert (np.isfinite(Yt).all(axis=1) == ok).all()
+        # Where |X|^2 is a SUBNORMAL double the reference's own X /= X.norm() (signed_heat_grid_solver.cpp:61) has lost most of its bits -- |X| < 1.5e-154, i.e. lambda r beyond
+        # ~350: 2.5e-8 off the exact direction at lambda r = 356 on this very input, numpy's long double against the C oracle and against either kernel, which both follow the
+        # reference there, each with the rounding of its own summation order; at lambda r ~ 372 it turns into 0/0.  The budget is a statement about the zone where the
+        # reference's arithmetic itself is accurate: nodes nearer than lambda r = 335 to the nearest source (profiles/NOTES_r06.md).
+        ijk = np.stack(np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij"), -1).reshape(-1, 3)[:, ::-1]   # (x fastest)
+        xyz = d["bbox_min"] + ijk * d["cell"]
+        cen = d["pos"].mean(axis=0)
+        r_lb = np.maximum(0.0, np.linalg.norm(xyz - cen, axis=1) - np.linalg.norm(d["pos"] - cen, axis=1).max())   # lower bound of the distance to the nearest source
+        ok &= d["lam"] * r_lb < 335.0
+        assert ok.mean() > 0.05, ok.mean()
         err = float(np.abs(Yt[ok] - Ye[ok]).max())
         worst = max(worst, err)
     print("\nadversarial %-10s n=%3d: max|dY| tiered vs all-fp64 = %.2e (budget %.0e, margin %.1fx)" % (kind, n, worst, Y_BUDGET, Y_BUDGET / max(worst, 1e-300)))
@@ -754,6 +771,11 @@ def test_phi_of_the_default_solve_against_c_oracle_at_full_size(shm, oracle_c, h
     phi, _ = s.get_phi()
     ste = s.solve(scrub=True, step1="exact_f64")        # the reference's arithmetic in every pair of Step 1 (round 5: through the tiered kernel's fp64 body)
     phi_exact, _ = s.get_phi()
+    # round 6: the curve the budget knob spans (shm_opts.step1_budget; reported, not a new default): phi of the solve at each budget, held below against the same oracle
+    curve = {}
+    for budget in (1e-7, 1e-6):
+        stb = s.solve(scrub=True, step1_budget=budget)
+        curve[budget] = (s.get_phi()[0], stb)
     s.close()
     ref = np.zeros(n ** 3)
     sto = np.zeros(5)
@@ -774,6 +796,11 @@ def test_phi_of_the_default_solve_against_c_oracle_at_full_size(shm, oracle_c, h
     err_exact = float(np.abs(phi_exact - ref).max())
     print("phi bunny_small.obj n=%d: step1_arith = EXACT_F64 (pairs fp64 %.3e, fp32 %.0f) against the C oracle: L_inf %.3e" % (n, ste.pairs_fp64, ste.pairs_fp32, err_exact))
     assert err_exact < 1e-7 and ste.pairs_fp32 == 0, err_exact
+    for budget, (phib, stb) in sorted(curve.items()):
+        errb = float(np.abs(phib - ref).max())
+        print("phi bunny_small.obj n=%d: step1_budget %.0e (Step 1 %.2f ms against %.2f at 1e-8; packed-fp32 share %.3f): L_inf against the C oracle %.3e"
+              % (n, budget, stb.ms_conv, st.ms_conv, stb.pairs_fp32 / max(1.0, stb.pairs_fp32 + stb.pairs_fp64), errb))
+        assert errb < 1e-6, (budget, errb)     # (phi inherits a few per cent of the budget on Y; the north star's gate is 1e-5)
 
 
 ALL_DATA = ["bunny_small.obj", "polygon-bear.obj", "rocker.obj", "chair.obj", "knot.obj", "bunny.pc", "rocker.pc", "chair.pc", "knot.pc", "SprayBottle.pc"]
@@ -1777,10 +1804,10 @@ print(repr(out))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("waves", ["4", "16"])
+@pytest.mark.parametrize("waves", ["16"])   # (round 6: the 4-wave shapes are A/B shapes, compiled only into -DSHM_AB_SHAPES builds)
 def test_fused_sweeps_other_workgroup_shapes_match_lu_golden(waves):
     """The fused stencil-CG sweeps ship with 8 waves per workgroup where a grid row needs one or two waves and with 16 where it needs four or more
-    (512^3 fp64, 1024^3 fp32) -- sizes the small fixtures never reach.  SHM_FUSED_WAVES forces the 4- / 16-wave kernels onto the fixtures
+    (512^3 fp64, 1024^3 fp32) -- sizes the small fixtures never reach.  SHM_FUSED_WAVES forces the 16-wave kernels onto the fixtures
     (a fresh process: the knob is read once): same LU-golden phi from the plain and the DCT-preconditioned primal solvers, fp64 and fp32 transforms."""
     import os
     import subprocess
