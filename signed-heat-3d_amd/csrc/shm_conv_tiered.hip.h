@@ -596,7 +596,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                 const bool far = lhs_far > g_l2 + rel && in_range;
                 // the drop rule by accumulated bound (see the block's header above): candidates of this cluster together, or only the ones below the hard threshold
                 bool drop = valid && cdrop_cur;   // (pass 1 walks a cluster that pass 0 dropped as a whole)
-#ifndef SHM_X_NO_SRCDROP
                 if (drop_on && !cdrop_cur) {
                     const float lb = rel - lhs_drop + 2e-5f;   // log2 of b_s without its geometric factor, rounded up
                     const bool cand = valid && lb <= P.drop_ltau;
@@ -618,7 +617,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                         }
                     }
                 }
-#endif
                 // pass 1 evaluates what pass 0 dropped as well, where the term's exponent stays inside the span of the block's scale (beyond it the term is < 2^-900 of the scale)
                 const bool span_ok = fmaf(dist, lam_l2, span_c) < 0.f;
                 const bool to64 = valid && (pass == 0 ? (!drop && !far) : (drop ? span_ok : far));   // (drop first: a source outside the fp32 exponent range is not "far", but it may well be dropped)
@@ -735,11 +733,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
             // what the block dropped, against |X| as well (round 6): its accumulated bound R is relative to the reference source's term at the node, evaluated here once per node
             // (in the block's scale, like the sums); R / eps_far puts it on the scale of the packed-fp32 tier's L1 sums
             // (fp32 is plenty for a bound that carries a 1 % margin, and it keeps the test out of the kernel's register peak)
-#ifdef SHM_X_NO_CHECKTERM
-            const float r_drop = 0.f;
-#else
             const float r_drop = R_soft + R_hard;
-#endif
             // (everything here is invariant in the pass loop; the reference source comes back from LDS, the rest is pinned behind the loops by the empty asm -- computed ahead of
             // them it held 16 registers through them)
             const float4 st = star_stash[wave];
