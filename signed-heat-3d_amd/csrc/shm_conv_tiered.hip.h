@@ -576,7 +576,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                 const bool in_range = fmaf(dist, lam_l2, range_c) <= lw;                   // every term of the source stays a normal fp32 number over the block
                 float lhs_far = lhs, lhs_drop = lhs;
                 {
-                    if (use_diff || (drop_on && !cdrop_cur)) {
+                    // The drop rule needs the differential bound only where it can change a decision: it exceeds the box rule's bound by at most 2 rt lambda' (|r_s - d_s| and
+                    // |r_hi - r_s*| are each at most a block radius), so a source the box rule already makes a candidate stays one, and one more than that slack above the
+                    // threshold cannot become one.  Evaluated for the whole cluster when ANY lane sits in the window (wave-uniform branch): on inputs whose sources all
+                    // matter (the bunny) almost never, and the fp32 solve -- whose far rule is not the differential one -- is back to its round-5 classification cost.
+                    bool want_diff = use_diff;
+                    if (!want_diff && drop_on && !cdrop_cur) {
+                        const float lb_box = rel - lhs;
+                        want_diff = __ballot(valid && lb_box > P.drop_ltau && lb_box <= P.drop_ltau + 2.02f * rt_w * lam_l2) != 0ull;
+                    }
+                    if (want_diff) {
                         // Differential rule (round 5, late; chosen per problem: Solver::far_rule_plan / far_rule_now): with s* the source nearest to the block's centre c,
                         //   r_s(x) - r_near(x) >= f(x) := r_s(x) - r_s*(x) >= f(c) - rt (|u_s(c) - u_s*(c)| + rt (1 / d_s + 1 / d_s*))      for every x of the block
                         // (u: unit vectors towards c; d: distances to the block's box -- the gradient of f is u_s - u_s*, a unit vector turns by at most |x - c| / d).  Two
@@ -690,35 +699,46 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                 near_source(rec);
             }
             // ---- far tier: packed fp32 (two nodes per instruction), kFarUnroll sources in flight (the transcendentals' results arrive late) ----
+            // (written stage by stage over the kFarUnroll x NPT / 2 packed pairs in flight: the order the scheduler starts from keeps every transcendental's consumer a full
+            // stage behind it.  Round 6: with the per-source form the fp32 solve's loop came out with 24 s_nop of trans-use hazards -- 142 instructions where round 5's
+            // build had 116 -- once unrelated code around it changed; this form does not depend on the scheduler finding the interleaving.)
             for (int i0f = 0; i0f < nfar; i0f += kFarUnroll) {
+                constexpr int kP = kFarUnroll * (NPT / 2);
+                float2v wxy[kFarUnroll], pcw[kFarUnroll], d2[kP], rinv[kP], g[kP];
+                float dxy2[kFarUnroll];
 #pragma unroll
                 for (int u = 0; u < kFarUnroll; u++) {
                     const int s = i0f + u;
                     const float4 pa = *reinterpret_cast<const float4*>(&tA[4 * s]);
-                    const float2v pc = *reinterpret_cast<const float2v*>(&tC[2 * s]);
-                    const float2v wxy = {pa.z, pa.w};
-                    float2v zz[NPT / 2];
+                    pcw[u] = *reinterpret_cast<const float2v*>(&tC[2 * s]);
+                    wxy[u] = float2v{pa.z, pa.w};
+                    const float dx = qx - pa.x, dy = qy - pa.y;   // (scaled coordinates: qx, qy and the staged positions are x lambda log2 e)
+                    dxy2[u] = dx * dx + dy * dy;
                     if constexpr (NPT == 4) {
                         const float4 pb = *reinterpret_cast<const float4*>(&tB[4 * s]);
-                        zz[0] = float2v{pb.x, pb.y};
-                        zz[1] = float2v{pb.z, pb.w};
+                        d2[2 * u] = float2v{pb.x, pb.y};
+                        d2[2 * u + 1] = float2v{pb.z, pb.w};
                     } else {
-                        zz[0] = *reinterpret_cast<const float2v*>(&tB[2 * s]);
+                        d2[u] = *reinterpret_cast<const float2v*>(&tB[2 * s]);
                     }
-                    const float dx = qx - pa.x, dy = qy - pa.y;   // (scaled coordinates: qx, qy and the staged positions are x lambda log2 e)
-                    const float dxy2 = dx * dx + dy * dy;
+                }
 #pragma unroll
-                    for (int h = 0; h < NPT / 2; h++) {
-                        const float2v d2 = zz[h] + float2v{dxy2, dxy2};
-                        const float2v rinv = {__builtin_amdgcn_rsqf(d2.x), __builtin_amdgcn_rsqf(d2.y)};   // 1 / (lambda log2 e r)
-                        const float2v arg = __builtin_elementwise_fma(-d2, rinv, float2v{coff, coff});     // -lambda log2 e (r - d0)
-                        const float2v ex = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
-                        const float2v g = ex * rinv;
-                        pk_fma_lo(fx[h], wxy, g);
-                        pk_fma_hi(fy[h], wxy, g);
-                        pk_fma_lo(fz[h], pc, g);
-                        if constexpr (CHECK) pk_fma_hi(fl[h], pc, g);
-                    }
+                for (int a = 0; a < kP; a++) d2[a] += float2v{dxy2[a / (NPT / 2)], dxy2[a / (NPT / 2)]};
+#pragma unroll
+                for (int a = 0; a < kP; a++) rinv[a] = float2v{__builtin_amdgcn_rsqf(d2[a].x), __builtin_amdgcn_rsqf(d2[a].y)};   // 1 / (lambda log2 e r)
+#pragma unroll
+                for (int a = 0; a < kP; a++) d2[a] = __builtin_elementwise_fma(-d2[a], rinv[a], float2v{coff, coff});              // -lambda log2 e (r - d0)
+#pragma unroll
+                for (int a = 0; a < kP; a++) g[a] = float2v{__builtin_amdgcn_exp2f(d2[a].x), __builtin_amdgcn_exp2f(d2[a].y)};
+#pragma unroll
+                for (int a = 0; a < kP; a++) g[a] *= rinv[a];
+#pragma unroll
+                for (int a = 0; a < kP; a++) {
+                    const int u = a / (NPT / 2), h = a % (NPT / 2);
+                    pk_fma_lo(fx[h], wxy[u], g[a]);
+                    pk_fma_hi(fy[h], wxy[u], g[a]);
+                    pk_fma_lo(fz[h], pcw[u], g[a]);
+                    if constexpr (CHECK) pk_fma_hi(fl[h], pcw[u], g[a]);
                 }
             }
             c = c_next;
