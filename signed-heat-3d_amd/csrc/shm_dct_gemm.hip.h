@@ -18,7 +18,7 @@ namespace shm {
 
 // Cm[k][i] = s_k cos(pi k (2 i + 1) / (2 n)), s_0 = sqrt(1/n), s_k = sqrt(2/n)  (orthonormal DCT-II: Cm Cm^T = I) and its transpose Ct[i][k];
 // ctab[r] = cos(pi r / (2 n)), r < 4 n, computed on the host: the argument is reduced exactly in integers
-__global__ __launch_bounds__(kBlock) void dct_matrix_kernel(int n, const double* __restrict__ ctab, double* __restrict__ Cm, double* __restrict__ Ct) {
+static __global__ __launch_bounds__(kBlock) void dct_matrix_kernel(int n, const double* __restrict__ ctab, double* __restrict__ Cm, double* __restrict__ Ct) {
     const int total = n * n;
     const double s0 = sqrt(1.0 / n), s1 = sqrt(2.0 / n);
     for (int v = blockIdx.x * kBlock + threadIdx.x; v < total; v += gridDim.x * kBlock) {
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(kBlock) void dct_matrix_kernel(int n, const double*
 }
 
 // W[c][b][a] *= 1 / (lam[a] + lam[b] + lam[c]); the constant mode (a = b = c = 0) -> 0
-__global__ __launch_bounds__(kBlock) void spectral_scale_kernel(int n, const double* __restrict__ lam, double* __restrict__ W) {
+static __global__ __launch_bounds__(kBlock) void spectral_scale_kernel(int n, const double* __restrict__ lam, double* __restrict__ W) {
     const size_t N = (size_t)n * n * n;
     for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < N; v += (size_t)gridDim.x * kBlock) {
         const int a = (int)(v % n), b = (int)((v / n) % n), c = (int)(v / ((size_t)n * n));

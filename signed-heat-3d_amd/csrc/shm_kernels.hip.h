@@ -775,7 +775,7 @@ enum Scalar : int {
 // red[] layout (the all-reduced vector): red[0] = scalar partial sum, red[1..m] = w = A r'
 
 // Sum `np` block partials into *dst (single block; fixed order -> deterministic).
-__global__ __launch_bounds__(kBlock) void finalize_sum_kernel(const double* __restrict__ partials, int np, double* __restrict__ dst) {
+static __global__ __launch_bounds__(kBlock) void finalize_sum_kernel(const double* __restrict__ partials, int np, double* __restrict__ dst) {
     __shared__ double red[8];
     double s = 0.;
     for (int a = threadIdx.x; a < np; a += kBlock) s += partials[a];
@@ -1128,7 +1128,7 @@ __global__ __launch_bounds__(kBlock) void restore_nodes_kernel(int nnodes, const
 }
 
 // y = B x for the sparse m x m matrix B = A K A^T (CSR); one thread per row
-__global__ __launch_bounds__(kBlock) void csr_matvec_kernel(int m, const int* __restrict__ ptr, const int* __restrict__ col, const double* __restrict__ val,
+static __global__ __launch_bounds__(kBlock) void csr_matvec_kernel(int m, const int* __restrict__ ptr, const int* __restrict__ col, const double* __restrict__ val,
                                                             const double* __restrict__ x, double* __restrict__ y) {
     const int r = blockIdx.x * kBlock + threadIdx.x;
     if (r >= m) return;
@@ -1154,14 +1154,14 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(size_t nown, size_t off, co
 }
 
 // init: mu = (sum b / m) 1;  (called once; sumb = all-reduced sum of b in red0)
-__global__ __launch_bounds__(kDualBlock) void dual_init_mu_kernel(int m, const double* __restrict__ sumb, double* __restrict__ mu, double* __restrict__ sc) {
+static __global__ __launch_bounds__(kDualBlock) void dual_init_mu_kernel(int m, const double* __restrict__ sumb, double* __restrict__ mu, double* __restrict__ sc) {
     const double v = *sumb / (double)m;
     for (int a = threadIdx.x; a < m; a += kDualBlock) mu[a] = v;
     if (threadIdx.x == 0) sc[SC_SUMB] = *sumb;
 }
 
 // r = Pm(g - S mu)  with Smu given;  rr0 = r.r
-__global__ __launch_bounds__(kDualBlock) void dual_init_residual_kernel(int m, const double* __restrict__ g, const double* __restrict__ Smu,
+static __global__ __launch_bounds__(kDualBlock) void dual_init_residual_kernel(int m, const double* __restrict__ g, const double* __restrict__ Smu,
                                                                         double* __restrict__ r, double* __restrict__ sc, int set_rr0 = 1) {
     __shared__ double lds[17];
     double s = 0.;
@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__(kDualBlock) void dual_init_residual_kernel(int m, c
 }
 
 // z = Pm(z);  rz_new = r.z;  init: p = z, else p = z + (rz_new/rz) p;  rz = rz_new
-__global__ __launch_bounds__(kDualBlock) void dual_direction_kernel(int m, int init, const double* __restrict__ r, double* __restrict__ z,
+static __global__ __launch_bounds__(kDualBlock) void dual_direction_kernel(int m, int init, const double* __restrict__ r, double* __restrict__ z,
                                                                     double* __restrict__ p, double* __restrict__ sc) {
     __shared__ double lds[17];
     double s = 0.;
@@ -1202,7 +1202,7 @@ __global__ __launch_bounds__(kDualBlock) void dual_direction_kernel(int m, int i
 }
 
 // Sp = Pm(Sp);  alpha = rz / (p.Sp);  mu += alpha p;  r -= alpha Sp;  rr = r.r
-__global__ __launch_bounds__(kDualBlock) void dual_update_kernel(int m, const double* __restrict__ Sp, const double* __restrict__ p, double* __restrict__ mu,
+static __global__ __launch_bounds__(kDualBlock) void dual_update_kernel(int m, const double* __restrict__ Sp, const double* __restrict__ p, double* __restrict__ mu,
                                                                  double* __restrict__ r, double* __restrict__ sc) {
     __shared__ double lds[17];
     double s = 0.;
@@ -1225,7 +1225,7 @@ __global__ __launch_bounds__(kDualBlock) void dual_update_kernel(int m, const do
 }
 
 // sum the per-slab reduction vectors of the slabs this process owns and write the result back to all of them
-__global__ __launch_bounds__(kBlock) void sum_slabs_kernel(int nslabs, double* const* __restrict__ bufs, int count) {
+static __global__ __launch_bounds__(kBlock) void sum_slabs_kernel(int nslabs, double* const* __restrict__ bufs, int count) {
     const int a = blockIdx.x * kBlock + threadIdx.x;
     if (a >= count) return;
     double s = 0.;
@@ -1234,7 +1234,7 @@ __global__ __launch_bounds__(kBlock) void sum_slabs_kernel(int nslabs, double* c
 }
 
 // dense[idx[a]] = val[a]  (non-zeros of G = A A^T, each index unique)
-__global__ __launch_bounds__(kBlock) void scatter_triplets_kernel(size_t cnt, const uint64_t* __restrict__ idx, const double* __restrict__ val,
+static __global__ __launch_bounds__(kBlock) void scatter_triplets_kernel(size_t cnt, const uint64_t* __restrict__ idx, const double* __restrict__ val,
                                                                   double* __restrict__ dense) {
     for (size_t a = (size_t)blockIdx.x * kBlock + threadIdx.x; a < cnt; a += (size_t)gridDim.x * kBlock) dense[idx[a]] = val[a];
 }
@@ -1587,7 +1587,7 @@ __device__ __forceinline__ void gj_invert64_block4(double (&r)[4][4], double* __
         }
     }
 }
-__global__ __launch_bounds__(256) void gj_pivot_block4_kernel(double* __restrict__ G, int ld, int kb, double* __restrict__ Pout, int* __restrict__ flag, int prio) {
+static __global__ __launch_bounds__(256) void gj_pivot_block4_kernel(double* __restrict__ G, int ld, int kb, double* __restrict__ Pout, int* __restrict__ flag, int prio) {
     __shared__ double lds[kGjBlock4Lds];
     if (prio) __builtin_amdgcn_s_setprio(3);   // (see gj_panels_kernel)
     const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
@@ -1607,7 +1607,7 @@ __global__ __launch_bounds__(256) void gj_pivot_block4_kernel(double* __restrict
 // step 2: R[:, b] = P * G[kb, b] and C[b, :] = G[b, kb] for every block index b, from the block-lower triangle:
 //   X = stored block (b >= kb ? G[b,kb] : G[kb,b]);   b > kb: G[kb,b] = X^T, G[b,kb] = X;   b < kb: G[kb,b] = X, G[b,kb] = -X^T.
 typedef double gj_f64x4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(kBlock) void gj_panels_kernel(const double* __restrict__ G_, int ld, int kb, const double* __restrict__ P_,
+static __global__ __launch_bounds__(kBlock) void gj_panels_kernel(const double* __restrict__ G_, int ld, int kb, const double* __restrict__ P_,
                                                            double* __restrict__ R_ /* [..][ld]: rows r_row0 .. r_row0+63 */, int r_row0,
                                                            double* __restrict__ C_ /* [ld][c_ld]: columns c_col0 .. c_col0+63 */, int c_ld, int c_col0, int prio,
                                                            GjBatch Bt = GjBatch{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}) {
@@ -1825,7 +1825,7 @@ __global__ __launch_bounds__(kBlock) void gj_update_kernel(double* __restrict__ 
 #endif
 constexpr int kGjStepScratch = 8 * (kGJ + 1);
 constexpr int kGjStepLds = kGJ * (kGJ + 1) + kGjStepScratch;
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_GJ_STEP_WAVES, SHM_GJ_STEP_WAVES))) void gj_step_kernel(
+static __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_GJ_STEP_WAVES, SHM_GJ_STEP_WAVES))) void gj_step_kernel(
     double* __restrict__ G, int ld, int nb, int k, const double* __restrict__ Rp /* [64][ld] of step k-1 */, const double* __restrict__ Cp /* [ld][64] */,
     double* __restrict__ Rn, double* __restrict__ Cn, int* __restrict__ flag, int prio) {
     __shared__ double smem[kGjStepLds];
@@ -1984,7 +1984,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_GJ_S
 }
 
 // after the last pivot block: G[bj, bi] = G[bi, bj]^T for bi > bj (the inverse is symmetric; only its block-lower triangle was kept)
-__global__ __launch_bounds__(kBlock) void gj_mirror_kernel(double* __restrict__ G_, int ld, GjBatch Bt = GjBatch{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}) {
+static __global__ __launch_bounds__(kBlock) void gj_mirror_kernel(double* __restrict__ G_, int ld, GjBatch Bt = GjBatch{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}) {
     __shared__ double x[kGJ][kGJ + 1];
     double* G = G_;
     if (Bt.D) {

@@ -24,7 +24,7 @@ namespace shm {
 // W0[k1][k2][k3] = gamma gamma gamma / lambda_k  (0 for k = 0);  lam1[k] = (2 - 2 cos(pi k / n)) / h^2 is the table the transforms use.
 // One (k1, k2) row of n entries per workgroup step, k3 across the threads: no 64-bit division by n per element (rounds 2-4 took 0.43 ms at 256^3 for 134 MB of
 // output -- and that much of the vector pipes away from the Step-1 waves it runs beside).  The quotient itself is an IEEE division, as before.
-__global__ __launch_bounds__(kBlock) void green_symbol_kernel(int n, const double* __restrict__ lam1, double* __restrict__ W0) {
+static __global__ __launch_bounds__(kBlock) void green_symbol_kernel(int n, const double* __restrict__ lam1, double* __restrict__ W0) {
     const double g0 = 0.5 / n, g1 = 1.0 / n;
     for (int row = blockIdx.x; row < n * n; row += gridDim.x) {
         const int k1 = row / n, k2 = row - k1 * n;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kBlock) void green_symbol_kernel(int n, const doubl
 
 // Cm[d][k] = cos(pi k d / n)  ((n + 1) x n, leading dimension n)  and  Ct[k][d]  (n x (n + 1), leading dimension P) from the 2n values
 // ctab[r] = cos(pi r / n): the argument is reduced exactly in integers
-__global__ __launch_bounds__(kBlock) void cosine_tables_kernel(int n, int P, const double* __restrict__ ctab, double* __restrict__ Cm, double* __restrict__ Ct) {
+static __global__ __launch_bounds__(kBlock) void cosine_tables_kernel(int n, int P, const double* __restrict__ ctab, double* __restrict__ Cm, double* __restrict__ Ct) {
     const int total = (n + 1) * n;
     for (int v = blockIdx.x * kBlock + threadIdx.x; v < total; v += gridDim.x * kBlock) {
         const int d = v / n, k = v - d * n;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WN == 4 
 // tiles below the diagonal are left to their mirror images.
 __device__ __forceinline__ int schur_fold(int e, int n) { return e <= n ? e : 2 * n - e; }
 typedef double schur_f64x2 __attribute__((ext_vector_type(2), aligned(8)));
-__global__ __launch_bounds__(kBlock) void schur_assemble_kernel(int m, int ld, int n, int P, const int* __restrict__ rowX /* [m][4]: cell i, j, k and the row index, in Morton order of the cells */,
+static __global__ __launch_bounds__(kBlock) void schur_assemble_kernel(int m, int ld, int n, int P, const int* __restrict__ rowX /* [m][4]: cell i, j, k and the row index, in Morton order of the cells */,
                                                                 const double* __restrict__ rowT /* [m][3] */, const double* __restrict__ T, double* __restrict__ S, int prio) {
     if (blockIdx.x < blockIdx.y) return;
     if (prio) __builtin_amdgcn_s_setprio(3);   // runs on the SIMDs Step 1 occupies (see gj_panels_kernel)
@@ -231,14 +231,14 @@ __global__ __launch_bounds__(kBlock) void schur_assemble_kernel(int m, int ld, i
 }
 
 // M[i][i] = v for i in [i0, i1)  (identity tail of a padded SPD matrix)
-__global__ __launch_bounds__(kBlock) void set_diagonal_kernel(double* __restrict__ M, int ld, int i0, int i1, double v) {
+static __global__ __launch_bounds__(kBlock) void set_diagonal_kernel(double* __restrict__ M, int ld, int i0, int i1, double v) {
     const int i = i0 + blockIdx.x * kBlock + threadIdx.x;
     if (i < i1) M[(size_t)i * ld + i] = v;
 }
 
 // Direct dual solve, bordered system [[S, 1], [1^T, 0]] [mu; c] = [rhs; sigma]:  with u = S^-1 rhs and v = S^-1 1,  c = (1^T u - sigma) / (1^T v),
 // mu (+)= u - c v.  sigma = *sigma_ptr (nullptr: 0).  One workgroup.
-__global__ __launch_bounds__(kDualBlock) void dual_bordered_kernel(int m, const double* __restrict__ u, const double* __restrict__ v, const double* __restrict__ sigma_ptr,
+static __global__ __launch_bounds__(kDualBlock) void dual_bordered_kernel(int m, const double* __restrict__ u, const double* __restrict__ v, const double* __restrict__ sigma_ptr,
                                                                   int accumulate, double* __restrict__ mu) {
     __shared__ double lds[17];
     double su = 0., sv = 0.;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(kDualBlock) void dual_bordered_kernel(int m, const 
     for (int a = threadIdx.x; a < m; a += kDualBlock) mu[a] = (accumulate ? mu[a] : 0.) + u[a] - c * v[a];
 }
 
-__global__ __launch_bounds__(kBlock) void fill_kernel(double* __restrict__ x, int count, double v) {
+static __global__ __launch_bounds__(kBlock) void fill_kernel(double* __restrict__ x, int count, double v) {
     const int a = blockIdx.x * kBlock + threadIdx.x;
     if (a < count) x[a] = v;
 }

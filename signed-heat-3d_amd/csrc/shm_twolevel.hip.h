@@ -42,7 +42,7 @@ __host__ __device__ __forceinline__ int tl_ld(int s) { return (s + 63) / 64 * 64
 
 // T_a = D_a^-1 E_a for all boxes: a workgroup per (box, 16 rows of T), a wave per 4 rows, lanes = consecutive columns (coalesced rows of E)
 constexpr int kTlRowsPerWg = 16;
-__global__ __launch_bounds__(kBlock) void tl_T_kernel(TlBoxes B, const int* __restrict__ chunkBox, const int* __restrict__ chunkRow, const double* __restrict__ Dinv,
+static __global__ __launch_bounds__(kBlock) void tl_T_kernel(TlBoxes B, const int* __restrict__ chunkBox, const int* __restrict__ chunkRow, const double* __restrict__ Dinv,
                                                       const double* __restrict__ E, double* __restrict__ Tm, int prio) {
     if (prio) __builtin_amdgcn_s_setprio(3);   // beside the tiered Step 1 (see gj_panels_kernel)
     const int a = chunkBox[blockIdx.x], r0 = chunkRow[blockIdx.x];
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kBlock) void tl_T_kernel(TlBoxes B, const int* __re
 
 // S[Sigma_a, Sigma_a] -= E_a^T T_a for the boxes of one colour (disjoint separator rows: plain read-modify-write): a workgroup per (box, 16 rows p of the
 // update), a wave per 4 rows, lanes = consecutive columns q
-__global__ __launch_bounds__(kBlock) void tl_schur_kernel(TlBoxes B, const int* __restrict__ chunkBox, const int* __restrict__ chunkRow, const double* __restrict__ E,
+static __global__ __launch_bounds__(kBlock) void tl_schur_kernel(TlBoxes B, const int* __restrict__ chunkBox, const int* __restrict__ chunkRow, const double* __restrict__ E,
                                                           const double* __restrict__ Tm, double* __restrict__ S, int ldS, int prio) {
     if (prio) __builtin_amdgcn_s_setprio(3);
     const int a = chunkBox[blockIdx.x], p0 = chunkRow[blockIdx.x];
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kBlock) void tl_sep_matvec_kernel(int nS, int ld, c
 }
 
 // step 2: v_S = w_S - E^T t, gathered per separator row from the boxes that border it (fixed order); the padded tail stays 0
-__global__ __launch_bounds__(kBlock) void tl_gather_sep_kernel(int nS, const int* __restrict__ sepRow, const int* __restrict__ adj_ptr, const int* __restrict__ adj_idx,
+static __global__ __launch_bounds__(kBlock) void tl_gather_sep_kernel(int nS, const int* __restrict__ sepRow, const int* __restrict__ adj_ptr, const int* __restrict__ adj_idx,
                                                                const double* __restrict__ w, const double* __restrict__ ybuf, double* __restrict__ vS) {
     const int g = blockIdx.x * kBlock + threadIdx.x;
     if (g >= nS) return;

@@ -9,7 +9,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 # The library reads its experiment knobs (SHM_CONV_EXACT, SHM_DUAL_NO_DIRECT, SHM_GJ_CLASSIC, ... : alternative forms the tests hold against each other) only when
-# this is set; a product run never sees them (csrc/shm_grid.hip `knob`).  Test processes and the children they spawn inherit it.
+# this is set; a product run never sees them (csrc/shm_host.hip.h `knob`).  Test processes and the children they spawn inherit it.
 os.environ.setdefault("SHM_DEBUG_KNOBS", "1")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
