@@ -504,7 +504,7 @@ def main():
         traffic = None
         # HBM bytes per launch from the rocprofv3 PMC passes of THIS command (tools/pmc_traffic.py; FETCH_SIZE doubled per the gfx950
         # correction), committed per round; PMC counters cannot be collected from inside the run
-        tfile = next((f for f in (os.path.join(ROOT, "profiles", "r05_pmc_traffic.json"), os.path.join(ROOT, "profiles", "r04_pmc_traffic.json"))
+        tfile = next((f for f in (os.path.join(ROOT, "profiles", "r06_pmc_traffic.json"), os.path.join(ROOT, "profiles", "r05_pmc_traffic.json"))
                       if os.path.exists(f)), "")
         if os.path.exists(tfile):
             try:
@@ -568,7 +568,7 @@ def main():
             out["roofline"] = {"kernel": s1["kernel"], "bound": "valu",
                                "bound_detail": "compute: vector-ALU issue (no matrix-core shape in the kernel, no MFMA instruction); peak = the vector peaks of the two "
                                                "arithmetic tiers (78.6 TFLOP/s fp64, 157.3 TFLOP/s fp32) weighted by the pairs each tier evaluated; SQ counters of this "
-                                               "kernel: profiles/r05_sq_counters_conv.txt",
+                                               "kernel: profiles/r06_sq_counters_conv.txt",
                                "achieved": s1["achieved_TFLOPs_18_per_evaluated_pair"], "peak": s1["peak_TFLOPs_weighted"], "unit": "TFLOP/s", "frac": s1["frac"],
                                "traffic": conv_traffic,
                                "note": "%d launch(es) per step, duration = phases_ms.ms_conv (HIP events on the solver's stream around all of them); achieved = 18 nominal "

@@ -108,7 +108,7 @@ typedef struct {
  * AUTO:          chosen per problem (DESIGN.md section 4b'): the direct solve where the inverse of S hides behind Step 1, else CG on the explicit S or through the grid.
  * DIRECT:        S = A K^+ A^T assembled from the image-sum Green's table and INVERTED beside Step 1; the solve is two dense mat-vecs + refinement passes.
  *                Applies for m <= 16384 rows and n <= 512, on one z-slab or -- round 6 -- on a power-of-two number of equal z-slabs with n a power of two (S and S^-1 are
- *                then replicated on every rank and K^+ runs on the slabs: SHM_SOLVER_DUAL_SLABS, and what AUTO picks for 256 <= n <= 512 with S <= 16384 sources);
+ *                then replicated on every rank and K^+ runs on the slabs: SHM_SOLVER_DUAL_SLABS, and what AUTO picks on four or more ranks for 256 <= n <= 512 with S <= 16384 sources);
  *                elsewhere the request falls back to AUTO's choice.
  * EXPLICIT_S_CG: S assembled, CG on it (one dense mat-vec per iteration), preconditioned by (A A^T)^-1 (A K A^T) (A A^T)^-1.
  * THROUGH_GRID:  CG with S applied through the grid (scatter, five transform sweeps, gather per iteration); no m x m matrix is formed.

@@ -3246,10 +3246,12 @@ struct Solver final : SolverBase {
             solve_fast(o, st, e_start, e_conv, e_div, wall0);
             return;
         }
-        // Several ranks.  Round 6: where S fits (S <= 16384 sources bound the rows) and the grid is one of the sizes BASELINE.json names (256^3 ... 512^3, equal power-of-two
-        // slabs), AUTO takes the slab-distributed explicit-S forms of solve_dual -- S and its inverse replicated beside every rank's Step 1, K^+ on the slabs: no gather of
+        // Several ranks.  Round 6: where S fits (S <= 16384 sources bound the rows) and the grid is one of the sizes BASELINE.json names (256^3 ... 512^3, four or more equal
+        // power-of-two slabs), AUTO takes the slab-distributed explicit-S forms of solve_dual -- S and its inverse replicated beside every rank's Step 1, K^+ on the slabs: no gather of
         // D^T Y, no whole-grid solve per rank.  Everything else (larger constraint sets, 1024^3, odd sizes, weighted plans; SHM_SOLVER_DUAL) keeps the gathered solve.
-        const bool slab_forms_auto = full_wanted() && o.solver == SHM_SOLVER_AUTO && o.preconditioner != SHM_PRECOND_NONE && fft_available() && n >= 256 && n <= 512 && S <= 16384 &&
+        // (from four ranks on: with two, each all-to-all crosses ONE xGMI link with a quarter of the grid, four times per solve, where the gather crosses it once with half --
+        // tools/scaling_model.py, link constants assumed: 115 against 107 ms at 512^3 on two ranks, 54 against 58 on four, 30 against 36 on eight)
+        const bool slab_forms_auto = full_wanted() && o.solver == SHM_SOLVER_AUTO && o.preconditioner != SHM_PRECOND_NONE && fft_available() && total_slabs >= 4 && n >= 256 && n <= 512 && S <= 16384 &&
                                      o.dual_form != SHM_DUAL_THROUGH_GRID && knob("SHM_MULTI_GATHERED") == nullptr;
         if (full_wanted() && !slab_forms_auto && (o.solver == SHM_SOLVER_AUTO || o.solver == SHM_SOLVER_DUAL) && o.preconditioner != SHM_PRECOND_NONE) {
             ensure_full();

@@ -216,7 +216,10 @@ Y_BUDGET_F32 = 2e-3   # fp32 kernel: every pair in fp32 (relative error ~1e-5 pe
 # tools/tier_worst_nodes.py on the round-3 kernel (profiles/r04_tier_worst_nodes.txt).  These planes come first; the centre / quarter / bbox planes follow while the
 # oracle's time budget lasts.  (knot 512^3: the 256^3 planes doubled; SprayBottle 1024^3: its worst nodes sit on the centre plane, a second plane 32 below it.)
 STEP1_WORST_PLANES = {("rocker.obj", 5.0): [272, 224, 304], ("chair.obj", 5.0): [240, 256], ("knot.obj", 4.0): [120, 128, 104], ("knot.obj", 5.0): [240, 256, 208],
-                      ("bunny_small.obj", 4.0): [136, 56], ("SprayBottle.pc", 6.0): [512, 480]}
+                      ("bunny_small.obj", 4.0): [136, 56],
+                      # (round 6, on the final kernel -- profiles/r06_tier_robustness_big.txt: k = 512 8.1e-9, 480 7.9e-9, then 1023 5.1e-9 -- the bbox plane, whose corners lie beyond
+                      # lambda r = 350 where the reference's own normalisation is noise, DESIGN.md section 2a -- and 448 5.0e-9: the third oracle plane)
+                      ("SprayBottle.pc", 6.0): [512, 480, 448]}
 
 
 def _oracle_planes(oracle_c, pre, ks):
@@ -251,7 +254,7 @@ def test_step1_full_size_against_c_oracle(shm, oracle_c, fname, hCoef, precision
     for k in STEP1_WORST_PLANES.get((fname, hCoef), []) + [n // 2, n // 4, 0, n - 1]:   # medial-axis planes, then centre, quarter, the planes through the bbox corners
         if k not in want:
             want.append(k)
-    ks = want[:max(1, min(len(want), int(100.0 / max(per_plane_s, 1e-3))))]
+    ks = want[:max(1, min(len(want), int(120.0 / max(per_plane_s, 1e-3))))]   # (120 s: three planes of SprayBottle.pc at 1024^3 on the 256-thread host)
     t0 = time.time()
     ref = _oracle_planes(oracle_c, pre, ks)
     t_or = time.time() - t0

@@ -5,10 +5,14 @@ all launches of a kernel inside one solve, and the launch count is printed besid
   r05_sq_counters_conv.txt  SQ / GRBM counters of the Step-1 kernel of one solve (VALU issue, LDS, effective clock), with the executed pairs of that solve
     python tools/pmc_report.py <dir with the *_results.db> <out dir> [executed_pairs_fp64 executed_pairs_fp32]"""
 import json
+import os
 import re
 import sqlite3
 import sys
 from collections import defaultdict
+
+
+TAG = os.environ.get("SHM_PROFILE_TAG", "r06")   # round tag of the files written (profiles/<tag>_pmc_traffic.json, <tag>_sq_counters_conv.txt)
 
 
 def per_kernel(db, counter):
@@ -98,7 +102,7 @@ if __name__ == "__main__":
                                                                      for k, v in t.items() if k.startswith("cg_")}
         except Exception as e:
             res["per_kernel_" + tag] = {"failed": repr(e)}
-    json.dump(res, open(out + "/r05_pmc_traffic.json", "w"), indent=1)
+    json.dump(res, open(out + "/" + TAG + "_pmc_traffic.json", "w"), indent=1)
     # ---- SQ counters of the Step-1 kernel, per step
     lines = ["SQ / GRBM counters of the Step-1 kernel ALONE (tools/conv_only.py: 2 x shm_grid_run_conv on bunny_small 256^3 fp64, no set-up kernels on the device).",
              "Two passes (SQ has 8 counter slots).  Every counter is the sum over all SEs / XCDs, PER STEP (= per Step 1: the sum over the run's launches divided by the",
@@ -145,6 +149,6 @@ if __name__ == "__main__":
         lines.append("  LDS bank-conflict cycles per LDS instruction = %.3f" % (vals["SQ_LDS_BANK_CONFLICT"] / max(vals["SQ_INSTS_LDS"], 1)))
     if "SQ_WAIT_INST_ANY" in vals and "SQ_WAVE_CYCLES" in vals:
         lines.append("  SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES = %.3f" % (vals["SQ_WAIT_INST_ANY"] / max(vals["SQ_WAVE_CYCLES"], 1)))
-    open(out + "/r05_sq_counters_conv.txt", "w").write("\n".join(lines) + "\n")
+    open(out + "/" + TAG + "_sq_counters_conv.txt", "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
     print(json.dumps(res["bunny_small_256_f64"], indent=1))

@@ -27,10 +27,10 @@ LINKS = 7                # hardware: xGMI links per GPU
 P2P_LAT_US = 15.0        # ASSUMED: one grouped ncclSend/ncclRecv pair on an idle stream
 ALLREDUCE_LAT_US = 20.0  # ASSUMED: small (<= 400 KB) all-reduce over 8 ranks
 SETUP_GJ_US_PER_STEP = 40.0  # MEASURED (profiles/r04_gj_step.txt, idle-GPU launches of gj_step_kernel: one launch per 64-row pivot block; rounds 1-3: 80 us in three launches)
-# MEASURED (profiles/r05_setup_alone.txt, tools/setup_alone.py): constraint set-up wall time in ms, (alone on an idle GPU, beside Step 1), by constraint rows m.
+# MEASURED (profiles/r06_setup_alone.txt, tools/setup_alone.py): constraint set-up wall time in ms, (alone on an idle GPU, beside Step 1), by constraint rows m.
 # The two 512^3 "beside" figures are round 3's (raised wave priority, which is what a rank with an eighth of Step 1 runs with: Solver::setup_prio) scaled by the
 # ratio of the "alone" times; the round-4 file has them at the low priority a 200 ms Step 1 selects (58.7 / 51.0 ms, hidden all the same).
-SETUP_MS = {1129: (1.27, 1.34), 2496: (2.92, 3.63), 2842: (3.89, 6.05), 2856: (9.26, 32.77), 1430: (5.59, 24.03), 12612: (38.78, 45.84), 48893: (145.0, None)}   # round 5: profiles/r05_setup_alone.txt (SprayBottle: round 4)
+SETUP_MS = {1129: (1.17, 1.51), 2496: (2.73, 3.47), 2842: (3.95, 6.48), 2856: (9.32, 33.30), 1430: (5.45, 25.07), 12612: (36.27, 51.56), 48893: (145.0, None)}   # round 6: profiles/r06_setup_alone.txt (SprayBottle: round 4)
 # MEASURED (profiles/r03_slab_plan_check*.txt, tools/slab_plan_check.py): max / mean of the slabs' own Step-1 times, by workload and slab count;
 # fp32 culled workloads with the weighted plan (shm_config.slab_plan = SHM_SLAB_PLAN_STEP1), the others with equal planes
 IMBALANCE = {"bunny_small_256_f64": {4: 1.04, 8: 1.09}, "bunny_small_512_f64": {4: 1.03, 8: 1.10}, "bunny_pc_512_f64": {4: 1.05, 8: 1.12},

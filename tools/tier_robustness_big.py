@@ -49,6 +49,10 @@ for f, hc in CASES:
     fin = np.isfinite(pe) & np.isfinite(pt)
     dphi = float(np.abs(pt[fin] - pe[fin]).max()) if fin.any() else float("nan")
     worst = max(worst, dY)
+    if ok.any():   # the planes that carry the largest differences (round 6: candidates for the oracle planes of tests/test_gpu_parity.py::STEP1_WORST_PLANES)
+        per_plane = [float(np.abs(np.where(ok[a][:, None], Yt[a] - Ye[a], 0.0)).max()) for a in range(len(ks))]
+        top = sorted(range(len(ks)), key=lambda a: -per_plane[a])[:5]
+        print("    worst planes: " + ", ".join("k=%d %.2e" % (ks[a], per_plane[a]) for a in top), flush=True)
     print("%-16s n=%4d S=%5d  pairs fp64 %.3f fp32 %.3f redone %.4f dropped %.3f  Step 1 %.0f ms (all-fp64 %.0f)  max|dY| %.2e  max|dphi| %.2e (max|phi| %.2f)  "
           "non-finite Y nodes %d / %d%s  [%d planes]" % (
               f, n, pre["S"], stt.pairs_fp64 / nom, stt.pairs_fp32 / nom, stt.pairs_redone / nom, max(0.0, 1.0 - (stt.pairs_fp64 + stt.pairs_fp32 - stt.pairs_redone) / nom), stt.ms_conv, ste.ms_conv, dY, dphi,
