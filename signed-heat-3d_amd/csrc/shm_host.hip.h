@@ -279,6 +279,97 @@ static double drop_rule_K(int64_t S, const double* wn, double lambda) {
     return std::min(std::max(64.0, (double)S), std::max(64.0, k_est));
 }
 
+// K of the drop rule chosen per problem on a sample of blocks (round 6, late): the formula above is within a factor of three of the best K and that factor is worth 3 % of Step 1
+// on the culled configurations (measured, SHM_CONV_DROP_K: rocker 512^3 fp32 254 ms at K = 350 against 262 at the formula's 1066; SprayBottle.pc 512^3 fp32 283 at 700 ... 1400
+// against 307 at 350).  The host walks up to 48 blocks spread over the grid through the kernel's own scan -- clusters in storage order, 64 at a time, then the sources of the kept
+// ones, candidates of a batch / cluster together or only the ones below the hard threshold -- for a ladder of K and keeps the K that drops most.  Deterministic (every rank
+// derives the same K from the same sources); (samples x sources) <= 1.5e6: a few ms, only for S >= 4096.  src6: the sources as the kernel gets them (Morton order, grid-centred
+// positions, UNscaled weights, padded with zero weights to whole clusters of 64); cl: their cluster records (centre, radius, ln largest weight, ln weight sum).
+static double choose_drop_K(const double* src6, int n_clusters, const float* cl, int rec, double lambda, int n, double cell, double eps, int64_t S_true, double k_formula) {
+    if (!(eps > 0.) || S_true < 4096 || n_clusters < 1) return k_formula;
+    const int64_t Sp = (int64_t)n_clusters * 64;
+    static const double fx[4] = {0.10, 0.37, 0.63, 0.90}, fz[3] = {0.15, 0.50, 0.85};
+    const int want = (int)std::max<int64_t>(8, std::min<int64_t>(48, 1500000 / std::max<int64_t>(1, Sp)));
+    const double ladder[] = {128., 192., 256., 384., 512., 768., 1024., 1536., 2048., 4096.};
+    constexpr int NK = sizeof(ladder) / sizeof(ladder[0]);
+    double dropped[NK] = {0};
+    const double hx = 3.5 * cell, hy = 3.5 * cell, hz = 1.5 * cell, rt = std::sqrt(hx * hx + hy * hy + hz * hz), half = 0.5 * (double)(n - 1) * cell;
+    const double eps_soft = 0.875 * eps, lhard = std::log(0.125 * eps / (double)S_true);
+    std::vector<double> lb((size_t)Sp), bs((size_t)Sp), lbmax((size_t)n_clusters), bc((size_t)n_clusters);
+    std::vector<char> cand_ok((size_t)n_clusters);
+    int done = 0;
+    for (int a = 0; a < 4 && done < want; a++)
+        for (int b = 0; b < 4 && done < want; b++)
+            for (int c3 = 0; c3 < 3 && done < want; c3++, done++) {
+                // (a different pairing of the lattice coordinates per sample index, so that fewer than 48 samples still spread over the grid)
+                const double c[3] = {(2. * fx[(a + c3) & 3] - 1.) * half, (2. * fx[(b + 2 * c3) & 3] - 1.) * half, (2. * fz[c3] - 1.) * half};
+                double dmin = 1e300, wstar = 0., nstar[3] = {0, 0, 0};
+                for (int64_t t = 0; t < Sp; t++) {
+                    const double* q = src6 + 6 * t;
+                    const double w = std::sqrt(q[3] * q[3] + q[4] * q[4] + q[5] * q[5]);
+                    if (!(w > 0.)) continue;
+                    const double dx = c[0] - q[0], dy = c[1] - q[1], dz = c[2] - q[2], d = std::sqrt(dx * dx + dy * dy + dz * dz);
+                    if (d < dmin || (d == dmin && w > wstar)) {
+                        dmin = d; wstar = w; nstar[0] = dx; nstar[1] = dy; nstar[2] = dz;
+                    }
+                }
+                if (!(wstar > 0.)) continue;
+                const double r_hi = std::sqrt((std::fabs(nstar[0]) + hx) * (std::fabs(nstar[0]) + hx) + (std::fabs(nstar[1]) + hy) * (std::fabs(nstar[1]) + hy) +
+                                              (std::fabs(nstar[2]) + hz) * (std::fabs(nstar[2]) + hz));
+                const double bxs = std::max(std::fabs(nstar[0]) - hx, 0.), bys = std::max(std::fabs(nstar[1]) - hy, 0.), bzs = std::max(std::fabs(nstar[2]) - hz, 0.);
+                const double dbs = std::sqrt(bxs * bxs + bys * bys + bzs * bzs), inv_dstar = dmin > 0. && dbs > 0. ? 1. / dbs : 1e300, lwstar = std::log(wstar);
+                for (int64_t t = 0; t < Sp; t++) {
+                    const double* q = src6 + 6 * t;
+                    const double w = std::sqrt(q[3] * q[3] + q[4] * q[4] + q[5] * q[5]);
+                    if (!(w > 0.)) { lb[(size_t)t] = 1e300; bs[(size_t)t] = 0.; continue; }
+                    const double ex = c[0] - q[0], ey = c[1] - q[1], ez = c[2] - q[2];
+                    const double bx = std::max(std::fabs(ex) - hx, 0.), by = std::max(std::fabs(ey) - hy, 0.), bz = std::max(std::fabs(ez) - hz, 0.);
+                    const double dist = std::sqrt(bx * bx + by * by + bz * bz), dc = std::sqrt(ex * ex + ey * ey + ez * ez);
+                    const double dot = dc > 0. && dmin > 0. ? (ex * nstar[0] + ey * nstar[1] + ez * nstar[2]) / (dc * dmin) : 1.;
+                    const double lip = std::sqrt(std::max(0., 2. - 2. * dot)) + rt * ((dist > 0. ? 1. / dist : 1e300) + inv_dstar);
+                    const double gap = std::max(dist - r_hi, dc - dmin - rt * lip);
+                    lb[(size_t)t] = std::log(w) - lwstar - lambda * gap;
+                    bs[(size_t)t] = dist > 0. ? std::exp(lb[(size_t)t]) * r_hi / dist : 1e300;
+                }
+                for (int k = 0; k < n_clusters; k++) {
+                    const float* r = cl + (size_t)k * rec;
+                    const double gx = c[0] - r[0], gy = c[1] - r[1], gz = c[2] - r[2], gap = std::sqrt(gx * gx + gy * gy + gz * gz) - rt - r[3] - r_hi;
+                    cand_ok[(size_t)k] = gap > 0.;
+                    lbmax[(size_t)k] = (double)r[4] - lwstar - lambda * gap;
+                    bc[(size_t)k] = gap > 0. ? std::exp((double)r[5] - lwstar - lambda * gap) * r_hi / (r_hi + gap) : 1e300;
+                }
+                for (int ki = 0; ki < NK; ki++) {
+                    const double ltau = std::log(eps_soft / ladder[ki]);
+                    double R = 0.;
+                    int64_t nd = 0;
+                    for (int k0 = 0; k0 < n_clusters; k0 += 64) {
+                        const int k1 = std::min(n_clusters, k0 + 64);
+                        double sum = 0.;
+                        for (int k = k0; k < k1; k++)
+                            if (cand_ok[(size_t)k] && lbmax[(size_t)k] <= ltau) sum += bc[(size_t)k];
+                        const bool all = R + sum <= eps_soft;
+                        if (all) R += sum;
+                        for (int k = k0; k < k1; k++) {
+                            const bool cd = cand_ok[(size_t)k] && lbmax[(size_t)k] <= (all ? ltau : std::min(ltau, lhard));
+                            if (cd) { nd += 64; continue; }
+                            double ssum = 0.;
+                            for (int64_t t = (int64_t)k * 64; t < (int64_t)(k + 1) * 64; t++)
+                                if (lb[(size_t)t] <= ltau) ssum += bs[(size_t)t];
+                            const bool sall = R + ssum <= eps_soft;
+                            if (sall) R += ssum;
+                            for (int64_t t = (int64_t)k * 64; t < (int64_t)(k + 1) * 64; t++)
+                                if (lb[(size_t)t] <= (sall ? ltau : std::min(ltau, lhard))) nd++;
+                        }
+                    }
+                    dropped[ki] += (double)nd;
+                }
+            }
+    int best = -1;
+    for (int ki = 0; ki < NK; ki++)
+        if (dropped[ki] > 0. && (best < 0 || dropped[ki] > dropped[best] * 1.002)) best = ki;   // (ties and near-ties: the smaller K)
+    return best < 0 ? k_formula : std::min(std::max(64.0, (double)S_true), ladder[best]);
+}
+
 static void step1_plane_weights_host(int64_t S, const double* pos, const double* wn, double lambda, int n, const double* bbox_min, double cell, int precision,
                                      double tier_log, double* weights, bool tiered32 = false) {
     const bool per_source = precision == SHM_F64 || tiered32;   // the tiered kernel's classification: per (8 x 8 x 4 block, source)

@@ -395,21 +395,7 @@ struct Solver final : SolverBase {
                 // that leaves the sum room (tools/r06_drop_sim.py: rocker 512^3 keeps 0.52-0.53 of its pairs for K = 512 ... 1024, 0.62 for K = 256, where the sum binds).
                 conv_drop_eps64 = sk ? 0. : (db ? atof(db) : 2e-9);
                 conv_drop_eps32 = sk ? 0. : (db32 ? atof(db32) : 6.0e-8);
-                {
-                    double wsum = 0.;
-                    int64_t nz = 0;
-                    for (int64_t t = 0; t < S; t++) {
-                        const double w = std::sqrt(h_wn[3 * t] * h_wn[3 * t] + h_wn[3 * t + 1] * h_wn[3 * t + 1] + h_wn[3 * t + 2] * h_wn[3 * t + 2]);
-                        if (w > 0. && std::isfinite(w)) {
-                            wsum += w;
-                            nz++;
-                        }
-                    }
-                    const double abar = nz ? wsum / (double)nz : 0.;
-                    const char* dk = knob("SHM_CONV_DROP_K");   // experiment knob
-                    const double k_est = abar > 0. ? 3.0 * 157.0 / (abar * lambda * lambda) : 64.;
-                    conv_drop_K = dk ? atof(dk) : std::min(std::max(64.0, (double)S), std::max(64.0, k_est));
-                }
+                conv_drop_K = knob("SHM_CONV_DROP_K") ? atof(knob("SHM_CONV_DROP_K")) : drop_rule_K(S, h_wn.data(), lambda);   // (the formula; refined on a sample of blocks below)
                 select_step1_arith(SHM_STEP1_AUTO);
             }
             d_src.upload(packed, stream);
@@ -441,6 +427,10 @@ struct Solver final : SolverBase {
                 }
             }
             d_clusters.upload(cl, stream);
+            if constexpr (sizeof(T) == 8) {   // (fp64 solve: the tiered kernel reads these very records -- clusters of 64, unscaled weights)
+                if (!solve_only && knob("SHM_CONV_DROP_K") == nullptr && knob("SHM_CONV_DROP_K_FORMULA") == nullptr)
+                    conv_drop_K = choose_drop_K(reinterpret_cast<const double*>(packed.data()), n_clusters, cl.data(), kConvClusterRec, lambda, n, cell, conv_drop_eps64, S, conv_drop_K);
+            }
             if constexpr (sizeof(T) == 4) {
                 // fp32 solve through the tiered kernel (conv_tiered_kernel<NPT, float, false>): it stages fp64 source records in clusters of 64 and scales the weights itself
                 n_clusters_t = (int)((S + kTierCluster - 1) / kTierCluster);
@@ -474,6 +464,8 @@ struct Solver final : SolverBase {
                     clt[kConvClusterRec * (size_t)c + 4] = wmax2 > 0. ? (float)(0.5 * std::log(wmax2) + 1e-5) : -1.0e30f;
                     clt[kConvClusterRec * (size_t)c + 5] = wsum > 0. ? (float)(std::log(wsum) + 1e-5) : -1.0e30f;
                 }
+                if (!solve_only && knob("SHM_CONV_DROP_K") == nullptr && knob("SHM_CONV_DROP_K_FORMULA") == nullptr)
+                    conv_drop_K = choose_drop_K(pk.data(), n_clusters_t, clt.data(), kConvClusterRec, lambda, n, cell, conv_drop_eps32, S, conv_drop_K);
                 d_src_t.upload(pk, stream);
                 d_clusters_t.upload(clt, stream);
             }
