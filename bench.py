@@ -306,15 +306,16 @@ def also_legs(shm, HostSolver, device, tol, pre256, scrub256):
     return out
 
 
-def multi_gpu_legs(shm, HostSolver, dist, torch, args, pre, precision, scrub, rank, world, local_rank, barrier):
+def multi_gpu_legs(shm, HostSolver, dist, torch, args, pre, precision, scrub, rank, world, local_rank, barrier, out=None):
     """N > 1 only.  The timed default above is the library's AUTO: since round 6 the slab-distributed explicit-S dual solve where it applies (256^3 ... 512^3, S <= 16384:
     S and S^-1 replicated beside every rank's Step 1, K^+ on the z-slabs), the gathered dual solve elsewhere (Steps 1-2 on z-slabs, D^T Y gathered, whole-grid solve
     replicated) -- which also runs here as the leg "gathered_dual" for the comparison.  BASELINE.json's own multi-GPU configurations come first.  The split the
     north star names -- z-slab stencil PCG with a one-plane halo exchange per sweep and an all-reduce per dot product -- is SHM_SOLVER_PRIMAL; it is
     run here as further legs on the SAME ranks so that whichever multi-GPU run the driver gets covers both: the DCT-preconditioned stencil PCG to the
     tolerance (z-slab transforms: two all-to-alls per application) and the plain stencil CG for a fixed 200 iterations (halo + two all-reduces per
-    iteration, nothing else).  Collective: every rank calls this with the same arguments."""
-    out = {}
+    iteration, nothing else).  Collective: every rank calls this with the same arguments.  `out` is filled leg by leg: should a later leg hang, the watchdog of main()
+    prints what the earlier ones measured."""
+    out = {} if out is None else out
     # BASELINE.json's own multi-GPU configurations, end to end with the library defaults on the SAME ranks: configs[3] (bunny.pc 512^3 fp64) and configs[4]
     # (SprayBottle.pc 1024^3 fp32, z-slabs weighted by the Step-1 work the source culling leaves in them) -- so that whichever multi-GPU record the driver
     # gets carries them whatever --workload it timed.  SHM_BENCH_MULTI_HCOEF: stand-in grid size for the flow test on a one-GPU box.
@@ -605,9 +606,10 @@ def main():
         line_printed = [False]
 
         def watchdog():
-            #  budgeted per leg: 120 s for each leg on the timed workload's grid (scaled with the grid beyond 256^3), 150 s for configs[3], 420 s for configs[4]
-            # (host pre-processing of 52 290 points, a 1024^3 set-up and two solves per rank); SHM_BENCH_LEGS_TIMEOUT overrides the sum
-            budget = 3 * 120.0 * max(1.0, (pre["n"] / 256.0) ** 3) + 150.0 + 420.0
+            #  budgeted per leg: 60 s for configs[3], 180 s for configs[4] (host pre-processing of 52 290 points, a 1024^3 set-up and two solves per rank), 40 s for
+            # each of the three legs on the timed workload's grid (scaled with the grid beyond 256^3); SHM_BENCH_LEGS_TIMEOUT overrides the sum.  The legs that finished
+            # before a hang are printed with the headline (multi_gpu_legs fills `multi_partial` leg by leg)
+            budget = 60.0 + 180.0 + 3 * 40.0 * max(1.0, (pre["n"] / 256.0) ** 3)
             if not legs_done.wait(float(os.environ.get("SHM_BENCH_LEGS_TIMEOUT", budget))):
                 with line_lock:
                     if line_printed[0]:
@@ -615,13 +617,15 @@ def main():
                     line_printed[0] = True
                     if rank == 0:
                         headline = dict(out)   # (the main thread only ever ADDS "also_multi" to `out`, after the legs: this copy cannot see a half-written record)
-                        headline["also_multi"] = {"failed": "timed out after SHM_BENCH_LEGS_TIMEOUT; the record above is complete without these legs; exit status 3"}
+                        headline["also_multi"] = dict(multi_partial)
+                        headline["also_multi"]["failed"] = "timed out after SHM_BENCH_LEGS_TIMEOUT; the headline record is complete, the legs listed here finished before the hang; exit status 3"
                         print(json.dumps(headline), flush=True)
                     os._exit(3)        # a hang in an extra leg is not a green run: the headline line is on stdout, the launcher sees a failing status
 
+        multi_partial = {}
         threading.Thread(target=watchdog, daemon=True).start()
         solver.close()   # (its communicator and whole-grid arrays go first: the legs build their own solver on a fresh communicator)
-        multi = multi_gpu_legs(shm, HostSolver, dist, torch, args, pre, precision, scrub, rank, world, local_rank, barrier)
+        multi = multi_gpu_legs(shm, HostSolver, dist, torch, args, pre, precision, scrub, rank, world, local_rank, barrier, multi_partial)
         with line_lock:
             if line_printed[0]:       # the watchdog got there first and is taking the process down
                 return
