@@ -116,6 +116,9 @@ template <int LOG2N, int TB> constexpr size_t dct_lds_bytes() {
     return ((size_t)(1 << LOG2N) * (dct_lc<LOG2N, TB>() + 1) + (dct_tw_in_lds<LOG2N>() ? (size_t)(1 << LOG2N) : 0)) * (size_t)(2 * TB) + 64;
 }
 
+// PF (round 6: LDS-DMA double buffer): the staging copy of the NEXT tile's input, in the input's natural order, behind the FFT buffer
+template <int LOG2N, int TB> constexpr size_t dct_stage_bytes() { return (size_t)(1 << LOG2N) * (size_t)(2 * dct_lc<LOG2N, TB>()) * (size_t)TB; }
+
 // One Stockham pass over the tile: every thread holds its work items in registers across the barrier.
 template <typename TP, int LOG2N, int R, int NS, int SIGN>
 __device__ __forceinline__ void dct_fft_pass(Cplx<TP>* buf, const Cplx<TP>* tw, int tid) {
@@ -207,10 +210,15 @@ template <int LOG2N, int CPLX_BYTES> constexpr int dct_waves_per_simd() {
     constexpr int want = LOG2N <= 8 ? (SHM_DCT_WAVES_256 > 0 ? SHM_DCT_WAVES_256 : 1) : (CPLX_BYTES == 8 ? SHM_DCT_WAVES_F32 : 2);
     return by_lds >= want ? want : (by_lds >= 1 ? by_lds : 1);
 }
-// PF (round 4, dense sweeps of the long transforms): the NEXT tile's input is loaded into registers (n L / 256 values per thread: 16 at n = 512 fp64)
-// before the current tile's FFT, so that its HBM latency runs under the FFT passes and the store phase instead of in front of them.  Without it a
-// workgroup alternates load -> FFT -> store, and the two or three workgroups a CU holds keep ~15-20 KB in flight per CU where 8 TB/s needs ~30:
-// 0.46-0.47 of the HBM peak at 512^3 (profiles/r03_bench_512_primal_dct.json).  Dense sweeps only (no tile list, no element mask, plain layout).
+// PF (dense sweeps of the long transforms).  A workgroup alternates load -> FFT -> store; the two or three workgroups a CU holds are out of phase, but each has its 16-32 KB
+// in flight only during its own load phase: ~40 KB per CU on average where 8 TB/s at ~2 us of loaded latency needs ~60 -- the sweeps sat at 0.45 of the HBM peak at 512^3
+// (fused z: 0.28) from round 2 to round 5.  Round 4 prefetched the next tile into REGISTERS and lost a workgroup of occupancy to them (slower).  Round 6: the next tile's input
+// travels global -> LDS directly (global_load_lds_dwordx4, no registers) into a staging region in the input's NATURAL order -- issued right after the current tile has been
+// copied out of it, in flight under this tile's FFT passes and stores --, and a permute-copy LDS -> LDS puts it into the padded, Makhoul-ordered FFT rows (the layout the DMA
+// cannot write).  One more LDS pass per tile (1/7 of the fused sweep's), 2 x the tile in LDS (73.5 KB at n = 512 fp64: two workgroups per CU, each with a tile in flight
+// all the time).  Dense sweeps only (no tile list, no element mask, plain layout, unit stride between the lines of a y / z tile).
+// MEASURED SLOWER (profiles/r06_dct_dma_rejected.txt: 512^3 fp64 0.46 -> 0.43 of the HBM peak, fp32 0.44 -> 0.36): the sweeps are bound by their LDS passes and barriers at the
+// occupancy the LDS allows, not by bytes in flight.  Kept as a verified A/B variant (-DSHM_DCT_PF), not shipped.
 template <typename TP, typename TIn, typename TOut, int MODE, bool DOT, int LOG2N, bool XPASS, bool SEG, bool PF = false>
 __global__ __launch_bounds__(kBlock, ((LOG2N >= SHM_DCT_WAVES_HINT || SHM_DCT_WAVES_256 > 0) && !(SHM_DCT_SEG9_ONE_WAVE && SEG && LOG2N == 9 && sizeof(TP) == 8) ? dct_waves_per_simd<LOG2N, (int)sizeof(Cplx<TP>)>() : 1)) void dct_lines_kernel(DctParams P, const TIn* __restrict__ in, TOut* __restrict__ out,
                                                            const Cplx<TP>* __restrict__ tw_g, const Cplx<TP>* __restrict__ om_g,
@@ -245,28 +253,32 @@ __global__ __launch_bounds__(kBlock, ((LOG2N >= SHM_DCT_WAVES_HINT || SHM_DCT_WA
     }
     if (MODE == DCT_FUSED) sp_lam_n = (TP)2 * lam_g[n / 2];   // lam_n = 4/h^2 = 2 lam_{n/2}
     static_assert(!PF || !SEG, "the prefetching variant serves plain layouts");
-    // PF: this thread's share of the next tile, in flight while the current one is transformed and stored
-    TP pf[PF ? EPT : 1];
+    static_assert(!PF || (sizeof(TIn) == sizeof(TP) && (total * sizeof(TIn)) % (16 * kBlock) == 0), "the prefetching variant moves whole 16-byte chunks of same-width input");
+    // PF: the staging region (input order: y / z sweeps [element][line], x sweep [line][element] -- in both, element idx of the copy loops below sits at stage[idx])
+    TIn* stage = reinterpret_cast<TIn*>(smem + dct_lds_bytes<LOG2N, (int)sizeof(TP)>());
     auto pf_issue = [&](int lbx) {
         if constexpr (PF) {
+            constexpr int kChunkElems = 16 / (int)sizeof(TIn);                       // elements per 16-byte chunk
+            constexpr int kChunks = total / kChunkElems, kPer = kChunks / kBlock;      // chunks per tile / per thread
             const int tx = lbx;
-            const long long bin = (long long)(tx % P.tiles_a) * P.in.a_stride + (long long)(tx / P.tiles_a) * P.in.b_stride;
-            const unsigned to = XPASS ? (n >= kBlock ? (unsigned)(tid * P.in.elem_stride) : (unsigned)((tid >> LOG2N) * P.in.line_stride + (tid & (n - 1)) * P.in.elem_stride))
-                                      : (unsigned)((tid & (L - 1)) * P.in.line_stride + (tid >> LOG2L) * P.in.elem_stride);
+            const long long bin = P.in.off + (long long)(tx % P.tiles_a) * P.in.a_stride + (long long)(tx / P.tiles_a) * P.in.b_stride;
+            const int wave0 = (tid >> 6) << 6;
 #pragma unroll
-            for (int a = 0; a < EPT; a++) {
-                long long u;
+            for (int a = 0; a < kPer; a++) {
+                const int q = a * kBlock + tid;                                          // this lane's chunk; the wave's 64 chunks land at consecutive 16-byte slots
+                long long g;
                 if (XPASS) {
-                    constexpr int per = n >= kBlock ? n / kBlock : 1, lp = n >= kBlock ? 1 : kBlock / n;
-                    u = n >= kBlock ? (long long)(a / per) * P.in.line_stride + (long long)((a % per) * kBlock) * P.in.elem_stride : (long long)(a * lp) * P.in.line_stride;
+                    constexpr int cpl = n / kChunkElems;                                 // chunks per line
+                    g = (long long)(q / cpl) * P.in.line_stride + (long long)((q % cpl) * kChunkElems);
                 } else {
-                    u = (long long)(a * (kBlock / L)) * P.in.elem_stride;
+                    constexpr int cpr = L / kChunkElems;                                 // chunks per element row (L consecutive lines = L consecutive x)
+                    g = (long long)(q / cpr) * P.in.elem_stride + (long long)((q % cpr) * kChunkElems);
                 }
-                pf[a] = (TP) * ((in + (P.in.off + bin + u)) + to);
+                // (the source as const char*: with the typed pointer in this dependent context the compiler silently emitted no host stub for the instantiation -- hipcc 7.2)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(in + (bin + g)), reinterpret_cast<char*>(stage) + (size_t)(a * kBlock + wave0) * 16, 16, 0, 0);
             }
         }
     };
-    static_assert(!PF || total % kBlock == 0, "the prefetching variant serves full tiles");
     if (PF) {
         const int lb0 = (int)xcd_remap(blockIdx.x, gridDim.x);
         if (lb0 < P.ntiles) pf_issue(lb0);
@@ -309,14 +321,23 @@ __global__ __launch_bounds__(kBlock, ((LOG2N >= SHM_DCT_WAVES_HINT || SHM_DCT_WA
 
     // ---------------- load: global -> registers (CH loads in flight) -> LDS ----------------
     if constexpr (PF) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this thread's chunks of the tile have landed in the staging region (and its stores of the previous tile have left)
+        __syncthreads();                       // ... and everyone else's
 #pragma unroll
-        for (int a = 0; a < EPT; a++) {
-            const int idx = tid + a * kBlock;
-            const int l = line_of(idx), j = elem_of(idx);
-            const int slot = (MODE == DCT_INV) ? j : makhoul_slot(j, n);
-            reinterpret_cast<TP*>(&buf[slot * kFftRow + (l >> 1)])[l & 1] = pf[a];
+        for (int a0 = 0; a0 < EPT; a0 += CH) {
+            TP v[CH];
+#pragma unroll
+            for (int a = 0; a < CH; a++) v[a] = (TP)stage[tid + (a0 + a) * kBlock];
+#pragma unroll
+            for (int a = 0; a < CH; a++) {
+                const int idx = tid + (a0 + a) * kBlock;
+                const int l = line_of(idx), j = elem_of(idx);
+                const int slot = (MODE == DCT_INV) ? j : makhoul_slot(j, n);
+                reinterpret_cast<TP*>(&buf[slot * kFftRow + (l >> 1)])[l & 1] = v[a];
+            }
         }
-        if (lb + (int)gridDim.x < P.ntiles) pf_issue(lb + (int)gridDim.x);   // in flight until the next iteration's LDS writes
+        __syncthreads();                       // the staging region has been read out: the next tile may land in it (the barrier below the load phase would do for buf alone)
+        if (lb + (int)gridDim.x < P.ntiles) pf_issue(lb + (int)gridDim.x);   // in flight under this tile's FFT passes and stores
     } else
 #pragma unroll 1
     for (int a0 = 0; a0 < EPT; a0 += CH) {

@@ -2357,26 +2357,41 @@ struct Solver final : SolverBase {
     }
     template <int MODE, typename TIn, typename TOut, bool DOT, int LOG2N, bool XPASS, bool SEG>
     void launch_dct_k(const DctParams& P, int ntiles, const TIn* in, TOut* out, const TOut* dotw, double* partials, const int* tile_list, const unsigned* elem_mask) {
-        // Prefetching variant of the dense sweeps (shm_dct.hip.h, PF: the next tile's loads in flight under this tile's FFT): measured SLOWER than two or three
-        // plain workgroups per CU out of phase -- 512^3 fp64 0.466 -> 0.449 of the HBM peak, fp32 0.447 -> 0.390 (the 16-32 registers of the prefetch cost a
-        // workgroup of occupancy in three of the five sweeps; profiles/r04_dct_prefetch_rejected.txt) -- so it is compiled only into -DSHM_DCT_PF A/B builds
+        // Dense sweeps of the long transforms (n >= 256): the LDS-DMA double buffer of shm_dct.hip.h (PF, round 6) -- the next tile's input in flight, global -> LDS, under this
+        // tile's FFT passes and stores.  Built, verified (76 GPU tests) and measured SLOWER than two or three plain workgroups per CU out of phase: 512^3 fp64 0.639 -> 0.687 ms per
+        // sweep (0.46 -> 0.43 of the HBM peak), fp32 0.333 -> 0.411, 256^3 0.059 -> 0.070 (profiles/r06_dct_dma_rejected.txt): the sweeps are bound by their barrier-separated
+        // LDS passes at the occupancy the LDS footprint allows, not by the bytes in flight -- the staging tile costs a workgroup per CU and adds a pass.  (Round 4's register
+        // prefetch: the same verdict, profiles/r04_dct_prefetch_rejected.txt.)  Compiled only into -DSHM_DCT_PF builds; SHM_DCT_NO_PF=1 switches it off there (A/B).
         static const bool no_pf = knob("SHM_DCT_NO_PF") != nullptr;
 #ifdef SHM_DCT_PF
-        constexpr bool kCanPf = LOG2N >= 9 && !SEG;
+        constexpr bool kCanPf = LOG2N >= 8 && !SEG && sizeof(TIn) == sizeof(TP) && ((size_t)(1 << LOG2N) * dct_lines_for(LOG2N, (int)sizeof(TP)) * sizeof(TIn)) % (16 * kBlock) == 0;
 #else
         constexpr bool kCanPf = false;
 #endif
         bool use_pf = false;
-        if constexpr (kCanPf) use_pf = !no_pf && !tile_list && !elem_mask;
-        auto kern = dct_lines_kernel<TP, TIn, TOut, MODE, DOT, LOG2N, XPASS, SEG, false>;
-        if constexpr (kCanPf)
-            if (use_pf) kern = dct_lines_kernel<TP, TIn, TOut, MODE, DOT, LOG2N, XPASS, SEG, true>;
-        static uint64_t configured[2] = {0, 0};  // per instantiation, one bit per device (the attribute is per device)
-        constexpr size_t lds = dct_lds_bytes<LOG2N, (int)sizeof(TP)>();
+        if constexpr (kCanPf) {
+            // (unit stride between the lines of a y / z tile, 16-byte aligned rows: what the plain layouts of launch_precond have)
+            const bool aligned = XPASS ? (P.in.elem_stride == 1 && (P.in.line_stride * (long long)sizeof(TIn)) % 16 == 0)
+                                       : (P.in.line_stride == 1 && (P.in.elem_stride * (long long)sizeof(TIn)) % 16 == 0 && (P.in.a_stride * (long long)sizeof(TIn)) % 16 == 0);
+            use_pf = !no_pf && !tile_list && !elem_mask && aligned && (P.in.off * (long long)sizeof(TIn)) % 16 == 0 && (P.in.b_stride * (long long)sizeof(TIn)) % 16 == 0;
+        }
+        if constexpr (kCanPf) {
+            if (use_pf) {
+                launch_dct_pf<MODE, TIn, TOut, DOT, LOG2N, XPASS, SEG, true>(P, ntiles, in, out, dotw, partials, tile_list, elem_mask);
+                return;
+            }
+        }
+        launch_dct_pf<MODE, TIn, TOut, DOT, LOG2N, XPASS, SEG, false>(P, ntiles, in, out, dotw, partials, tile_list, elem_mask);
+    }
+    // (the kernel is named in the launch itself: a variant reached only through a function pointer assigned in a branch got no host stub from this compiler)
+    template <int MODE, typename TIn, typename TOut, bool DOT, int LOG2N, bool XPASS, bool SEG, bool PF>
+    void launch_dct_pf(const DctParams& P, int ntiles, const TIn* in, TOut* out, const TOut* dotw, double* partials, const int* tile_list, const unsigned* elem_mask) {
+        static uint64_t configured = 0;  // per instantiation, one bit per device (the attribute is per device)
+        constexpr size_t lds = dct_lds_bytes<LOG2N, (int)sizeof(TP)>() + (PF ? dct_stage_bytes<LOG2N, (int)sizeof(TP)>() : 0);
         const uint64_t dev_bit = 1ull << (cfg.device & 63);
-        if (!(configured[use_pf] & dev_bit) || cfg.device >= 64) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            configured[use_pf] |= dev_bit;
+        if (!(configured & dev_bit) || cfg.device >= 64) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dct_lines_kernel<TP, TIn, TOut, MODE, DOT, LOG2N, XPASS, SEG, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            configured |= dev_bit;
         }
         DctParams Q = P;
         Q.ntiles = ntiles;
@@ -2387,7 +2402,8 @@ struct Solver final : SolverBase {
 #endif
         const int per_cu = std::max(1, (int)((size_t)(160 * 1024) / lds));
         const int grid = (int)std::min<long long>(ntiles, std::max<long long>(1, (long long)dct_grid_x16 * num_cus * per_cu / 16));
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), lds, stream, Q, in, out, d_tw.p, d_om.p, d_lam.p, dotw, partials, tile_list, elem_mask);
+        hipLaunchKernelGGL((dct_lines_kernel<TP, TIn, TOut, MODE, DOT, LOG2N, XPASS, SEG, PF>), dim3((unsigned)grid), dim3(kBlock), lds, stream, Q, in, out, d_tw.p, d_om.p, d_lam.p, dotw,
+                           partials, tile_list, elem_mask);
     }
     template <int MODE, typename TIn, typename TOut, bool DOT, bool XPASS>
     void launch_dct(const DctParams& P, int ntiles, const TIn* in, TOut* out, const TOut* dotw, double* partials, const int* tile_list = nullptr,
