@@ -105,7 +105,7 @@ typedef struct {
 } shm_opts;
 
 /* Form of the dual solver (SHM_SOLVER_DUAL / AUTO on one process; the same operator in every form, so the same phi up to the tolerance).
- * AUTO:          chosen per problem (DESIGN.md section 4b'): the direct solve where the inverse of S hides behind Step 1, else CG on the explicit S or through the grid.
+ * AUTO:          chosen per problem: the direct solve where the inverse of S hides behind Step 1, else CG on the explicit S or through the grid.
  * DIRECT:        S = A K^+ A^T assembled from the image-sum Green's table and INVERTED beside Step 1; the solve is two dense mat-vecs + refinement passes.
  *                Applies for m <= 16384 rows and n <= 512, on one z-slab or -- round 6 -- on a power-of-two number of equal z-slabs with n a power of two (S and S^-1 are
  *                then replicated on every rank and K^+ runs on the slabs: SHM_SOLVER_DUAL_SLABS, and what AUTO picks on four or more ranks for 256 <= n <= 512 with S <= 16384 sources);

@@ -14,7 +14,8 @@
 // with box_w the block's bounding box, r_hi_w the distance from the block's farthest corner to the source s* nearest to its centre -- an upper
 // bound of every node's distance to its nearest source -- and w_near the weight of s*: every term of s is then below e^-G of the dominant term
 // of every node of the block.
-// The same lane-parallel test with the skip threshold drops sources whose terms vanish against the budget altogether.
+// Sources whose terms vanish against the budget are dropped altogether -- round 6: while the RUNNING SUM of their bounds stays inside the budget, not S times the worst case;
+// whole clusters first, 64 at a time (see "The drop rule by ACCUMULATED bound" in the kernel).
 // Exponent range: the far tier carries ONE offset d0_w per block.  Over the block's nodes a source's exponent lambda' (r - d0_w) reaches up to
 // lambda' (dist(b_s, box_w) + 2 rt_w - d0_w); a source that is neither dropped nor guaranteed to stay a normal fp32 number there -- that bound, plus
 // log2(w_max / w_s) (the weights are staged relative to the largest one) and 13 bits for the factor 1 / r' and the accumulation -- is evaluated in fp64
@@ -27,11 +28,14 @@
 //     eps_far * L1_far  <=  budget * |X|          (P.far_redo_ratio = budget / eps_far)
 // with eps_far the calibrated relative error of a packed-fp32 term as it shows up in X (3e-6: five times the largest |dY| |X| / L1_far observed over ten data
 // files at up to 1024^3; the rounding errors of the terms are independent, their sum grows slower than L1_far).  A block with a failing node walks the
-// sources a second time and evaluates its far sources in fp64 on top of the near sums it already holds -- no packed-fp32 term is left in it.
+// sources a second time and evaluates its far sources in fp64 on top of the near sums it already holds -- no packed-fp32 term is left in it.  Round 6: the bound of what the
+// block DROPPED enters the same test (R |term_s*(x)|), and the second pass evaluates the dropped sources as well.
 // The GPU tests hold Y to the stated budget against the C oracle at the full sizes of BASELINE.json (planes through the measured worst nodes) and against
 // the all-fp64 kernel (shm_opts.step1_arith = EXACT_F64); shm_opts.step1_budget moves the budget (G, the test and the drop threshold together).
-// Round 5: exponent insertion by an integer add with a per-block exponent (yukawa_near), squared z offsets staged per source,
+// Round 5 (profiles/NOTES_r01_r05.md section 4.1b): exponent insertion by an integer add with a per-block exponent (yukawa_near), squared z offsets staged per source,
 // weights broadcast by op_sel, and a register diet (181 -> 171 with four pairs of a near source in flight) -- 16.4 -> 15.4 VALU instructions per nominal pair.
+// Round 6 (profiles/NOTES_r06.md): the accumulated drop rule, the cluster scan as a lane-parallel batch test, the far loop written stage by stage
+// (the scheduler's 24 s_nop are gone), the in-launch verdict of the far-rule sample as one word written by compare-and-swap.  176 registers.
 #pragma once
 #include "shm_kernels.hip.h"
 

@@ -144,7 +144,7 @@ struct ConvParams {
     int n_clusters;
     float far_gap;      // fp64 path: a cluster is "far" when d_lo(tile, cluster) - r_hi(tile) > far_gap
     float tier_log;     // tiered fp64 path (shm_conv_tiered.hip.h): a source is "far" for a sub-tile when all its terms are below e^-tier_log of the sub-tile's dominant terms
-    float skip_base;    // ln(64 S / eps): a cluster (largest weight A_c) is skipped when lambda gap > skip_base + ln(A_c / A_near)
+    float skip_base;    // conv_normalize_kernel only: ln(S / eps) -- a cluster (largest weight A_c) is skipped when lambda gap > skip_base + ln(A_c / A_near); the tiered kernels drop by accumulated bound (drop_* below)
     float inv_lambda;
     int exact_offset;   // fp32 path only: 1 = per-node nearest-source distance (coarse grids: lambda * tile diameter too large)
     int n_tiles;        // total tiles; workgroups stride over them (fewer workgroups than slots leave room for the set-up stream)
