@@ -892,10 +892,12 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(int m, const int* _
 }
 
 // u = Ginv * w  (Ginv = (A A^T)^-1, dense, row-major, leading dimension ld, a multiple of 4).  One workgroup per row, four
-// consecutive columns per lane and load (16 or 32 bytes); rows up to 4096 columns are fetched with every load of the row in flight
-// at once (the kernel is pure latency otherwise: a row is only 11-23 KB).  TM = float: the dual solver's preconditioner reads a
-// single-precision copy (any fixed symmetric positive definite operator will do there); products and sums stay in double.
-template <typename TM>
+// consecutive columns per lane and load (16 or 32 bytes), U loads of the row in flight per lane at once (the kernel is pure latency
+// otherwise: a row is 11-100 KB): U = 4 covers rows up to 4096 columns in one go; longer rows (round 6: rocker at 512^3, m = 12 612,
+// where one load in flight per lane read the 1.27 GB of S at 3.1 TB/s) take chunks of 8192 columns with U = 8 (launch_ginv_matvec).
+// TM = float: the dual solver's preconditioner reads a single-precision copy (any fixed symmetric positive definite operator will do
+// there); products and sums stay in double.
+template <typename TM, int U>
 __global__ __launch_bounds__(kBlock) void ginv_matvec_kernel(int m, int ld, const TM* __restrict__ Ginv, const double* __restrict__ w,
                                                              double* __restrict__ u) {
     __shared__ double lds[8];
@@ -916,27 +918,26 @@ __global__ __launch_bounds__(kBlock) void ginv_matvec_kernel(int m, int ld, cons
         return s;
     };
     double s = 0.;
-    if (m <= 4 * kBlock * 4) {
-        TM gv[4][4];
+    for (int c0 = 0; c0 < m; c0 += U * kBlock * 4) {
+        TM gv[U][4];
 #pragma unroll
-        for (int a = 0; a < 4; a++) {
-            const int c = (threadIdx.x + a * kBlock) * 4;
+        for (int a = 0; a < U; a++) {
+            const int c = c0 + (threadIdx.x + a * kBlock) * 4;
             if (c < m) load4(c, gv[a]);
         }
 #pragma unroll
-        for (int a = 0; a < 4; a++) {
-            const int c = (threadIdx.x + a * kBlock) * 4;
+        for (int a = 0; a < U; a++) {
+            const int c = c0 + (threadIdx.x + a * kBlock) * 4;
             if (c < m) s += dot4(c, gv[a]);
-        }
-    } else {
-        for (int c = threadIdx.x * 4; c < m; c += kBlock * 4) {
-            TM gv[4];
-            load4(c, gv);
-            s += dot4(c, gv);
         }
     }
     s = block_sum(s, lds);
     if (threadIdx.x == 0) u[row] = s;
+}
+template <typename TM>
+static inline void launch_ginv_matvec(hipStream_t st, int rows, int m, int ld, const TM* G, const double* w, double* u) {
+    if (m <= 4 * kBlock * 4) hipLaunchKernelGGL((ginv_matvec_kernel<TM, 4>), dim3(rows), dim3(kBlock), 0, st, m, ld, G, w, u);
+    else hipLaunchKernelGGL((ginv_matvec_kernel<TM, 8>), dim3(rows), dim3(kBlock), 0, st, m, ld, G, w, u);
 }
 
 // v[node] -= sum_e coef * u[row]  (node-major lists: no atomics, deterministic); block 0 also

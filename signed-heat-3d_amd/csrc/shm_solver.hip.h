@@ -1634,8 +1634,8 @@ struct Solver final : SolverBase {
     void apply_Ginv(const double* w, double* u, bool f32, hipStream_t st) {
         if (m <= 0) return;
         if (!tl.on) {
-            if (f32) hipLaunchKernelGGL(ginv_matvec_kernel<float>, dim3(m), dim3(kBlock), 0, st, m, mp, Ginv32.p, w, u);
-            else hipLaunchKernelGGL(ginv_matvec_kernel<double>, dim3(m), dim3(kBlock), 0, st, m, mp, Ginv.p, w, u);
+            if (f32) launch_ginv_matvec<float>(st, m, m, mp, Ginv32.p, w, u);
+            else launch_ginv_matvec<double>(st, m, m, mp, Ginv.p, w, u);
             return;
         }
         const TlBoxes V = tl.view();
@@ -1674,8 +1674,8 @@ struct Solver final : SolverBase {
         }
         hipLaunchKernelGGL(tl_gather_sep_kernel, dim3((unsigned)((tl.nS + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, tl.nS, tl.sepRow.p, tl.adj_ptr.p, tl.adj_idx.p, w,
                            tl.ybuf.p, tl.vS.p);
-        if (f32) hipLaunchKernelGGL(ginv_matvec_kernel<float>, dim3(tl.nS), dim3(kBlock), 0, st, tl.nS, tl.nSp, Ginv32.p, tl.vS.p, tl.uS.p);
-        else hipLaunchKernelGGL(ginv_matvec_kernel<double>, dim3(tl.nS), dim3(kBlock), 0, st, tl.nS, tl.nSp, Ginv.p, tl.vS.p, tl.uS.p);
+        if (f32) launch_ginv_matvec<float>(st, tl.nS, tl.nS, tl.nSp, Ginv32.p, tl.vS.p, tl.uS.p);
+        else launch_ginv_matvec<double>(st, tl.nS, tl.nS, tl.nSp, Ginv.p, tl.vS.p, tl.uS.p);
         const unsigned gfin = grows + (unsigned)((tl.nS + kBlock - 1) / kBlock);
         if (f32) hipLaunchKernelGGL((tl_finish_kernel<float>), dim3(gfin), dim3(kBlock), 0, st, V, tl.rowBox.p, tl.nI, tl.nS, tl.sepRow.p, tl.T32.p, tl.tbuf.p, tl.uS.p, u);
         else hipLaunchKernelGGL((tl_finish_kernel<double>), dim3(gfin), dim3(kBlock), 0, st, V, tl.rowBox.p, tl.nI, tl.nS, tl.sepRow.p, tl.Tm.p, tl.tbuf.p, tl.uS.p, u);
@@ -1983,7 +1983,7 @@ struct Solver final : SolverBase {
             enqueue_gj_invert(Sinv.p, mp, true);
             Sinv_ones.alloc((size_t)2 * mp);
             hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, Sinv_ones.p + mp, m, 1.0);
-            hipLaunchKernelGGL(ginv_matvec_kernel<double>, dim3(m), dim3(kBlock), 0, st, m, mp, Sinv.p, Sinv_ones.p + mp, Sinv_ones.p);
+            launch_ginv_matvec<double>(st, m, m, mp, Sinv.p, Sinv_ones.p + mp, Sinv_ones.p);
         } else {
             e_sch_done->record(st);
             HIPCHK(hipStreamWaitEvent(stream2, e_sch_done->e, 0));   // "set-up done" on stream2 (what the solve waits for) now includes S
@@ -2745,7 +2745,7 @@ struct Solver final : SolverBase {
         if (!dense_S)
             for (Slab<T>& sl : slabs) HIPCHK(hipMemsetAsync(sl.p.p, 0, sl.ntot * sizeof(T), stream));  // w = A^T nu lives in p: zero outside the touched nodes
         auto apply_S = [&](int vec) {   // red[1..m] = S v
-            for (Slab<T>& sl : slabs) hipLaunchKernelGGL(ginv_matvec_kernel<double>, dim3(m), dim3(kBlock), 0, stream, m, mp, Sdense.p, mv(sl, vec), sl.red.p + 1);
+            for (Slab<T>& sl : slabs) launch_ginv_matvec<double>(stream, m, m, mp, Sdense.p, mv(sl, vec), sl.red.p + 1);
         };
         if (dense_S) apply_S(V_MU);
         else {
@@ -2797,7 +2797,7 @@ struct Solver final : SolverBase {
             // u = S^-1 r, v = S^-1 1 (formed behind the inversion, in the set-up), delta = u - (1^T u / 1^T v) v;  then r = Pm(g - S mu) again with the explicit S.
             // The first pass IS the solution (cond(S) ~ 5e2 ... 7e4 on the bunny grids: 1e-12 and better); further passes are iterative refinement, taken only
             // while the residual test of the CG path -- the same one -- is not met.
-            auto apply_Sinv = [&](const double* w, double* u) { hipLaunchKernelGGL(ginv_matvec_kernel<double>, dim3(m), dim3(kBlock), 0, stream, m, mp, Sinv.p, w, u); };
+            auto apply_Sinv = [&](const double* w, double* u) { launch_ginv_matvec<double>(stream, m, m, mp, Sinv.p, w, u); };
             // At most six passes, and never more than max_iters.  A tolerance below what the arithmetic can deliver (about eps * cond(S): cond is 5e2 ... 7e4
             // here) would otherwise end in SHM_ERR_NOCONV although mu is at rounding accuracy: when a pass no longer reduces the residual by at least a
             // factor of four and the residual already sits below 1e-9 of the right-hand side, the stagnation IS convergence; rel_residual reports what was reached.
