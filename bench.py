@@ -127,6 +127,8 @@ def live_step1_traffic(path, hCoef, precision, timeout_s=150.0):
     prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if prof is None:
         return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process is itself being profiled (no profiler inside a profiler)"
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_report
     reps = 2
