@@ -5,7 +5,7 @@
 // X(x) = sum_s w_s e^{-lambda r}/r is dominated, at every node, by the handful of sources nearest to it: a source whose term is a factor
 // e^-G below the node's largest term needs a relative accuracy of only budget * e^G.  So the pairs are evaluated in two tiers:
 //   near  (fp64, division-free, 2^(k/2048) table + short polynomial: relative error ~1e-12 per term), and
-//   far   (packed fp32 with the sub-tile's exponent offset, two nodes per v_pk_*_f32 instruction, ~3e-6 per term),
+//   far   (packed fp32 with the sub-tile's exponent offset, two nodes per v_pk_*_f32 instruction, ~1e-6 per term and more with the exponent),
 // classified per (wave sub-tile, SOURCE) -- not per (workgroup tile, cluster of 64) as the e^-25 branch of conv_normalize_kernel was: a
 // wave owns a compact 8 x 8 x NPT block of nodes and each of its 64 lanes tests one source of a 64-source cluster against that block's
 // bounds, a ballot turns the 64 answers into two scalar masks, every lane stages its source at its rank in its mask, and the wave then walks the dense
@@ -25,11 +25,19 @@
 // source geometry cancel (medial axis): measured at 512^3 / 1024^3 the tiered result left the 1e-8 budget exactly there (|X| / L1 = 2e-3 ... 8e-3, max|dY|
 // 1.1e-8 ... 3.3e-8) and nowhere else (tools/tier_worst_nodes.py, profiles/r04_tier_worst_nodes.txt).  So the far loop also accumulates, per node,
 // L1_far = sum_far |w_s|_1 e^{-lambda r} / r, and when the block is done every node is tested:
-//     eps_far * L1_far  <=  budget * |X|          (P.far_redo_ratio = budget / eps_far)
-// with eps_far the calibrated relative error of a packed-fp32 term as it shows up in X (3e-6: five times the largest |dY| |X| / L1_far observed over ten data
-// files at up to 1024^3; the rounding errors of the terms are independent, their sum grows slower than L1_far).  A block with a failing node walks the
-// sources a second time and evaluates its far sources in fp64 on top of the near sums it already holds -- no packed-fp32 term is left in it.  Round 6: the bound of what the
-// block DROPPED enters the same test (R |term_s*(x)|), and the second pass evaluates the dropped sources as well.
+//     eps_far(u) * L1_far  <=  budget * |X|          (P.far_redo_ratio = budget / eps_far(0))
+// with eps_far the calibrated relative error of a packed-fp32 term as it shows up in X.  Rounds 4-6: a flat 3e-6.  Round 6, late (tools/r06_tier_calib.sh,
+// profiles/r06_tier_calib.txt): two things that number had been covering are now dealt with where they arise --
+//   * the ACCUMULATION: an fp32 accumulator that has taken N terms carries ~6e-8 sqrt(N) of its partial sums (thousands of far sources per block on SprayBottle.pc, 1700 on the
+//     bunny): the packed-fp32 sums are flushed into the fp64 accumulators every kTierFlush = 256 far sources (12 conversions and 12 fp64 fmas per flush, 0.6 % of the far
+//     loop) -- max|dY| against the all-fp64 arithmetic fell by 1.3 ... 2.7 x on every file (bunny 256^3 2.55e-9 -> 9.3e-10);
+//   * the EXPONENT: a term's scaled distance u = lambda' r carries ~1e-7 u of rounding into 2^-u, so the price grows with u: eps_far(u) = 1e-6 max(1, u / 24) with u the
+//     block's smallest far exponent (coff + G log2 e) -- 3e-6, the old flat price, at u = 72; less below (the blocks near the surface: fewer second passes, the bunny's
+//     Step 1 2.8 % shorter), more beyond (the nodes far from every source, where the flat price had let 6e-9 ... 8e-9 through: SprayBottle.pc 1024^3 8.1e-9 -> 6.0e-9).
+// Still a calibration, not a bound (the terms' rounding errors are independent, their sum grows slower than L1_far); what is measured is max|dY| <= 6.0e-9 over the ten
+// files at up to 1024^3 and the adversarial inputs of the tests.  A block with a failing node walks the sources a second time and evaluates EVERY source in fp64 from
+// scratch (the fp64 accumulators hold flushed packed-fp32 sums by then) -- no packed-fp32 term is left in it.  Round 6: the bound of what the block DROPPED enters the
+// same test (R |term_s*(x)|), and the second pass evaluates the dropped sources as well.
 // The GPU tests hold Y to the stated budget against the C oracle at the full sizes of BASELINE.json (planes through the measured worst nodes) and against
 // the all-fp64 kernel (shm_opts.step1_arith = EXACT_F64); shm_opts.step1_budget moves the budget (G, the test and the drop threshold together).
 // Round 5 (profiles/NOTES_r01_r05.md section 4.1b): exponent insertion by an integer add with a per-block exponent (yukawa_near), squared z offsets staged per source,
@@ -52,6 +60,11 @@ namespace shm {
 // the block (where the reference's underflow to 0 -> NaN far from the sources is reproduced by that one v_ldexp_f64).  The host keeps blocks whose near
 // terms could span more than 2^-990 off this kernel (Solver::tier_exponent_span_ok).
 typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+// The quadratic of the near tier's exponential, 2^(f / 2048) ~ 1 + A1 f + A2 f^2 on |f| <= 1/2: with c = ln 2 / 2048 the Taylor coefficient A1 = c leaves the cubic term
+// (c f)^3 / 6 <= 8.1e-13; A1 = c (1 + c^2 / 32) -- the best linear stand-in for that cubic on the interval (Chebyshev) -- leaves a quarter of it, 2.0e-13, for nothing
+// (round 6, late: at nodes where the sources' terms cancel to 1e-4 of their sum -- inside SprayBottle.pc at 1024^3 -- the 8e-13 was the whole 8.1e-9 of the measured
+// error of Y: tools/r06_worst_node_diag.py, NOTES_r06.md section 7)
+constexpr double kNearA1 = 3.384507729693224e-04;
 __device__ __forceinline__ double yukawa_near(double x, double c, double m1, const uint2v* __restrict__ tab) {
     const double y0 = __builtin_amdgcn_rsq(x);
     const double t = x * y0;
@@ -64,7 +77,7 @@ __device__ __forceinline__ double yukawa_near(double x, double c, double m1, con
     const unsigned ki = (unsigned)__double_as_longlong(tm);
     const double f = fma(r, c, -kf);
     double p = 5.727446245172041e-08;                   // (ln2/2048)^2 / 2
-    p = fma(p, f, 3.384507717577858e-04);               // ln2/2048
+    p = fma(p, f, kNearA1);
     p = fma(p, f, 1.0);
     uint2v tv = tab[ki & 2047u];
     tv.y += ki << 9;
@@ -98,7 +111,7 @@ __device__ __forceinline__ void yukawa_near_batch(const double* __restrict__ x, 
 #pragma unroll
     for (int b = 0; b < B; b++) rinv[b] = fma(y0[b], e[b], y0[b]);
 #pragma unroll
-    for (int b = 0; b < B; b++) p[b] = fma(fma(5.727446245172041e-08, f[b], 3.384507717577858e-04), f[b], 1.0);
+    for (int b = 0; b < B; b++) p[b] = fma(fma(5.727446245172041e-08, f[b], kNearA1), f[b], 1.0);
 #pragma unroll
     for (int b = 0; b < B; b++) {
         g[b] = __builtin_bit_cast(double, tv[b]) * (p[b] * rinv[b]);
@@ -137,7 +150,7 @@ __device__ __forceinline__ double exp2_tab(double u, const uint2v* __restrict__ 
     const double f = u - (tm - 6755399441055744.0);
     uint2v tv = tab[ki & 2047u];
     tv.y += ki << 9;
-    return __builtin_bit_cast(double, tv) * fma(fma(5.727446245172041e-08, f, 3.384507717577858e-04), f, 1.0);
+    return __builtin_bit_cast(double, tv) * fma(fma(5.727446245172041e-08, f, kNearA1), f, 1.0);
 }
 
 // a wave-uniform float as a scalar register (the builtin is integer-typed: pass the bits, not the value)
@@ -187,13 +200,15 @@ __device__ __forceinline__ void sample_report(unsigned long long* ctr, unsigned 
 #endif
 constexpr int kTierTX = SHM_TIER_TX, kTierTY = 64 / kTierTX;   // a wave's block of nodes is kTierTX x kTierTY x NPT (one z-column of NPT nodes per lane)
 // The budget of the tiers on the normalised field Y (what tests/test_gpu_parity.py asserts against the C oracle at BASELINE.json's full sizes), and the
-// calibrated relative error of a packed-fp32 term as it shows up in X.  Measured max|dY| |X| / L1_far (L1_far by a per-pair e^-8 rule, an upper bound of the
-// kernel's own): 4.8e-7 (bunny_small 512^3), 6e-7 (SprayBottle.pc 1024^3, lambda r = 28: the error of a term grows with lambda r); 3e-6 = five times that.
-// A block where eps_far L1_far > budget |X| at any node re-evaluates its far sources in fp64: 0.03-0.13 % of the packed-fp32 pairs on the shipped data at
-// 256^3 ... 1024^3, +0.3 % of Step 1 (profiles/r04_redo_sweep.txt: thresholds 1e-2 ... 2e-3 against max|dY| and the re-evaluated share).
-// (A threshold that grows with the block's exponent offset -- eps_far proportional to lambda' r, as the 1-ulp error of v_rsq_f32 suggests -- was measured
-// too: SprayBottle.pc 1024^3 8.3e-9 -> 7.7e-9 for +9 % of its Step 1, knot 1024^3 +6.5 %; profiles/r04_eps_sweep.txt.  Not adopted.)
-constexpr double kTierBudget = 1.0e-8, kTierEpsFar = 3.0e-6;
+// calibrated relative error of a packed-fp32 term as it shows up in X: eps_far(u) = kTierEpsFar max(1, u / kTierU0) (see the header).  History: rounds 4-6 priced every
+// term at a flat 3e-6 ("five times the largest max|dY| |X| / L1_far measured": 4.8e-7 on bunny_small 512^3, 6e-7 on SprayBottle.pc 1024^3 at lambda r = 28); round 4 had
+// measured a price proportional to lambda' r ON TOP of that flat floor (SprayBottle.pc 1024^3 8.3e-9 -> 7.7e-9 for +9 % of its Step 1; profiles/r04_eps_sweep.txt) and not
+// adopted it.  With the accumulation taken out of the number (kTierFlush) the floor is a third of it, the slope meets the old price at u = 72, and the same sweep reads
+// SprayBottle.pc 1024^3 8.1e-9 -> 6.0e-9 for +3.5 % (fp64 solve), knot 1024^3 5.5e-9 -> 2.1e-9 for -1.8 %, the bunny 2.6e-9 -> 1.3e-9 for -2.8 % (profiles/r06_tier_calib.txt).
+// A block where eps_far L1_far > budget |X| at any node is evaluated again, every source in fp64: 0.1 ... 0.8 % of the pairs on the shipped data.
+constexpr double kTierBudget = 1.0e-8, kTierEpsFar = 1.0e-6;   // (eps_far at small exponents: see the header)
+constexpr double kTierU0 = 24.0;  // exponent beyond which the a-posteriori test prices a packed-fp32 term at eps_far u / u0 (0: flat)
+constexpr int kTierFlush = 256;   // packed-fp32 sources between two flushes of their sums into the fp64 accumulators (0: never)
 constexpr int kTierCluster = 64;                    // sources per cluster = lanes per wave: one source per lane in the classification
 constexpr int kTierChunk = 4;                       // clusters per LDS fill
 constexpr int kTierFill = kTierCluster * kTierChunk;
@@ -414,14 +429,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
         // its distance from the block's box (inf when the block holds it: the rule then never fires)
         float star_ux = 0.f, star_uy = 0.f, star_uz = 0.f, star_dc = 0.f, star_inv_d = 0.f;
         if constexpr (CHECK) {
-            // The a-posteriori test prices a packed-fp32 term at a relative error of kTierEpsFar = 3e-6 -- calibrated: five times the largest error observed, 6e-7 at lambda r = 28.
-            // What a term's error is grows with its exponent: the scaled distance u = lambda' r carries its rounding, ~1e-7 u, into 2^-u.  Far from the sources (u in the hundreds: point
-            // clouds with lambda r ~ 1e2 ... 1e3) every term of a node is off by more than the 3e-6; under the box rule the far tier's share of |X| is so small there that it does not
-            // show (8.1e-9 of the 1e-8 budget at worst, measured), but the differential rule triples that share -- SprayBottle.pc then read 1.8e-8 against the all-fp64 kernel
-            // (profiles/r05_far_rule.txt).  So the rule is used only in blocks whose nearest terms stay below u = 72 (lambda' (d0 + 2 rt) <= 72, lambda r <~ 50: the whole grid of a mesh
-            // whose mean edge is a few cells, the neighbourhood of a dense point cloud), where the observed errors extrapolate to ~1.1e-6, a third of what the test assumes; everywhere
-            // else the box rule and its measured margin stand.  (A test that tightens with u instead was measured: it fails so many sample blocks that the bunny's verdict turns to the
-            // box rule and SprayBottle / rocker 256^3 pay 8 % for the sample.)
+            // What a packed-fp32 term's error is grows with its exponent: the scaled distance u = lambda' r carries its rounding, ~1e-7 u, into 2^-u.  Far from the sources (u in
+            // the hundreds: point clouds with lambda r ~ 1e2 ... 1e3) every term of a node is off by several 1e-6; under the box rule the far tier's share of |X| is so small
+            // there that it does not show (6.0e-9 of the 1e-8 budget at worst, measured, with the test's price growing with u -- see the header), but the differential rule
+            // triples that share: SprayBottle.pc read 1.8e-8 against the all-fp64 kernel with it (profiles/r05_far_rule.txt).  So the rule is used only in blocks whose
+            // nearest terms stay below u = 72 (lambda' (d0 + 2 rt) <= 72, lambda r <~ 50: the whole grid of a mesh whose mean edge is a few cells, the neighbourhood of a
+            // dense point cloud); everywhere else the box rule and its measured margin stand.
             use_diff = use_diff && coff + 2.f * rt_w * lam_l2 <= 72.f;
         }
         // (round 6: the drop rule reads the same differential bound in every block -- it decides what is evaluated at all, not in which arithmetic)
@@ -455,6 +468,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
         }
         const float span_c = uniform_f32(2.f * rt_w * lam_l2 - coff - 960.f);   // pass 1: a dropped source is evaluated only where its exponent stays inside the block's span
         // pass 0: near sources in fp64, far ones in packed fp32.  pass 1 (only when the a-posteriori test failed): the far sources again, in fp64.
+        int far_pending = 0;
 #pragma unroll 1
         for (int pass = 0; pass < 2; pass++) {
         // the lane's source of cluster c: fetched into the wave's raw LDS region one cluster ahead (issued once cluster c - 1 has been read out of it, in flight
@@ -632,7 +646,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                 }
                 // pass 1 evaluates what pass 0 dropped as well, where the term's exponent stays inside the span of the block's scale (beyond it the term is < 2^-900 of the scale)
                 const bool span_ok = fmaf(dist, lam_l2, span_c) < 0.f;
-                const bool to64 = valid && (pass == 0 ? (!drop && !far) : (drop ? span_ok : far));   // (drop first: a source outside the fp32 exponent range is not "far", but it may well be dropped)
+                const bool to64 = valid && (pass == 0 ? (!drop && !far) : (drop ? span_ok : true));   // (drop first: a source outside the fp32 exponent range is not "far", but it may well be dropped)
                 const bool to32 = valid && pass == 0 && far && !drop;
                 nearmask = __ballot(to64);
                 farmask = __ballot(to32);
@@ -745,6 +759,23 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                     if constexpr (CHECK) pk_fma_hi(fl[h], pcw[u], g[a]);
                 }
             }
+            if constexpr (CHECK) {
+                // the packed-fp32 sums go to the fp64 accumulators every P.tier_flush far sources (0: never): an fp32 accumulator that has taken N terms carries ~6e-8 sqrt(N) of its
+                // partial sums, which the test's price of a far TERM does not know about
+                far_pending += nfar;
+                if (P.tier_flush > 0 && far_pending >= P.tier_flush) {
+                    far_pending = 0;
+                    const double e0f = far_scale();
+#pragma unroll
+                    for (int e = 0; e < NPT; e++) {
+                        ax[e] = fma((double)fx[e / 2][e & 1], e0f, ax[e]);
+                        ay[e] = fma((double)fy[e / 2][e & 1], e0f, ay[e]);
+                        az[e] = fma((double)fz[e / 2][e & 1], e0f, az[e]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < NPT / 2; e++) fx[e] = fy[e] = fz[e] = float2v{0.f, 0.f};
+                }
+            }
             c = c_next;
             cdrop_cur = cdrop_next;
         }
@@ -765,6 +796,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
             asm volatile("" : "+v"(chk), "+v"(k0_here));
             const float rs = r_drop * chk * 1.01f * sqrtf(st.w) * __builtin_amdgcn_exp2f(-lws) * lam_l2;   // (lambda': the reciprocal below is of the SCALED distance)
             const float sdx = qx - st.x, sdy = qy - st.y, sdz0 = qz0 - st.z;   // scaled coordinates, like the far tier's
+            // the price of a packed-fp32 term grows with its exponent (its scaled distance carries ~1e-7 u of rounding into 2^-u): beyond u = P.tier_u0 the block's far terms
+            // -- at least coff + g_l2 powers of two below 1 -- are priced at eps_far u / u0 (a wave-uniform fp32 factor on the threshold: a scalar register; u0 = 0: flat)
+            const float ratio_f = uniform_f32((float)P.far_redo_ratio * (P.tier_u0 > 0.f ? fminf(1.f, P.tier_u0 / (coff + g_l2)) : 1.f));
             const float sxy2 = sdx * sdx + sdy * sdy;
 #pragma unroll
             for (int e = 0; e < NPT; e++) {
@@ -772,11 +806,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
                 // |w_*| e^{-lambda r} / r in the block's scale 2^-k0:  2^(-lambda' r - k0) lambda' / (lambda' r)      (the node on s*: inf * 0 = NaN -- compares false, X is NaN there itself)
                 const float dz = e * cellq + sdz0, d2 = fmaf(dz, dz, sxy2), rinv = __builtin_amdgcn_rsqf(d2);
                 const float tstar = r_drop > 0.f ? rs * __builtin_amdgcn_exp2f(-d2 * rinv - k0_here) * rinv : 0.f;
-                fail = fail || (live_xy && kk0 + e < P.kk_end && fma((double)fl[e / 2][e & 1], e0, (double)tstar) > (double)P.far_redo_ratio * sqrt(x0 * x0 + x1 * x1 + x2 * x2));
+                fail = fail || (live_xy && kk0 + e < P.kk_end && fma((double)fl[e / 2][e & 1], e0, (double)tstar) > (double)ratio_f * sqrt(x0 * x0 + x1 * x1 + x2 * x2));
             }
             if (__ballot(fail) == 0ull) break;
 #pragma unroll
             for (int e = 0; e < NPT / 2; e++) fx[e] = fy[e] = fz[e] = float2v{0.f, 0.f};
+            // (the fp64 accumulators hold flushed packed-fp32 sums: the second pass starts from nothing and takes every source in fp64)
+#pragma unroll
+            for (int e = 0; e < NPT; e++) ax[e] = ay[e] = az[e] = 0.;
         }
         }  // pass loop
         const double e0 = far_scale();

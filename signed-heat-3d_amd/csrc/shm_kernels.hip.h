@@ -162,6 +162,8 @@ struct ConvParams {
     // block's dropped bounds stays <= drop_eps_soft; one with b_s <= 2^drop_ltau_hard = drop_tau_hard (the S-times-worst-case rule of rounds 3-5 on an eighth of the
     // budget) is dropped whatever the sum.  drop_eps_soft = 0: nothing is dropped.
     float drop_eps_soft, drop_ltau, drop_ltau_hard, drop_tau_hard;
+    float tier_u0;            // fp64 solve: exponent beyond which the a-posteriori test prices a packed-fp32 term at eps_far u / u0 (0: flat)
+    int tier_flush;           // fp64 solve: packed-fp32 sources between two flushes of their sums into the fp64 accumulators (0: never)
     float drop_check;         // fp64 solve: 1 / eps_far -- what a unit of dropped bound weighs against the packed-fp32 tier's L1 sums in the a-posteriori test
 };
 

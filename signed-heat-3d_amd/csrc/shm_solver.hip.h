@@ -752,7 +752,11 @@ struct Solver final : SolverBase {
                 P.drop_ltau = eps > 0. ? (float)std::log2(tau) : -3.0e38f;
                 P.drop_ltau_hard = eps > 0. ? (float)std::log2(tau_hard) : -3.0e38f;
                 P.drop_tau_hard = (float)(tau_hard * 1.0001);
-                P.drop_check = (float)(1.0 / kTierEpsFar);
+                P.drop_check = P.far_redo_ratio < 1.0e30f ? (float)((double)P.far_redo_ratio / budget) : (float)(1.0 / kTierEpsFar);   // 1 / eps_far
+                static const double u0_env = knob("SHM_TIER_U0") ? atof(knob("SHM_TIER_U0")) : -1.;          // experiment knobs (defaults: kTierU0, kTierFlush)
+                static const int flush_env = knob("SHM_TIER_FLUSH") ? atoi(knob("SHM_TIER_FLUSH")) : -1;
+                P.tier_u0 = (float)(u0_env >= 0. ? u0_env : kTierU0);
+                P.tier_flush = flush_env >= 0 ? flush_env : kTierFlush;
             }
             P.inv_lambda = (float)(1.0 / lambda);
             P.tiles_x = (n + kConvTile - 1) / kConvTile;
