@@ -126,7 +126,7 @@ enum { SHM_DUAL_AUTO = 0, SHM_DUAL_DIRECT = 1, SHM_DUAL_EXPLICIT_S_CG = 2, SHM_D
  *            BASELINE.json), phi inherits < 1e-9.
  * EXACT_F64: every (node, source) pair in fp64 like the reference (~1.4x the Step-1 time); Y agrees with the serial loops to 1e-11.  (Round 5: the tiered kernel with nothing far
  * and nothing dropped where every pair of the grid stays inside a block's exponent span -- lambda * grid diagonal below ~600 --, the all-fp64 kernel of rounds 1-4 otherwise.)
- * step1_budget (ABI 5) moves AUTO's three thresholds together: a budget b puts the far threshold at e^-(8 - ln(b / 1e-8)), the a-posteriori test at b / 3e-6 and the
+ * step1_budget (ABI 5) moves AUTO's three thresholds together: a budget b puts the far threshold at e^-(8 - ln(b / 1e-8)), the a-posteriori test at b / eps_far (1e-6, growing with the far terms' exponent beyond 24) and the
  * drop threshold at b / 5.  (With SHM_DEBUG_KNOBS=1 in the environment, SHM_CONV_EXACT=1 forces EXACT_F64 whatever the caller asks: A/B runs and tests.) */
 enum { SHM_STEP1_AUTO = 0, SHM_STEP1_EXACT_F64 = 1 };
 
