@@ -382,12 +382,25 @@ def _adversarial_sources(kind, n, seed):
         base = 4 * np.pi * R * R * 0.7 / S
         area = base * 10.0 ** (-4.0 * rng.random(S))     # 1e4 : 1
         lam = 1.0 / np.sqrt(base)
+    elif kind == "shell":
+        # a closed, finely sampled surface seen from INSIDE (round 6, late): the interior's nodes are tens of kernel widths from the nearest source, thousands of sources
+        # lie within e^-8 ... e^-30 of it, and their terms cancel (outward normals: X would vanish for a uniform kernel) -- the place where the accumulation of the
+        # packed-fp32 sums in fp32 showed in SprayBottle.pc at 1024^3 (8.1e-9 of the 1e-8 budget until the sums were flushed into fp64 every 256 sources)
+        S = 40000
+        v = rng.normal(size=(S, 3))
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        ax3 = np.array([0.62, 0.5, 0.41])
+        pos = v * ax3 * (1.0 + 0.01 * rng.normal(size=(S, 1))) + np.array([0.03, -0.02, 0.04])
+        nrm = v / ax3
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        area = np.full(S, 4 * np.pi * 0.5 * 0.5 / S) * (0.7 + 0.6 * rng.random(S))
+        lam = 0.46 / cell
     else:
         raise ValueError(kind)
     return dict(pos=pos, wnormal=nrm * area[:, None], area=area, lam=float(lam), n=n, bbox_min=bbox_min, cell=cell)
 
 
-@pytest.mark.parametrize("kind,n", [("sheets:0.5", 128), ("sheets:1", 128), ("sheets:2", 256), ("sheets:4", 128), ("cloud", 256), ("cloud", 128), ("areas", 128), ("areas", 256)])
+@pytest.mark.parametrize("kind,n", [("sheets:0.5", 128), ("sheets:1", 128), ("sheets:2", 256), ("sheets:4", 128), ("cloud", 256), ("cloud", 128), ("areas", 128), ("areas", 256), ("shell", 256)])
 def test_tier_budget_on_adversarial_inputs(shm, kind, n):
     """The tiered Step 1 against the all-fp64 arithmetic (shm_opts.step1_arith = EXACT_F64) on seeded inputs built to break the tiers: cancelling sheets, exponents in the
     hundreds, weights over four decades.  The budget on Y holds where the all-fp64 field is finite, the non-finite sets agree, two default runs agree bit for bit; the margin
