@@ -1,0 +1,28 @@
+"""The 'shell' adversarial input of tests/test_gpu_parity.py (closed surface seen from inside) at other source counts and kernel widths: max|dY| of the tiered Step 1
+against the all-fp64 arithmetic.   python tools/r06_shell_probe.py [n]"""
+import os, sys
+import numpy as np
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+import shm_import
+shm = shm_import.load()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+cell = 2.0 / (n - 1)
+for S, lc in ((40000, 0.46), (160000, 0.46), (160000, 0.25), (40000, 0.15), (400000, 0.46), (160000, 1.0)):
+    rng = np.random.default_rng(7)
+    v = rng.normal(size=(S, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    ax3 = np.array([0.62, 0.5, 0.41])
+    pos = v * ax3 * (1.0 + 0.01 * rng.normal(size=(S, 1))) + np.array([0.03, -0.02, 0.04])
+    nrm = v / ax3; nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    area = np.full(S, 4 * np.pi * 0.25 / S) * (0.7 + 0.6 * rng.random(S))
+    lam = lc / cell
+    s = shm.GridSolver()
+    s.set_problem(pos, nrm * area[:, None], area, lam, n, np.array([-1.0, -1.0, -1.0]), cell)
+    s.run_conv(); Yt = np.stack([s.get_field(k) for k in (0, 1, 2)], axis=1)
+    st = s.last_stats() if hasattr(s, "last_stats") else None
+    s.run_conv(step1="exact_f64"); Ye = np.stack([s.get_field(k) for k in (0, 1, 2)], axis=1)
+    s.close()
+    ok = np.isfinite(Ye).all(1) & np.isfinite(Yt).all(1)
+    d = np.abs(Yt - Ye).max(axis=1); d[~ok] = 0
+    i = int(np.argmax(d))
+    print("shell S=%6d lambda*cell=%.2f n=%d: max|dY| %.2e at node (%d,%d,%d)  finite %.3f" % (S, lc, n, d.max(), i % n, (i // n) % n, i // (n * n), ok.mean()), flush=True)
