@@ -8,7 +8,10 @@ import shm_import
 shm = shm_import.load()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 cell = 2.0 / (n - 1)
-for S, lc in ((40000, 0.46), (160000, 0.46), (160000, 0.25), (40000, 0.15), (400000, 0.46), (160000, 1.0)):
+CASES = ((40000, 0.46), (160000, 0.46), (160000, 0.25), (40000, 0.15), (400000, 0.46), (160000, 1.0))
+if len(sys.argv) > 2:   # S lc S lc ...
+    CASES = tuple((int(sys.argv[i]), float(sys.argv[i + 1])) for i in range(2, len(sys.argv) - 1, 2))
+for S, lc in CASES:
     rng = np.random.default_rng(7)
     v = rng.normal(size=(S, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
     ax3 = np.array([0.62, 0.5, 0.41])
@@ -25,4 +28,11 @@ for S, lc in ((40000, 0.46), (160000, 0.46), (160000, 0.25), (40000, 0.15), (400
     ok = np.isfinite(Ye).all(1) & np.isfinite(Yt).all(1)
     d = np.abs(Yt - Ye).max(axis=1); d[~ok] = 0
     i = int(np.argmax(d))
-    print("shell S=%6d lambda*cell=%.2f n=%d: max|dY| %.2e at node (%d,%d,%d)  finite %.3f" % (S, lc, n, d.max(), i % n, (i // n) % n, i // (n * n), ok.mean()), flush=True)
+    from scipy.spatial import cKDTree
+    tree = cKDTree(pos)
+    top = np.argsort(-d)[:2000]
+    P = np.stack([top % n, (top // n) % n, top // (n * n)], axis=1) * cell - 1.0
+    lr = lam * tree.query(P)[0]
+    in_zone = lr < 335.0     # (beyond it the reference's own normalisation has lost its bits: DESIGN.md section 2a)
+    print("shell S=%6d lambda*cell=%.2f n=%d: max|dY| %.2e at node (%d,%d,%d) lambda r %.1f; over the 2000 worst nodes with lambda r < 335: %.2e  finite %.3f" % (
+        S, lc, n, d.max(), i % n, (i // n) % n, i // (n * n), lr[0], d[top][in_zone].max() if in_zone.any() else 0.0, ok.mean()), flush=True)
