@@ -467,7 +467,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
             if (drop_on && lane == 0) star_stash[wave] = float4{(cx - nx) * lam_l2, (cy - ny) * lam_l2, (cz - nz) * lam_l2, wnear};
         }
         const float span_c = uniform_f32(2.f * rt_w * lam_l2 - coff - 960.f);   // pass 1: a dropped source is evaluated only where its exponent stays inside the block's span
-        // pass 0: near sources in fp64, far ones in packed fp32.  pass 1 (only when the a-posteriori test failed): the far sources again, in fp64.
+        // pass 0: near sources in fp64, far ones in packed fp32.  pass 1 (only when the a-posteriori test failed): every source in fp64, from cleared accumulators.
         int far_pending = 0;
 #pragma unroll 1
         for (int pass = 0; pass < 2; pass++) {
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHM_TIER
         if (!CHECK) break;
         if (pass == 0) {
             // a-posteriori test of the far tier's contribution (see the header): eps_far L1_far <= budget |X| at every node of the block, or the far sources
-            // are evaluated again in fp64 (pass 1) and the packed-fp32 sums discarded
+            // -- near, far and dropped -- are evaluated again in fp64 (pass 1) and the sums of pass 0 discarded
             bool fail = false;
             const double e0 = far_scale();
             // what the block dropped, against |X| as well (round 6): its accumulated bound R is relative to the reference source's term at the node, evaluated here once per node
